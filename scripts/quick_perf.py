@@ -1,0 +1,44 @@
+"""Ad-hoc perf probe (development aid): forward/inverse device time for a few geometries."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from sdft_amd.sdft import SDFT
+from sdft_amd.signals import sine_sweep
+
+def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
+    td = np.float32 if combo[:3] == "f32" else np.float64
+    x = torch.from_numpy(np.stack([sine_sweep(n, dtype=td)] * channels) if channels > 1 else sine_sweep(n, dtype=td)).cuda()
+    p = SDFT(m, window, 1.0, combo, channels)
+    for k, v in opts.items(): p.set_option(k, v)
+    p.set_option("profile", 1); p.set_option("async", 1)
+    cdt = torch.complex128 if combo[3:] == "f64" else torch.complex64
+    shape = (n, m) if channels == 1 else (channels, n, m)
+    out = torch.empty(shape, dtype=cdt, device="cuda")
+    y = None
+    for _ in range(2):
+        p.sdft(x, out); y = p.isdft(out)
+    p.synchronize(); p.profile()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.sdft(x, out); p.isdft(out, y)
+    p.synchronize(); wall = (time.perf_counter() - t0) / reps
+    pr = p.profile()
+    esz = 16 if combo[3:] == "f64" else 8
+    byts = channels * n * (m * esz + x.element_size())
+    f = pr["forward"][0] / pr["forward"][1]; i = pr["inverse"][0] / pr["inverse"][1]
+    c = pr["carry"][0] / max(pr["carry"][1], 1); d = pr["delta"][0] / pr["delta"][1]
+    print(f"n={n} m={m} {window} {combo} ch={channels} opts={opts} chunks={p.get_option('last_chunks')} len={p.get_option('last_chunk_len')}: "
+          f"fwd {f:.3f} ms ({byts/f/1e9:.0f} GB/s, {channels*n/f/1e3:.1f} Msamp/s) carry {c:.3f} delta {d:.3f} inv {i:.3f} ms ({byts/i/1e9:.0f} GB/s) wall/iter {wall*1e3:.3f} ms", flush=True)
+    p.close(); del out
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "base":
+        run(48000, 1024)
+        run(1000000, 1024)
+        for tw in (4096, 8192, 32768, 65536):
+            run(1000000, 1024, target_waves=tw)
+        for il in (56, 60):
+            run(1000000, 1024, interior=il)
+        run(262144, 4096, "blackman", "f32f32")
+        run(48000, 1024, channels=64)

@@ -1,0 +1,82 @@
+"""Builds libsdft_hip.so (the C-ABI + HIP kernels) in-tree with hipcc for gfx950.
+
+    python -m sdft_amd.build [--force] [--save-temps]
+
+The library has no Python or torch dependency; it is what a C host links against
+(INTEGRATION.md).  -ffp-contract=off is part of the numerical contract: the kernels must not
+fuse a*b+c, otherwise float-FD results drift from the reference by more than the parity bar
+(hard part 1).
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libsdft_hip.so")
+ARCH = "gfx950"
+COMBOS = ("f32f64", "f32f32", "f64f64", "f64f32")
+SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
+HEADERS = ["sdft_kernels.hpp", "sdft_plan.hpp", "sdft_capi.inc"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libsdft_hip.so cannot be built (no CPU fallback exists)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """Compile (if stale) and return the path of libsdft_hip.so."""
+    if not force and not _stale():
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    obj_dir = os.path.join(OUT_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [cc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if save_temps:
+            cmd.insert(1, "-save-temps=obj")
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=obj_dir)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    # -no-hip-rt: no DT_NEEDED on a particular libamdhip64.  A process must hold exactly one HIP
+    # runtime (two cannot both open the GPU); PyTorch wheels bundle their own under a different
+    # soname than /opt/rocm's.  The host decides: a C program links -lamdhip64 itself
+    # (INTEGRATION.md), capi.load() binds to the runtime already loaded in the interpreter.
+    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lm"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,157 @@
+"""ctypes binding of the C-ABI in ``libsdft_hip.so`` (``include/sdft/sdft.h`` + ``sdft_hip.h``).
+
+This is the same boundary a C host links against; nothing here computes anything.  There is no
+CPU fallback: if the library is missing or no GPU is present, calls fail loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+COMBOS = _build.COMBOS
+WINDOWS = {"boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3}   # sdft.h:127-133 of the reference
+STAGES = ("delta", "carry", "forward", "inverse")
+
+# every typed entry point exported per (td, fd) combination:  name -> (restype, argtypes)
+_TD = {"f32": C.c_float, "f64": C.c_double}
+_FD = {"f32": C.c_float, "f64": C.c_double}
+
+
+def typed_signatures(combo: str):
+    td, fd = _TD[combo[:3]], _FD[combo[3:]]
+    vp, sz = C.c_void_p, C.c_size_t
+    return {
+        # drop-in surface (reference sdft.h:413-687)
+        "alloc": (vp, [sz]),
+        "alloc_custom": (vp, [sz, C.c_int, C.c_double]),
+        "free": (None, [vp]),
+        "reset": (None, [vp]),
+        "size": (sz, [vp]),
+        "window": (C.c_int, [vp]),
+        "latency": (C.c_double, [vp]),
+        "sdft": (None, [vp, td, vp]),
+        "sdft_n": (None, [vp, sz, vp, vp]),
+        "sdft_nd": (None, [vp, sz, vp, vp]),
+        "isdft": (td, [vp, vp]),
+        "isdft_n": (None, [vp, sz, vp, vp]),
+        "isdft_nd": (None, [vp, sz, vp, vp]),
+        # additions
+        "alloc_batch": (vp, [sz, C.c_int, C.c_double, sz]),
+        "channels": (sz, [vp]),
+        "set_stream": (C.c_int, [vp, vp]),
+        "get_stream": (vp, [vp]),
+        "synchronize": (C.c_int, [vp]),
+        "set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
+        "get_option": (C.c_long, [vp, C.c_char_p]),
+        "get_profile": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+        "get_state": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
+        "plan_tables": (C.c_int, [sz, C.c_double, vp, vp, vp, vp]),
+    }
+
+
+UNTYPED = {
+    "sdft_hip_last_error": (C.c_char_p, []),
+    "sdft_hip_clear_error": (None, []),
+    "sdft_hip_device_count": (C.c_int, []),
+    "sdft_hip_set_device": (C.c_int, [C.c_int]),
+    "sdft_hip_get_device": (C.c_int, []),
+    "sdft_hip_version": (C.c_char_p, []),
+    "sdft_hip_selftest": (C.c_int, []),
+}
+
+
+def symbol(name: str, combo: str) -> str:
+    return f"sdft_hip_{name}_{combo}"
+
+
+class SdftHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.environ.get("SDFT_HIP_LIBRARY", _build.LIB)
+
+
+def _bind_hip_runtime() -> str:
+    """Make exactly one HIP runtime visible (RTLD_GLOBAL) before libsdft_hip.so is loaded.
+
+    libsdft_hip.so carries no DT_NEEDED for libamdhip64 (see build.py).  If PyTorch is in the
+    process its bundled runtime must be the one (a second runtime cannot open the GPU), otherwise
+    the system ROCm runtime is used.
+    """
+    import sys
+    cands = []
+    if "torch" not in sys.modules and not os.environ.get("SDFT_HIP_NO_TORCH"):
+        try:                        # PyTorch may be imported later by the same process: settle on its
+            import torch  # noqa: F401   runtime now, or its CUDA init would find the GPU already taken
+        except Exception:
+            pass
+    if "torch" in sys.modules:
+        tl = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib")
+        cands.append(os.path.join(tl, "libamdhip64.so"))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return c
+        except OSError:
+            continue
+    raise SdftHipError("no HIP runtime (libamdhip64.so) could be loaded")
+
+
+hip_runtime = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load libsdft_hip.so and declare every prototype; raises if it cannot be had."""
+    global _lib, hip_runtime
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise SdftHipError(f"{path} not found; run `python -m sdft_amd.build`")
+        path = _build.build()
+    hip_runtime = _bind_hip_runtime()
+    lib = C.CDLL(path)
+    for name, (res, args) in UNTYPED.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for combo in COMBOS:
+        for name, (res, args) in typed_signatures(combo).items():
+            fn = getattr(lib, symbol(name, combo))
+            fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class Api:
+    """The typed entry points of one (td, fd) combination as attributes: ``api.sdft_n(...)``."""
+
+    def __init__(self, combo: str = "f32f64"):
+        if combo not in COMBOS:
+            raise ValueError(f"unknown type combination {combo!r}; expected one of {COMBOS}")
+        self.combo = combo
+        self.lib = load()
+        for name in typed_signatures(combo):
+            setattr(self, name, getattr(self.lib, symbol(name, combo)))
+
+    def last_error(self):
+        e = self.lib.sdft_hip_last_error()
+        return e.decode() if e else None
+
+    def check(self):
+        """Raise if the library recorded an error on this thread (the C API itself never aborts)."""
+        e = self.last_error()
+        if e:
+            self.lib.sdft_hip_clear_error()
+            raise SdftHipError(e)

@@ -1,0 +1,554 @@
+// sdft_kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4) implementing the modulated
+// Sliding DFT hot path.  Citations are into /root/reference/c/src/sdft/sdft.h.
+//
+// Work decomposition:
+//   lanes      <-> frequency bins (one complex bin per lane for 16-byte bins, two adjacent
+//                  bins per lane for 8-byte bins, so a wave always stores 16 B per lane),
+//   wave loop  <-> time: the sample loop is carried inside the kernel,
+//   grid       <-> bin tiles x time chunks x channels.
+// A wave owns 64 lanes of which the outer ones are *halo* lanes: they run the recurrence of the
+// neighbouring (or mirrored) bins redundantly so that the 3/5-tap spectral window needs no LDS
+// and no barrier -- neighbours are fetched with DPP wave shifts (v_mov_b32_dpp wave_shr/shl).
+// The per-sample input difference is wave-uniform and arrives through the scalar cache
+// (s_load), twiddles/state live in VGPRs for the whole chunk.
+//
+// Arithmetic follows the reference's struct-complex formulas operation by operation and the
+// translation units are compiled with -ffp-contract=off: given the same carry-in a wave
+// reproduces the reference bit for bit.
+
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace sdfthip {
+
+#define SDFT_HD __host__ __device__ __forceinline__
+#define SDFT_D  __device__ __forceinline__
+
+template <typename T> struct cx { T re, im; };
+
+// sdft.h:265-331 (SDFT_NO_COMPLEX_H formulas)
+template <typename T> SDFT_HD cx<T> cmake(T re, T im) { cx<T> z; z.re = re; z.im = im; return z; }
+template <typename T> SDFT_HD cx<T> cadd(cx<T> a, cx<T> b) { return cmake<T>(a.re + b.re, a.im + b.im); }
+template <typename T> SDFT_HD cx<T> csub(cx<T> a, cx<T> b) { return cmake<T>(a.re - b.re, a.im - b.im); }
+template <typename T> SDFT_HD cx<T> cmul(cx<T> a, cx<T> b) { return cmake<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+template <typename T> SDFT_HD cx<T> cscale(cx<T> a, T s) { return cmake<T>(a.re * s, a.im * s); }
+template <typename T> SDFT_HD cx<T> cconj(cx<T> a) { return cmake<T>(a.re, -a.im); }
+
+enum : int { WIN_BOXCAR = 0, WIN_HANN = 1, WIN_HAMMING = 2, WIN_BLACKMAN = 3 };   // sdft.h:127-133
+
+template <int WIN> struct win_halo { static constexpr int value = (WIN == WIN_BLACKMAN) ? 2 : (WIN == WIN_BOXCAR ? 0 : 1); };
+
+// Wave-uniform read-only streams (the per-sample differences) are read through the constant
+// address space so that the compiler keeps them on the scalar unit (s_load via the scalar cache)
+// even though the kernel also stores to global memory.  Legal because no kernel writes a buffer
+// it reads this way.
+#define SDFT_CONSTANT __attribute__((address_space(4)))
+template <typename T> SDFT_D const SDFT_CONSTANT T* as_uniform(const T* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const SDFT_CONSTANT T*)p;
+#pragma clang diagnostic pop
+}
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kGroup = 8;                // samples per scalar-load burst in the time loop
+
+// ------------------------------------------------------------------------------------------
+// cross-lane neighbour fetch: lane i <- lane i-1 (from_below) / lane i+1 (from_above).
+// gfx950 is a GFX9-family ISA and still has the whole-wave DPP shifts.
+// ------------------------------------------------------------------------------------------
+#if defined(SDFT_NEIGHBOUR_BPERMUTE)
+SDFT_D int lane_from_below(int v) { return __shfl_up(v, 1, 64); }
+SDFT_D int lane_from_above(int v) { return __shfl_down(v, 1, 64); }
+#else
+SDFT_D int lane_from_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+SDFT_D int lane_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
+#endif
+
+SDFT_D float from_below(float v) { return __int_as_float(lane_from_below(__float_as_int(v))); }
+SDFT_D float from_above(float v) { return __int_as_float(lane_from_above(__float_as_int(v))); }
+SDFT_D double from_below(double v)
+{
+  const int lo = lane_from_below(__double2loint(v)), hi = lane_from_below(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+SDFT_D double from_above(double v)
+{
+  const int lo = lane_from_above(__double2loint(v)), hi = lane_from_above(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <typename T> SDFT_D cx<T> from_below(cx<T> z) { return cmake<T>(from_below(z.re), from_below(z.im)); }
+template <typename T> SDFT_D cx<T> from_above(cx<T> z) { return cmake<T>(from_above(z.re), from_above(z.im)); }
+
+// ------------------------------------------------------------------------------------------
+// index reflection for the halo (sdft.h:589-595): X[-i] = conj X[i], X[N-1+i] = conj X[N-1-i],
+// iterated for tiny N.  Returns the source bin, sets `flip` when an odd number of conjugations
+// applies.  (N == 1 is special: the reference's halo cells stay zero -- handled by the caller.)
+// ------------------------------------------------------------------------------------------
+SDFT_HD long reflect_bin(long k, long nbins, bool& flip)
+{
+  flip = false;
+  if (nbins <= 1) return 0;                 // N == 1: reflections about bin 0 never settle; caller zeroes the halo
+  while (k < 0 || k > nbins - 1)
+  {
+    k = (k < 0) ? -k : 2 * (nbins - 1) - k;
+    flip = !flip;
+  }
+  return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0  delta + delay line  (sdft.h:186-191, :564)
+//   delta[t] = (FD)( x[t] - x[t-2N] ), the subtraction in TD precision.
+//   hist is the delay line kept in time order (oldest first); a second buffer receives the
+//   last 2N samples of (hist ++ x) for the next call.
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD>
+__global__ __launch_bounds__(kBlock) void delta_kernel(const TD* __restrict__ x, size_t x_stride,
+                                                       const TD* __restrict__ hist_in, TD* __restrict__ hist_out,
+                                                       FD* __restrict__ delta, size_t n, size_t span /*2N*/)
+{
+  const size_t ch = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const TD* xs = x + ch * x_stride;
+  const TD* hi = hist_in + ch * span;
+  if (i < n)
+  {
+    const TD cur = xs[i];
+    const TD old = (i < span) ? hi[i] : xs[i - span];
+    const TD d = cur - old;                       // TD precision
+    delta[ch * n + i] = (FD)d;
+  }
+  if (i < span)
+  {
+    // element i of the new history = element (n + i) of the concatenation hist ++ x, minus span
+    const size_t j = n + i;
+    hist_out[ch * span + i] = (j >= span) ? xs[j - span] : hi[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// shared pieces of the recurrence
+// ------------------------------------------------------------------------------------------
+template <typename FD> struct BinState { cx<FD> acc, fid, tw; };
+
+// normal step (sdft.h:583-585) -- returns the demodulated bin
+template <typename FD> SDFT_D cx<FD> step_normal(BinState<FD>& s, FD delta)
+{
+  s.acc = cadd(s.acc, cscale(s.fid, delta));
+  s.fid = cmul(s.fid, s.tw);
+  return cmul(s.acc, cconj(s.fid));
+}
+// roll-over step (sdft.h:572-574)
+template <typename FD> SDFT_D cx<FD> step_wrap(BinState<FD>& s, FD delta)
+{
+  s.acc = cadd(s.acc, cscale(s.fid, delta));
+  s.fid = cmake<FD>((FD)1, (FD)0);
+  return s.acc;
+}
+// recurrence without the demodulation (carry passes)
+template <typename FD> SDFT_D void advance_normal(BinState<FD>& s, FD delta)
+{
+  s.acc = cadd(s.acc, cscale(s.fid, delta));
+  s.fid = cmul(s.fid, s.tw);
+}
+template <typename FD> SDFT_D void advance_wrap(BinState<FD>& s, FD delta)
+{
+  s.acc = cadd(s.acc, cscale(s.fid, delta));
+  s.fid = cmake<FD>((FD)1, (FD)0);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a (fast carry, FD double): per (chunk, bin) partial sums of delta*fid over one chunk,
+// written to carry[ch][chunk+1][k]; K1b turns them into carry-ins by an exclusive scan over
+// chunks.  fid is seeded from the table W[j] = exp(-i*pi*j/N), j = k*cursor mod 2N, and then
+// advanced exactly like the main kernel does, so both see the same rotation sequence.
+// ------------------------------------------------------------------------------------------
+template <typename FD> struct CarryArgs
+{
+  const FD* delta;            // [channels][n]
+  const cx<FD>* tw;           // [N]
+  const cx<FD>* wtab;         // [2N]
+  cx<FD>* carry;              // [channels][chunks][N]
+  cx<FD>* seed;               // [channels][chunks][N]   (exact mode only)
+  const cx<FD>* acc_state;    // [channels][N]
+  const cx<FD>* fid_state;    // [channels][N]
+  size_t n;
+  unsigned nbins, chunks, chunk_len, cursor0;
+};
+
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
+{
+  const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned j = blockIdx.y;            // chunk 0 .. chunks-2
+  const size_t ch = blockIdx.z;
+  const unsigned kk = k < a.nbins ? k : a.nbins - 1;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  const size_t t0 = (size_t)j * a.chunk_len, t1 = t0 + a.chunk_len;
+  unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
+
+  BinState<FD> s;
+  s.acc = cmake<FD>((FD)0, (FD)0);
+  s.tw = a.tw[kk];
+  s.fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+  const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+
+  size_t t = t0;
+  while (t < t1)
+  {
+    size_t run = maxc - c;
+    if (run > t1 - t) run = t1 - t;
+    for (size_t i = 0; i < run; ++i) advance_normal(s, d[t + i]);
+    t += run; c += (unsigned)run;
+    if (t < t1) { advance_wrap(s, d[t]); ++t; c = 0; }
+  }
+  if (k < a.nbins)
+    a.carry[(ch * a.chunks + (j + 1)) * a.nbins + k] = s.acc;
+}
+
+// K1b: carry[0] = acc_state, carry[j] = carry[j-1] + partial[j-1]  (in place)
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void carry_scan_kernel(CarryArgs<FD> a)
+{
+  const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+  const size_t ch = blockIdx.y;
+  if (k >= a.nbins) return;
+  cx<FD>* col = a.carry + ch * a.chunks * a.nbins + k;
+  cx<FD> run = a.acc_state[ch * a.nbins + k];
+  col[0] = run;
+  for (unsigned j = 1; j < a.chunks; ++j)
+  {
+    run = cadd(run, col[(size_t)j * a.nbins]);
+    col[(size_t)j * a.nbins] = run;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a' (exact carry): time-serial per (channel, bin); reproduces the reference's rounding
+// sequence of acc and fid and records both at every chunk start.  Used for FD float, where the
+// 1e-4 parity bar is tighter than float's own accumulation error.
+// ------------------------------------------------------------------------------------------
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void carry_exact_kernel(CarryArgs<FD> a)
+{
+  const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+  const size_t ch = blockIdx.y;
+  const unsigned kk = k < a.nbins ? k : a.nbins - 1;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  BinState<FD> s;
+  s.acc = a.acc_state[ch * a.nbins + kk];
+  s.fid = a.fid_state[ch * a.nbins + kk];
+  s.tw = a.tw[kk];
+  const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+  unsigned c = a.cursor0;
+  size_t t = 0;
+  for (unsigned j = 0; j < a.chunks; ++j)
+  {
+    if (k < a.nbins)
+    {
+      const size_t o = (ch * a.chunks + j) * a.nbins + k;
+      a.carry[o] = s.acc;
+      a.seed[o] = s.fid;
+    }
+    if (j + 1 == a.chunks) break;               // the main kernel runs the last chunk itself
+    const size_t t1 = t + a.chunk_len;
+    while (t < t1)
+    {
+      size_t run = maxc - c;
+      if (run > t1 - t) run = t1 - t;
+      for (size_t i = 0; i < run; ++i) advance_normal(s, d[t + i]);
+      t += run; c += (unsigned)run;
+      if (t < t1) { advance_wrap(s, d[t]); ++t; c = 0; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// spectral window (sdft.h:350-402); e[] holds X[k-2] .. X[k+2] at index 0..4
+// ------------------------------------------------------------------------------------------
+template <typename FD, int WIN> SDFT_D cx<FD> window_tap(cx<FD> m2, cx<FD> m1, cx<FD> c0, cx<FD> p1, cx<FD> p2, FD w)
+{
+  if constexpr (WIN == WIN_HANN)
+  {
+    const cx<FD> a = cadd(c0, c0);
+    const cx<FD> b = cadd(m1, p1);
+    return cscale(csub(a, b), w);                       // w = weight * 0.25, formed on the host
+  }
+  else if constexpr (WIN == WIN_HAMMING)
+  {
+    const cx<FD> a = cscale(c0, (FD)(0.54));
+    const cx<FD> b = cscale(cadd(m1, p1), (FD)(0.23));
+    return cscale(csub(a, b), w);
+  }
+  else if constexpr (WIN == WIN_BLACKMAN)
+  {
+    const cx<FD> a = cscale(c0, (FD)(0.42));
+    const cx<FD> b = cscale(cadd(m1, p1), (FD)(0.25));
+    const cx<FD> d = cscale(cadd(m2, p2), (FD)(0.04));
+    return cscale(cadd(csub(a, b), d), w);
+  }
+  else
+  {
+    return cscale(c0, w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  forward: recurrence + mirror + window + coalesced store of the (n, N) matrix
+// ------------------------------------------------------------------------------------------
+template <typename FD> struct ForwardArgs
+{
+  const FD* delta;            // [channels][n]
+  const cx<FD>* tw;           // [N]
+  const cx<FD>* wtab;         // [2N]   (used when seed == nullptr)
+  const cx<FD>* carry;        // [channels][chunks][N]
+  const cx<FD>* seed;         // [channels][chunks][N] or nullptr
+  cx<FD>* out;                // rows: out + ch*out_stride + t*N
+  size_t out_stride;
+  cx<FD>* const* out_rows;    // optional row-pointer table [channels*n] (sdft_sdft_nd); nullptr = dense
+  cx<FD>* acc_state;          // [channels][N]  written by the last chunk
+  cx<FD>* fid_state;
+  size_t n;
+  unsigned long long total_waves;
+  unsigned nbins, chunks, chunk_len, tiles, interior_lanes, cursor0;
+  int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
+  FD wscale;                  // weight (or weight*0.25 for Hann)
+};
+
+template <typename FD, int BPL> struct StoreVec;
+template <> struct StoreVec<double, 1> { using type = double2; };
+template <> struct StoreVec<float, 2>  { using type = float4; };
+template <> struct StoreVec<float, 1>  { using type = float2; };
+template <> struct StoreVec<double, 2> { using type = double2; };
+
+template <typename FD, int BPL, int WIN, bool ROWS>
+__global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
+{
+  constexpr int H = win_halo<WIN>::value;                 // halo bins per side
+  constexpr int HL = (H + BPL - 1) / BPL;                 // halo lanes per side
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long wave = (unsigned long long)blockIdx.x * kWavesPerBlock + wib;
+  if (wave >= a.total_waves) return;
+
+  const unsigned tile = (unsigned)(wave % a.tiles);
+  const unsigned long long rest = wave / a.tiles;
+  const unsigned chunk = (unsigned)(rest % a.chunks);
+  const size_t ch = (size_t)(rest / a.chunks);
+
+  const long nbins = (long)a.nbins;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  const size_t t0 = (size_t)chunk * a.chunk_len;
+  const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
+  unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
+
+  // lane -> bins
+  const long kfirst = (long)tile * a.interior_lanes * BPL + (long)(lane - HL) * BPL;
+  const bool owner = (lane >= HL) && (lane < HL + (int)a.interior_lanes);
+
+  BinState<FD> s[BPL];
+  bool flip[BPL], live[BPL], keep[BPL];
+  const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+  {
+    const long k = kfirst + b;
+    const long kk = reflect_bin(k, nbins, flip[b]);
+    live[b] = !(nbins == 1 && k != 0);                    // N == 1: halo cells are zero for ever
+    keep[b] = owner && k >= 0 && k < nbins;
+    s[b].tw = a.tw[kk];
+    s[b].acc = a.carry[cbase + kk];
+    s[b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+  }
+
+  const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+  const FD w = a.wscale;
+  const bool last_chunk = (chunk + 1 == a.chunks);
+
+  // destination of this lane's first bin in row t0
+  cx<FD>* dst = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + kfirst;
+  // ROWS: destination rows come from a pointer table (sdft_sdft_nd); kept out of the dense
+  // instantiation so that its stores stay global_store_dwordx4 (a loaded pointer would force flat)
+  cx<FD>* const* rows = ROWS ? a.out_rows + ch * a.n : nullptr;
+
+  auto emit = [&](cx<FD> (&x)[BPL], size_t t)
+  {
+    // mirror lanes conjugate; N == 1 halo is zero
+#pragma unroll
+    for (int b = 0; b < BPL; ++b)
+    {
+      if (flip[b]) x[b].im = -x[b].im;
+      if (!live[b]) x[b] = cmake<FD>((FD)0, (FD)0);
+    }
+    // gather X[k-2..k+2] for every bin of the lane
+    cx<FD> e[BPL + 4] = {};
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
+    if constexpr (H >= 1)
+    {
+      e[1] = from_below(x[BPL - 1]);             // X[k-1] of the lane's first bin
+      e[BPL + 2] = from_above(x[0]);             // X[k+1] of the lane's last bin
+    }
+    if constexpr (H >= 2)
+    {
+      if constexpr (BPL >= 2)
+      {
+        e[0] = from_below(x[BPL - 2]);
+        e[BPL + 3] = from_above(x[1]);
+      }
+      else
+      {
+        e[0] = from_below(e[1]);                 // two lanes down
+        e[BPL + 3] = from_above(e[BPL + 2]);     // two lanes up
+      }
+    }
+    cx<FD> y[BPL];
+#pragma unroll
+    for (int b = 0; b < BPL; ++b)
+      y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+
+    cx<FD>* p = dst;
+    if constexpr (ROWS) p = rows[t] + kfirst;
+    if constexpr (BPL == 2)
+    {
+      if (a.vec_store && !ROWS)
+      {
+        if (keep[0])
+        {
+          using V = typename StoreVec<FD, 2>::type;
+          V v; v.x = y[0].re; v.y = y[0].im; v.z = y[1].re; v.w = y[1].im;
+          *reinterpret_cast<V*>(p) = v;
+        }
+      }
+      else
+      {
+        if (keep[0]) p[0] = y[0];
+        if (keep[1]) p[1] = y[1];
+      }
+    }
+    else
+    {
+      if (keep[0]) p[0] = y[0];
+    }
+    dst += a.nbins;
+  };
+
+  size_t t = t0;
+  while (t < t1)
+  {
+    size_t run = maxc - c;
+    if (run > t1 - t) run = t1 - t;
+    size_t i = 0;
+    for (; i + kGroup <= run; i += kGroup)          // one s_load burst per kGroup samples
+    {
+      FD dl[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) dl[u] = d[t + i + u];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u)
+      {
+        cx<FD> x[BPL];
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) x[b] = step_normal(s[b], dl[u]);
+        emit(x, t + i + u);
+      }
+    }
+    for (; i < run; ++i)
+    {
+      const FD dl = d[t + i];
+      cx<FD> x[BPL];
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) x[b] = step_normal(s[b], dl);
+      emit(x, t + i);
+    }
+    t += run; c += (unsigned)run;
+    if (t < t1)
+    {
+      const FD dl = d[t];
+      cx<FD> x[BPL];
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) x[b] = step_wrap(s[b], dl);
+      emit(x, t);
+      ++t; c = 0;
+    }
+  }
+
+  if (last_chunk)
+  {
+#pragma unroll
+    for (int b = 0; b < BPL; ++b)
+      if (keep[b])
+      {
+        a.acc_state[ch * a.nbins + kfirst + b] = s[b].acc;
+        a.fid_state[ch * a.nbins + kfirst + b] = s[b].fid;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  inverse (sdft.h:635-657): one wave per row, 16-byte coalesced loads, per-lane strided
+// partial sums, wave reduction by cross-lane shuffles, lane 0 scales and stores one TD sample.
+// Summation order differs from the reference's serial bin loop.
+// ------------------------------------------------------------------------------------------
+template <typename FD> SDFT_D FD wave_sum(FD v)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename TD, typename FD> struct InverseArgs
+{
+  const cx<FD>* in;           // rows: in + ch*in_stride + t*N
+  size_t in_stride;
+  const cx<FD>* const* in_rows;   // optional row-pointer table (sdft_isdft_nd)
+  const cx<FD>* syn;          // [N]
+  TD* y;                      // y + ch*y_stride + t
+  size_t y_stride;
+  size_t n;
+  unsigned nbins, channels;
+  FD sweight;
+};
+
+template <typename TD, typename FD, bool LAT1>
+__global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  const size_t rows = (size_t)a.channels * a.n;
+  const FD sign = (lane & 1) ? (FD)(-1) : (FD)(+1);          // k % 2 == lane % 2 (sdft.h:643)
+
+  for (size_t r = (size_t)blockIdx.x * kWavesPerBlock + wib; r < rows; r += nwaves)
+  {
+    const size_t ch = r / a.n, t = r - ch * a.n;
+    const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
+    FD part = (FD)0;
+#pragma unroll 4
+    for (unsigned k = lane; k < a.nbins; k += kWave)
+    {
+      const cx<FD> v = row[k];
+      if constexpr (LAT1)
+        part += v.re * sign;
+      else
+      {
+        const cx<FD> s = a.syn[k];
+        part += v.re * s.re - v.im * s.im;                    // real part of sdft.h:650
+      }
+    }
+    const FD sum = wave_sum(part);
+    if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);
+  }
+}
+
+}  // namespace sdfthip

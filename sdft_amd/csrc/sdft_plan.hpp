@@ -1,0 +1,606 @@
+// sdft_plan.hpp -- host side of the HIP engine: plan tables, device-resident stream state,
+// chunk geometry, kernel launches.  One instance per (TD, FD) pair, see sdft_capi.inc.
+// Citations are into /root/reference/c/src/sdft/sdft.h.
+
+#pragma once
+
+#include "sdft_kernels.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace sdfthip {
+
+// ---- error channel (the reference has none: void returns, sdft.h:413-687) -----------------
+void set_error(const char* what, const char* detail);   // sdft_common.hip
+bool lane_selftest();                                   // sdft_common.hip
+
+#define SDFT_TRY(expr)                                                        \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) { set_error(#expr, hipGetErrorString(e_)); return false; } \
+  } while (0)
+
+// ---- plan tables: the reference's own expressions (sdft.h:422-423, :439-446) evaluated on the
+// host with the host libm, so the device tables are bit-identical to the oracle's ------------
+template <typename FD> static inline FD host_cos(FD a);
+template <> inline float  host_cos<float>(float a)   { return cosf(a); }
+template <> inline double host_cos<double>(double a) { return cos(a); }
+template <typename FD> static inline FD host_sin(FD a);
+template <> inline float  host_sin<float>(float a)   { return sinf(a); }
+template <> inline double host_sin<double>(double a) { return sin(a); }
+template <typename FD> static inline FD host_acos(FD a);
+template <> inline float  host_acos<float>(float a)   { return acosf(a); }
+template <> inline double host_acos<double>(double a) { return acos(a); }
+
+// polar(r, t) of sdft.h:333-348.  The canonical oracle build (gcc -O2) merges the
+// cos(t)/sin(t) pair into one glibc sincos() call, whose results differ from separate calls in
+// the last bit for a few arguments; calling sincos explicitly keeps the tables bit-identical.
+template <typename FD> static inline cx<FD> host_polar(FD r, FD t);
+template <> inline cx<float> host_polar<float>(float r, float t)
+{
+  float s, c; sincosf(t, &s, &c); return cmake<float>(r * c, r * s);
+}
+template <> inline cx<double> host_polar<double>(double r, double t)
+{
+  double s, c; sincos(t, &s, &c); return cmake<double>(r * c, r * s);
+}
+
+template <typename FD>
+struct Tables
+{
+  FD aweight, sweight;
+  std::vector<cx<FD>> tw, syn, wtab;
+
+  void build(size_t nbins, double latency)
+  {
+    aweight = (FD)(1) / (nbins * 2);                                    // :422
+    sweight = (FD)(2);                                                  // :423
+    tw.resize(nbins); syn.resize(nbins); wtab.resize(nbins * 2);
+    const FD omega = (FD)(-2) * host_acos<FD>((FD)(-1)) / (nbins * 2);  // :439
+    const FD gain = (FD)(+2) / ((FD)(1) - host_cos<FD>((FD)(omega * nbins * latency)));   // :440
+    for (size_t k = 0; k < nbins; ++k)
+    {
+      const FD a = omega * k;                                           // :444
+      const FD s = (FD)(omega * k * nbins * latency);                   // :445 (fd products, then * double)
+      tw[k] = host_polar<FD>((FD)(1), a);
+      syn[k] = host_polar<FD>(gain, s);
+    }
+    // W[j] = exp(-i*pi*j/N), j in [0, 2N): closed form of fid after j mod 2N rotations of bin 1
+    // (only used to seed time chunks in the fast-carry mode)
+    for (size_t j = 0; j < nbins * 2; ++j)
+    {
+      const double a = -3.14159265358979323846 * (double)j / (double)nbins;
+      wtab[j] = (j < nbins) ? tw[j] : cmake<FD>((FD)cos(a), (FD)sin(a));
+    }
+  }
+};
+
+enum CarryMode : int { CARRY_FAST = 0, CARRY_EXACT = 1 };
+
+enum ProfileStage : int { ST_DELTA = 0, ST_CARRY = 1, ST_FORWARD = 2, ST_INVERSE = 3, ST_COUNT = 4 };
+
+struct PtrKind { bool device; };
+static inline bool is_device_pointer(const void* p)
+{
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  const hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+template <typename T> struct DevBuf
+{
+  T* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t count)
+  {
+    if (count <= cap) return true;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    SDFT_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    cap = count;
+    return true;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename TD, typename FD>
+class Plan
+{
+ public:
+  using fdx = cx<FD>;
+
+  size_t nbins = 0, channels = 1;
+  int window = WIN_HANN;
+  double latency = 1.0;
+  Tables<FD> tab;
+
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false, async = false;
+
+  // options
+  int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
+  long opt_chunk = 0;            // forced chunk length (0 = heuristic)
+  long opt_interior = 0;         // forced interior lanes per wave (0 = maximum)
+  long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
+  size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
+  bool profile = false;
+
+  // device-resident stream state
+  DevBuf<fdx> d_tw, d_syn, d_wtab, d_acc, d_fid;
+  DevBuf<TD> d_hist[2];
+  int hist_cur = 0;
+  size_t cursor = 0;             // reference cursor (:153)
+
+  // workspace
+  DevBuf<FD> d_delta;
+  DevBuf<fdx> d_carry, d_seed;
+  DevBuf<TD> d_stage_td;
+  DevBuf<fdx> d_stage_fdx;
+  DevBuf<fdx*> d_rowptr;
+
+  // profile: HIP events on the plan's stream, one pair per stage launch, collected lazily so
+  // that back-to-back asynchronous calls are never serialised by the measurement
+  std::vector<hipEvent_t> ev_pool[ST_COUNT];
+  size_t ev_used[ST_COUNT] = {};
+  double prof_ms[ST_COUNT] = {};
+  long prof_calls[ST_COUNT] = {};
+
+  // last launch geometry (introspection for tests / bench)
+  long last_chunks = 0, last_chunk_len = 0, last_tiles = 0, last_interior = 0;
+
+  bool create(size_t dftsize, int win, double lat, size_t nch)
+  {
+    nbins = dftsize; window = win; latency = lat; channels = nch ? nch : 1;
+    if (window < 0 || window > 3) window = WIN_BOXCAR;      // reference: unknown window -> default branch (:394)
+    tab.build(nbins, latency);
+    SDFT_TRY(hipGetDevice(&device));
+    if (!lane_selftest()) return false;
+    SDFT_TRY(hipStreamCreate(&stream));
+    own_stream = true;
+    if (const char* e = getenv("SDFT_HIP_CARRY"))
+      carry_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? CARRY_EXACT : CARRY_FAST;
+    if (sizeof(FD) == 4) carry_mode = CARRY_EXACT;         // float FD must follow the reference's rounding
+    if (const char* e = getenv("SDFT_HIP_CHUNK")) opt_chunk = atol(e);
+    if (const char* e = getenv("SDFT_HIP_INTERIOR")) opt_interior = atol(e);
+    if (const char* e = getenv("SDFT_HIP_TARGET_WAVES")) opt_target_waves = atol(e);
+    if (nbins == 0) return true;
+    const size_t nb = nbins, span = 2 * nbins;
+    if (!d_tw.reserve(nb) || !d_syn.reserve(nb) || !d_wtab.reserve(span)) return false;
+    if (!d_acc.reserve(channels * nb) || !d_fid.reserve(channels * nb)) return false;
+    if (!d_hist[0].reserve(channels * span) || !d_hist[1].reserve(channels * span)) return false;
+    SDFT_TRY(hipMemcpyAsync(d_tw.p, tab.tw.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    SDFT_TRY(hipMemcpyAsync(d_syn.p, tab.syn.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    SDFT_TRY(hipMemcpyAsync(d_wtab.p, tab.wtab.data(), span * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    return reset();
+  }
+
+  void destroy()
+  {
+    if (stream) (void)hipStreamSynchronize(stream);
+    d_tw.release(); d_syn.release(); d_wtab.release(); d_acc.release(); d_fid.release();
+    d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
+    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release();
+    for (int st = 0; st < ST_COUNT; ++st)
+    {
+      for (hipEvent_t e : ev_pool[st]) (void)hipEventDestroy(e);
+      ev_pool[st].clear(); ev_used[st] = 0;
+    }
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+
+  // sdft.h:517-529
+  bool reset()
+  {
+    cursor = 0; hist_cur = 0;
+    if (nbins == 0) return true;
+    const size_t nb = nbins, span = 2 * nbins;
+    SDFT_TRY(hipMemsetAsync(d_hist[0].p, 0, channels * span * sizeof(TD), stream));
+    SDFT_TRY(hipMemsetAsync(d_acc.p, 0, channels * nb * sizeof(fdx), stream));
+    std::vector<fdx> ones(channels * nb, cmake<FD>((FD)1, (FD)0));
+    SDFT_TRY(hipMemcpyAsync(d_fid.p, ones.data(), ones.size() * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    SDFT_TRY(hipStreamSynchronize(stream));
+    return true;
+  }
+
+  bool set_stream(hipStream_t s)
+  {
+    if (stream) SDFT_TRY(hipStreamSynchronize(stream));
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = s; own_stream = false;
+    return true;
+  }
+
+  bool synchronize() { SDFT_TRY(hipStreamSynchronize(stream)); return collect_profile(); }
+
+  // ---- profiling ---------------------------------------------------------------------------
+  bool prof_begin(int st)
+  {
+    if (!profile) return true;
+    if (ev_used[st] + 2 > ev_pool[st].size())
+    {
+      hipEvent_t a, b;
+      SDFT_TRY(hipEventCreate(&a)); SDFT_TRY(hipEventCreate(&b));
+      ev_pool[st].push_back(a); ev_pool[st].push_back(b);
+    }
+    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st]], stream));
+    return true;
+  }
+  bool prof_end(int st)
+  {
+    if (!profile) return true;
+    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st] + 1], stream));
+    ev_used[st] += 2;
+    return true;
+  }
+  bool collect_profile()
+  {
+    for (int st = 0; st < ST_COUNT; ++st)
+    {
+      for (size_t i = 0; i + 1 < ev_used[st]; i += 2)
+      {
+        SDFT_TRY(hipEventSynchronize(ev_pool[st][i + 1]));
+        float ms = 0.f;
+        SDFT_TRY(hipEventElapsedTime(&ms, ev_pool[st][i], ev_pool[st][i + 1]));
+        prof_ms[st] += ms; prof_calls[st] += 1;
+      }
+      ev_used[st] = 0;
+    }
+    return true;
+  }
+
+  // ---- geometry -----------------------------------------------------------------------
+  static int bins_per_lane() { return sizeof(fdx) == 16 ? 1 : 2; }
+  int halo_bins() const { return window == WIN_BLACKMAN ? 2 : (window == WIN_BOXCAR ? 0 : 1); }
+  int halo_lanes() const { return (halo_bins() + bins_per_lane() - 1) / bins_per_lane(); }
+  long interior_lanes() const
+  {
+    // Each lane stores 16 B; a tile of 8*j lanes starts and ends on 128-byte lines, so no line is
+    // shared between two waves.  Measured on MI355X (n=1e6, N=1024, f64): 62 lanes 4.2 TB/s,
+    // 60 lanes 5.4 TB/s, 56 lanes 5.6 TB/s.
+    const long mx = kWave - 2 * halo_lanes();
+    long v = opt_interior > 0 ? std::min(opt_interior, mx) : (mx / 8) * 8;
+    return std::max(v, 1L);
+  }
+  long tiles() const
+  {
+    const long per = interior_lanes() * bins_per_lane();
+    return (long)((nbins + per - 1) / per);
+  }
+  // time chunking: enough waves to fill 256 CUs, chunks not shorter than min_len samples
+  void choose_chunks(size_t n, long& chunks, long& len) const
+  {
+    const long target = opt_target_waves > 0 ? opt_target_waves : 16384;
+    const long min_len = 64;
+    if (opt_chunk <= 0 && n < 512) { chunks = 1; len = (long)n; return; }   // short hops stay serial (and bit-exact)
+    long want = (long)((target + (long)(channels * tiles()) - 1) / (long)(channels * tiles()));
+    if (opt_chunk > 0) len = opt_chunk;
+    else
+    {
+      want = std::max(1L, std::min(want, (long)(n / min_len)));
+      len = (long)((n + want - 1) / want);
+      len = ((len + kGroup - 1) / kGroup) * kGroup;        // whole scalar-load groups
+    }
+    len = std::max(1L, std::min(len, (long)n));
+    chunks = (long)((n + len - 1) / len);
+  }
+
+  // ---- forward on device-resident buffers ------------------------------------------------
+  // x: [channels] x n with stride x_stride; out: rows at out + ch*out_stride + t*N, or the row
+  // pointer table `rows` (device array of channels*n device pointers)
+  bool forward_device(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows)
+  {
+    if (n == 0 || nbins == 0) return true;
+    const size_t nb = nbins, span = 2 * nbins;
+    SDFT_TRY(hipSetDevice(device));
+
+    long chunks, len;
+    choose_chunks(n, chunks, len);
+    const long ntiles = tiles(), inter = interior_lanes();
+    last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
+
+    if (!d_delta.reserve(channels * n)) return false;
+    if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
+    const bool exact = (carry_mode == CARRY_EXACT);
+    if ((exact || chunks == 1) && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
+
+    // K0: differences + delay line
+    if (!prof_begin(ST_DELTA)) return false;
+    {
+      const size_t work = std::max(n, span);
+      dim3 grid((unsigned)((work + kBlock - 1) / kBlock), (unsigned)channels);
+      hipLaunchKernelGGL((delta_kernel<TD, FD>), grid, dim3(kBlock), 0, stream, x, x_stride,
+                         d_hist[hist_cur].p, d_hist[hist_cur ^ 1].p, d_delta.p, n, span);
+      SDFT_TRY(hipGetLastError());
+      hist_cur ^= 1;
+    }
+    if (!prof_end(ST_DELTA)) return false;
+
+    // carries
+    if (!prof_begin(ST_CARRY)) return false;
+    CarryArgs<FD> ca;
+    ca.delta = d_delta.p; ca.tw = d_tw.p; ca.wtab = d_wtab.p; ca.carry = d_carry.p; ca.seed = d_seed.p;
+    ca.acc_state = d_acc.p; ca.fid_state = d_fid.p; ca.n = n;
+    ca.nbins = (unsigned)nb; ca.chunks = (unsigned)chunks; ca.chunk_len = (unsigned)len; ca.cursor0 = (unsigned)cursor;
+    const unsigned bin_blocks = (unsigned)((nb + kBlock - 1) / kBlock);
+    bool use_seed = true;
+    if (chunks == 1)
+    {
+      // single chunk: the stream state is the carry (copied, because halo lanes of other tiles
+      // read bins whose owner may already have written the new state)
+      SDFT_TRY(hipMemcpyAsync(d_carry.p, d_acc.p, channels * nb * sizeof(fdx), hipMemcpyDeviceToDevice, stream));
+      SDFT_TRY(hipMemcpyAsync(d_seed.p, d_fid.p, channels * nb * sizeof(fdx), hipMemcpyDeviceToDevice, stream));
+    }
+    else if (exact)
+    {
+      hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3(bin_blocks, (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      SDFT_TRY(hipGetLastError());
+    }
+    else
+    {
+      hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      SDFT_TRY(hipGetLastError());
+      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3(bin_blocks, (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      SDFT_TRY(hipGetLastError());
+      use_seed = false;
+    }
+    if (!prof_end(ST_CARRY)) return false;
+
+    // K1
+    if (!prof_begin(ST_FORWARD)) return false;
+    ForwardArgs<FD> fa;
+    fa.delta = d_delta.p; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = d_carry.p;
+    fa.seed = use_seed ? d_seed.p : nullptr;
+    fa.out = out; fa.out_stride = out_stride; fa.out_rows = rows;
+    fa.acc_state = d_acc.p; fa.fid_state = d_fid.p; fa.n = n;
+    fa.total_waves = (unsigned long long)channels * (unsigned long long)chunks * (unsigned long long)ntiles;
+    fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
+    fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor;
+    fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
+    fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
+    const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    launch_forward(fa, (unsigned)blocks);
+    SDFT_TRY(hipGetLastError());
+    if (!prof_end(ST_FORWARD)) return false;
+
+    cursor = (cursor + n) % span;
+    return true;
+  }
+
+  template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
+  {
+    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
+    const dim3 g(blocks), b(kBlock);
+    switch (window)
+    {
+      case WIN_HANN:     hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_HANN, ROWS>), g, b, 0, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_HAMMING, ROWS>), g, b, 0, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_BLACKMAN, ROWS>), g, b, 0, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_BOXCAR, ROWS>), g, b, 0, stream, fa); break;
+    }
+  }
+  void launch_forward(const ForwardArgs<FD>& fa, unsigned blocks)
+  {
+    if (fa.out_rows) launch_forward_t<true>(fa, blocks); else launch_forward_t<false>(fa, blocks);
+  }
+
+  // ---- inverse on device-resident buffers --------------------------------------------------
+  bool inverse_device(size_t n, const fdx* in, size_t in_stride, const fdx* const* rows, TD* y, size_t y_stride)
+  {
+    if (n == 0) return true;
+    SDFT_TRY(hipSetDevice(device));
+    if (!prof_begin(ST_INVERSE)) return false;
+    InverseArgs<TD, FD> ia;
+    ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
+    ia.n = n; ia.nbins = (unsigned)nbins; ia.channels = (unsigned)channels; ia.sweight = tab.sweight;
+    const size_t total_rows = channels * n;
+    size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    blocks = std::min(blocks, (size_t)256 * 8 * 4);
+    if (latency == 1)                                                           // :639 exact compare
+      hipLaunchKernelGGL((inverse_kernel<TD, FD, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+    else
+      hipLaunchKernelGGL((inverse_kernel<TD, FD, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+    SDFT_TRY(hipGetLastError());
+    if (!prof_end(ST_INVERSE)) return false;
+    return true;
+  }
+
+  bool finish() { if (!async) return synchronize(); return true; }
+
+  // one strip per channel; per-channel async copies (no pitch limits, works for any size)
+  bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, hipMemcpyKind kind)
+  {
+    for (size_t c = 0; c < channels; ++c)
+      SDFT_TRY(hipMemcpyAsync((char*)dst + c * dpitch, (const char*)src + c * spitch, width, kind, stream));
+    return true;
+  }
+
+  // ---- public entry points: dense matrices, host or device pointers ---------------------------
+  // x: [channels][n], dfts: [channels][n][N]
+  bool sdft_n(size_t n, const TD* x, fdx* dfts)
+  {
+    if (n == 0 || nbins == 0) return true;
+    const bool xd = is_device_pointer(x), od = is_device_pointer(dfts);
+    if (xd && od)
+      return forward_device(n, x, n, dfts, n * nbins, nullptr) && finish();
+
+    // staged path (host pointers): time segments so that the staging matrix stays bounded;
+    // the stream state carries over from segment to segment exactly like hop-wise calls do
+    const size_t row_bytes = channels * nbins * sizeof(fdx);
+    size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
+    seg = std::min(seg, n);
+    if (!xd && !d_stage_td.reserve(channels * seg)) return false;
+    if (!od && !d_stage_fdx.reserve(channels * seg * nbins)) return false;
+    for (size_t t = 0; t < n; t += seg)
+    {
+      const size_t m = std::min(seg, n - t);
+      const TD* xs; size_t xstride;
+      if (xd) { xs = x + t; xstride = n; }
+      else
+      {
+        if (!copy2d(d_stage_td.p, m * sizeof(TD), x + t, n * sizeof(TD), m * sizeof(TD), hipMemcpyHostToDevice)) return false;
+        xs = d_stage_td.p; xstride = m;
+      }
+      if (od)
+      {
+        if (!forward_device(m, xs, xstride, dfts + t * nbins, n * nbins, nullptr)) return false;
+      }
+      else
+      {
+        if (!forward_device(m, xs, xstride, d_stage_fdx.p, m * nbins, nullptr)) return false;
+        if (!copy2d(dfts + t * nbins, n * nbins * sizeof(fdx), d_stage_fdx.p, m * nbins * sizeof(fdx),
+                    m * nbins * sizeof(fdx), hipMemcpyDeviceToHost)) return false;
+      }
+      if (!xd || !od) SDFT_TRY(hipStreamSynchronize(stream));     // staging buffers are reused
+    }
+    return synchronize();
+  }
+
+  // array-of-row-pointers variant (sdft.h:622-628); single channel
+  bool sdft_nd(size_t n, const TD* x, fdx** dfts)
+  {
+    if (n == 0 || nbins == 0) return true;
+    const bool table_on_device = is_device_pointer(dfts);
+    bool rows_on_device = false;
+    std::vector<fdx*> host_rows;
+    if (!table_on_device) { rows_on_device = is_device_pointer(dfts[0]); }
+    if (table_on_device || rows_on_device)
+    {
+      // rows live on the device: hand the pointer table to the kernel
+      fdx* const* table = dfts;
+      if (!table_on_device)
+      {
+        if (!d_rowptr.reserve(n)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_rowptr.p, dfts, n * sizeof(fdx*), hipMemcpyHostToDevice, stream));
+        table = d_rowptr.p;
+      }
+      const TD* xs = x;
+      if (!is_device_pointer(x))
+      {
+        if (!d_stage_td.reserve(n)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, n * sizeof(TD), hipMemcpyHostToDevice, stream));
+        xs = d_stage_td.p;
+      }
+      return forward_device(n, xs, n, nullptr, 0, table) && synchronize();
+    }
+    // host rows: compute dense segments, scatter row by row
+    const size_t seg = std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(nbins * sizeof(fdx), 1)));
+    std::vector<fdx> host(seg * nbins);
+    for (size_t t = 0; t < n; t += seg)
+    {
+      const size_t m = std::min(seg, n - t);
+      const bool saved = async; async = false;
+      const bool ok = sdft_n(m, x + t, host.data());
+      async = saved;
+      if (!ok) return false;
+      for (size_t r = 0; r < m; ++r) memcpy(dfts[t + r], host.data() + r * nbins, nbins * sizeof(fdx));
+    }
+    return true;
+  }
+
+  bool isdft_n(size_t n, const fdx* dfts, TD* y)
+  {
+    if (n == 0) return true;
+    const bool id = is_device_pointer(dfts), yd = is_device_pointer(y);
+    if (nbins == 0)
+    {
+      // empty spectrum: the reference returns (td)(0 * 2)
+      if (yd) SDFT_TRY(hipMemsetAsync(y, 0, channels * n * sizeof(TD), stream)); else memset(y, 0, channels * n * sizeof(TD));
+      return finish();
+    }
+    if (id && yd)
+      return inverse_device(n, dfts, n * nbins, nullptr, y, n) && finish();
+    const size_t row_bytes = channels * nbins * sizeof(fdx);
+    size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
+    seg = std::min(seg, n);
+    if (!id && !d_stage_fdx.reserve(channels * seg * nbins)) return false;
+    if (!yd && !d_stage_td.reserve(channels * seg)) return false;
+    for (size_t t = 0; t < n; t += seg)
+    {
+      const size_t m = std::min(seg, n - t);
+      const fdx* in; size_t istride;
+      if (id) { in = dfts + t * nbins; istride = n * nbins; }
+      else
+      {
+        if (!copy2d(d_stage_fdx.p, m * nbins * sizeof(fdx), dfts + t * nbins, n * nbins * sizeof(fdx),
+                    m * nbins * sizeof(fdx), hipMemcpyHostToDevice)) return false;
+        in = d_stage_fdx.p; istride = m * nbins;
+      }
+      if (yd)
+      {
+        if (!inverse_device(m, in, istride, nullptr, y + t, n)) return false;
+      }
+      else
+      {
+        if (!inverse_device(m, in, istride, nullptr, d_stage_td.p, m)) return false;
+        if (!copy2d(y + t, n * sizeof(TD), d_stage_td.p, m * sizeof(TD), m * sizeof(TD), hipMemcpyDeviceToHost)) return false;
+      }
+      SDFT_TRY(hipStreamSynchronize(stream));
+    }
+    return synchronize();
+  }
+
+  bool isdft_nd(size_t n, const fdx** dfts, TD* y)
+  {
+    if (n == 0) return true;
+    if (nbins == 0) return isdft_n(n, nullptr, y);
+    const bool table_on_device = is_device_pointer(dfts);
+    const bool rows_on_device = table_on_device || is_device_pointer(dfts[0]);
+    if (rows_on_device)
+    {
+      const fdx* const* table = dfts;
+      if (!table_on_device)
+      {
+        if (!d_rowptr.reserve(n)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_rowptr.p, dfts, n * sizeof(fdx*), hipMemcpyHostToDevice, stream));
+        table = d_rowptr.p;
+      }
+      TD* yy = y;
+      const bool yd = is_device_pointer(y);
+      if (!yd) { if (!d_stage_td.reserve(n)) return false; yy = d_stage_td.p; }
+      if (!inverse_device(n, nullptr, 0, table, yy, n)) return false;
+      if (!yd) SDFT_TRY(hipMemcpyAsync(y, yy, n * sizeof(TD), hipMemcpyDeviceToHost, stream));
+      return synchronize();
+    }
+    const size_t seg = std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(nbins * sizeof(fdx), 1)));
+    std::vector<fdx> host(seg * nbins);
+    for (size_t t = 0; t < n; t += seg)
+    {
+      const size_t m = std::min(seg, n - t);
+      for (size_t r = 0; r < m; ++r) memcpy(host.data() + r * nbins, dfts[t + r], nbins * sizeof(fdx));
+      const bool saved = async; async = false;
+      const bool ok = isdft_n(m, host.data(), y + t);
+      async = saved;
+      if (!ok) return false;
+    }
+    return true;
+  }
+
+  // state read-back for tests: acc, fid [channels][N]; hist [channels][2N] in time order
+  bool get_state(fdx* acc, fdx* fid, TD* hist, size_t* cur)
+  {
+    SDFT_TRY(hipStreamSynchronize(stream));
+    if (nbins)
+    {
+      if (acc) SDFT_TRY(hipMemcpy(acc, d_acc.p, channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
+      if (fid) SDFT_TRY(hipMemcpy(fid, d_fid.p, channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
+      if (hist) SDFT_TRY(hipMemcpy(hist, d_hist[hist_cur].p, channels * 2 * nbins * sizeof(TD), hipMemcpyDeviceToHost));
+    }
+    if (cur) *cur = cursor;
+    return true;
+  }
+};
+
+}  // namespace sdfthip

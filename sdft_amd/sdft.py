@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's operator interface over the C-ABI.
+
+``SDFT(dftsize, window, latency).sdft(x) / .isdft(dfts)`` has the shape of the reference's
+Python class (/root/reference/python/src/sdft/sdft.py:30,76,122) and the call order of its C
+test driver (/root/reference/test/test.c:49-93), but every call goes through
+``libsdft_hip.so``: torch tensors on the GPU are passed as device pointers (nothing is copied),
+numpy arrays take the library's staged host-pointer path.  torch is used for device memory
+only.  There is no CPU implementation in this package.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .capi import Api, STAGES, WINDOWS, SdftHipError
+
+_NP_REAL = {"f32": np.float32, "f64": np.float64}
+_NP_CPLX = {"f32": np.complex64, "f64": np.complex128}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _is_tensor(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+class SDFT:
+    """One analysis/synthesis plan = one stream (or a batch of independent channels).
+
+    Parameters follow ``sdft_alloc_custom`` (reference sdft.h:413): ``dftsize`` bins, analysis
+    ``window`` in {boxcar, hann, hamming, blackman}, synthesis ``latency`` in (0, 1].
+    ``combo`` selects time/frequency domain scalar types (``SDFT_TD_*`` / ``SDFT_FD_*`` macros).
+    ``channels`` > 1 allocates a batched plan (an addition over the reference).
+    """
+
+    def __init__(self, dftsize: int, window="hann", latency: float = 1.0, combo: str = "f32f64",
+                 channels: int = 1, device=None):
+        self.api = Api(combo)
+        self.combo = combo
+        self.td = _NP_REAL[combo[:3]]
+        self.fd = _NP_REAL[combo[3:]]
+        self.fdx = _NP_CPLX[combo[3:]]
+        self.dftsize = int(dftsize)
+        self.channels = int(channels)
+        self.window = WINDOWS[window] if isinstance(window, str) else int(window)
+        self.latency = float(latency)
+        if device is not None:
+            if self.api.lib.sdft_hip_set_device(int(device)) != 0:
+                self.api.check()
+        self._p = self.api.alloc_batch(self.dftsize, self.window, self.latency, self.channels)
+        if not self._p:
+            err = self.api.last_error()
+            self.api.lib.sdft_hip_clear_error()
+            raise SdftHipError(f"sdft_alloc failed: {err}")
+
+    # ---- lifetime -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_p", None):
+            self.api.free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        self.api.reset(self._p)
+        self.api.check()
+
+    def size(self) -> int:
+        return int(self.api.size(self._p))
+
+    # ---- options ------------------------------------------------------------------------
+    def set_option(self, key: str, value: int):
+        if self.api.set_option(self._p, key.encode(), int(value)) != 0:
+            raise SdftHipError(f"unknown option {key!r}")
+
+    def get_option(self, key: str) -> int:
+        return int(self.api.get_option(self._p, key.encode()))
+
+    def set_stream(self, stream_handle: int):
+        """Launch on a caller-owned HIP stream (e.g. ``torch.cuda.Stream().cuda_stream``)."""
+        if self.api.set_stream(self._p, C.c_void_p(stream_handle)) != 0:
+            self.api.check()
+
+    def synchronize(self):
+        if self.api.synchronize(self._p) != 0:
+            self.api.check()
+
+    def profile(self) -> dict:
+        """-> {stage: (milliseconds, launches)} accumulated since the last call; needs option profile=1."""
+        ms = (C.c_double * 4)()
+        calls = (C.c_long * 4)()
+        if self.api.get_profile(self._p, ms, calls) != 0:
+            self.api.check()
+        return {s: (ms[i], calls[i]) for i, s in enumerate(STAGES)}
+
+    def state(self):
+        """(acc, fid, hist, cursor) copied from the device; hist is in time order."""
+        n, c = self.dftsize, self.channels
+        acc = np.empty((c, n), dtype=self.fdx)
+        fid = np.empty((c, n), dtype=self.fdx)
+        hist = np.empty((c, 2 * n), dtype=self.td)
+        cur = C.c_size_t(0)
+        if self.api.get_state(self._p, acc.ctypes.data, fid.ctypes.data, hist.ctypes.data, C.byref(cur)) != 0:
+            self.api.check()
+        if c == 1:
+            acc, fid, hist = acc[0], fid[0], hist[0]
+        return acc, fid, hist, int(cur.value)
+
+    # ---- analysis / synthesis ---------------------------------------------------------------
+    def _shape_x(self, shape):
+        if self.channels == 1 and len(shape) == 1:
+            return shape[0]
+        if len(shape) == 2 and shape[0] == self.channels:
+            return shape[1]
+        raise ValueError(f"samples must have shape (n,) or ({self.channels}, n), got {tuple(shape)}")
+
+    def sdft(self, x, out=None):
+        """Analyse samples ``x`` -> DFT matrix of shape (n, dftsize) [(channels, n, dftsize) if batched].
+
+        State persists across calls exactly like the reference's plan (endless streaming).
+        """
+        if _is_tensor(x):
+            torch = _torch()
+            n = self._shape_x(x.shape)
+            assert x.is_cuda and x.is_contiguous() and x.dtype == getattr(torch, np.dtype(self.td).name)
+            shape = (n, self.dftsize) if x.dim() == 1 else (self.channels, n, self.dftsize)
+            if out is None:
+                out = torch.empty(shape, dtype=getattr(torch, np.dtype(self.fdx).name), device=x.device)
+            assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == shape
+            self.api.sdft_n(self._p, n, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()))
+        else:
+            x = np.ascontiguousarray(x, dtype=self.td)
+            n = self._shape_x(x.shape)
+            shape = (n, self.dftsize) if x.ndim == 1 else (self.channels, n, self.dftsize)
+            if out is None:
+                out = np.empty(shape, dtype=self.fdx)
+            assert out.flags.c_contiguous and out.shape == shape and out.dtype == self.fdx
+            self.api.sdft_n(self._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data))
+        self.api.check()
+        return out
+
+    def isdft(self, dfts, out=None):
+        """Synthesise samples from a DFT matrix (n, dftsize) [(channels, n, dftsize)]."""
+        batched = (len(dfts.shape) == 3)
+        n = dfts.shape[-2]
+        assert dfts.shape[-1] == self.dftsize and (not batched or dfts.shape[0] == self.channels)
+        yshape = (self.channels, n) if batched else (n,)
+        if _is_tensor(dfts):
+            torch = _torch()
+            assert dfts.is_cuda and dfts.is_contiguous() and dfts.dtype == getattr(torch, np.dtype(self.fdx).name)
+            if out is None:
+                out = torch.empty(yshape, dtype=getattr(torch, np.dtype(self.td).name), device=dfts.device)
+            self.api.isdft_n(self._p, n, C.c_void_p(dfts.data_ptr()), C.c_void_p(out.data_ptr()))
+        else:
+            dfts = np.ascontiguousarray(dfts, dtype=self.fdx)
+            if out is None:
+                out = np.empty(yshape, dtype=self.td)
+            self.api.isdft_n(self._p, n, C.c_void_p(dfts.ctypes.data), C.c_void_p(out.ctypes.data))
+        self.api.check()
+        return out
+
+
+def plan_tables(dftsize: int, latency: float = 1.0, combo: str = "f32f64"):
+    """Host-only: (tw, syn, wtab, weights) exactly as the library uploads them (no GPU needed)."""
+    api = Api(combo)
+    fd, fdx = _NP_REAL[combo[3:]], _NP_CPLX[combo[3:]]
+    tw = np.empty(dftsize, dtype=fdx)
+    syn = np.empty(dftsize, dtype=fdx)
+    wtab = np.empty(2 * dftsize, dtype=fdx)
+    w = np.empty(2, dtype=fd)
+    api.plan_tables(dftsize, latency, tw.ctypes.data, syn.ctypes.data, wtab.ctypes.data, w.ctypes.data)
+    return tw, syn, wtab, w

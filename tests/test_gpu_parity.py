@@ -1,0 +1,179 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle, on a real MI355X.
+
+Bars (BASELINE.json north_star): max|a-b| / max|b| <= 1e-6 for FD double, <= 1e-4 for FD float.
+Where the HIP path is time-serial (single chunk, or the exact-carry mode that FD float always
+uses) the forward result is required to be bit-identical.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdft_amd.signals import noise, sine_sweep, sweep_batch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": 1e-6, "f32": 1e-4}
+
+
+def rel_err(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    scale = float(np.abs(b).max())
+    if scale == 0.0:
+        return float(np.abs(a).max())
+    return float(np.abs(a - b).max()) / scale
+
+
+def make(dftsize, window="hann", latency=1.0, combo="f32f64", channels=1, **opts):
+    from sdft_amd.sdft import SDFT
+    p = SDFT(dftsize, window, latency, combo, channels)
+    for k, v in opts.items():
+        p.set_option(k, v)
+    return p
+
+
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8)) or np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# small exhaustive: every combo x window x latency, tiny and ragged sizes, host-pointer path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combo", O.COMBOS)
+@pytest.mark.parametrize("window", ["boxcar", "hann", "hamming", "blackman"])
+def test_small_sizes_bit_exact(combo, window):
+    td, fd, fdx = O.combo_types(combo)
+    for m in (1, 2, 3, 4, 5, 7, 61, 62, 63, 64, 100, 125, 130):
+        for latency in (1.0, 0.5):
+            n = 5 * m + 3
+            x = noise(n, seed=m, dtype=td)
+            ref = O.best(m, window, latency, combo)
+            want = ref.sdft(x)
+            with make(m, window, latency, combo, chunk=1 << 30) as p:
+                got = p.sdft(x)                      # numpy in -> staged host path, single chunk
+                assert np.array_equal(got, want), (combo, window, m, latency, rel_err(got, want))
+                y = p.isdft(got)
+                assert rel_err(y, ref.isdft(want)) <= TOL[combo[3:]], (combo, window, m, latency)
+                acc, fid, hist, cur = p.state()
+                racc, rfid, rhist, rcur = ref.state()
+                assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid) and np.array_equal(hist, rhist)
+
+
+@pytest.mark.parametrize("combo", O.COMBOS)
+def test_streaming_hops_match_one_call(combo):
+    """test.c:69-83 pattern: hop-wise calls with persistent state == the reference, bit for bit."""
+    td, fd, fdx = O.combo_types(combo)
+    m, hop = 100, 37
+    x = sine_sweep(20 * hop, dtype=td)
+    ref = O.best(m, "hann", 1.0, combo)
+    with make(m, "hann", 1.0, combo) as p:            # hops < 512 samples are never time-chunked
+        for i in range(0, x.size, hop):
+            want = ref.sdft(x[i:i + hop])
+            got = p.sdft(x[i:i + hop])
+            assert np.array_equal(got, want)
+            assert rel_err(p.isdft(got), ref.isdft(want)) <= TOL[combo[3:]]
+        p.reset(); ref.reset()
+        assert np.array_equal(p.sdft(x[:50]), ref.sdft(x[:50]))
+
+
+# ---------------------------------------------------------------------------------------------
+# time-chunked paths
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("window", ["hann", "blackman", "hamming", "boxcar"])
+def test_fast_carry_double_chunked(window):
+    """FD double, chunk-parallel carries (sum order differs from the serial reference)."""
+    m, n = 1024, 20000
+    x = sine_sweep(n)
+    ref = O.best(m, window, 1.0, "f32f64")
+    want = ref.sdft(x)
+    with make(m, window, 1.0, "f32f64", chunk=512, carry=0) as p:
+        got = p.sdft(x)
+        assert p.get_option("last_chunks") == 40
+        e = rel_err(got, want)
+        assert e <= 1e-11, e                     # far inside the 1e-6 bar
+        # second call continues from the chunked state
+        x2 = noise(3000)
+        e2 = rel_err(p.sdft(x2), ref.sdft(x2))
+        assert e2 <= 1e-11, e2
+
+
+@pytest.mark.parametrize("combo", ["f32f32", "f64f32", "f32f64"])
+@pytest.mark.parametrize("window", ["hann", "blackman"])
+def test_exact_carry_chunked_bit_exact(combo, window):
+    """Exact-carry mode: time chunks seeded by the serial pre-pass reproduce the reference bit for bit."""
+    td, fd, fdx = O.combo_types(combo)
+    m, n = 256, 6000
+    x = noise(n, dtype=td)
+    ref = O.best(m, window, 1.0, combo)
+    want = ref.sdft(x)
+    with make(m, window, 1.0, combo, chunk=200, carry=1) as p:
+        got = p.sdft(x)
+        assert p.get_option("last_chunks") == 30
+        assert np.array_equal(got, want), rel_err(got, want)
+        x2 = noise(777, seed=5, dtype=td)
+        assert np.array_equal(p.sdft(x2), ref.sdft(x2))
+        acc, fid, hist, cur = p.state()
+        racc, rfid, rhist, rcur = ref.state()
+        assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid) and np.array_equal(hist, rhist)
+
+
+def test_config3_shape_float_blackman_roundtrip():
+    """BASELINE config 3 at parity size: m=4096, Blackman, FD float, latency 1, n=20000."""
+    m, n = 4096, 20000
+    x = sine_sweep(n)
+    ref = O.best(m, "blackman", 1.0, "f32f32")
+    want = ref.sdft(x)
+    with make(m, "blackman", 1.0, "f32f32", chunk=1000) as p:
+        got = p.sdft(x)
+        assert np.array_equal(got, want), rel_err(got, want)
+        y = p.isdft(got)
+        assert rel_err(y, ref.isdft(want)) <= 1e-4
+
+
+def test_device_pointers_and_batch():
+    """Device-resident tensors (no copies) and a batched plan == per-channel reference plans."""
+    import torch
+    ch, m, n = 5, 200, 3000
+    xb = sweep_batch(ch, n)
+    with make(m, "hann", 1.0, "f32f64", channels=ch, chunk=256) as p:
+        xd = torch.from_numpy(xb).cuda()
+        d = p.sdft(xd)
+        y = p.isdft(d)
+        torch.cuda.synchronize()
+        dn, yn = d.cpu().numpy(), y.cpu().numpy()
+    for c in range(ch):
+        ref = O.best(m, "hann", 1.0, "f32f64")
+        want = ref.sdft(xb[c])
+        assert rel_err(dn[c], want) <= 1e-11
+        assert rel_err(yn[c], ref.isdft(want)) <= 1e-6
+
+
+def test_latency_synthesis_branch():
+    m, n = 512, 4000
+    x = noise(n)
+    for combo in ("f32f64", "f32f32"):
+        for latency in (0.5, 0.25):
+            ref = O.best(m, "hann", latency, combo)
+            want = ref.sdft(x)
+            with make(m, "hann", latency, combo) as p:
+                got = p.sdft(x)
+                assert rel_err(got, want) <= 1e-11 if combo == "f32f64" else np.array_equal(got, want)
+                assert rel_err(p.isdft(got), ref.isdft(want)) <= TOL[combo[3:]]
+
+
+def test_config1_shape_n48000():
+    """BASELINE config 1/2 shape (m=1024, Hann, TD float / FD double) at n=48000, default chunking."""
+    m, n = 1024, 48000
+    x = sine_sweep(n)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    dig, yref = O.Port(m, "hann", 1.0, "f32f64").digest(x)
+    want = ref.sdft(x)
+    import torch
+    with make(m) as p:
+        d = p.sdft(torch.from_numpy(x).cuda())
+        y = p.isdft(d)
+        got = d.cpu().numpy()
+        assert p.get_option("last_chunks") > 1
+        assert rel_err(got, want) <= 1e-11
+        assert rel_err(y.cpu().numpy(), yref) <= 1e-6
+        assert np.allclose(got.real.sum(axis=1), dig[:, 0], rtol=0, atol=1e-9)
