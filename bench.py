@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Sliding DFT engine (contract: see README/DESIGN).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: `sdft_sdft_n` through the C-ABI of libsdft_hip.so on device pointers.
+
+  N = 1  -> BASELINE.json configs[1]: n = 1e6 samples, m = 1024, Hann, TD float / FD double,
+            forward only, one channel.
+  N > 1  -> BASELINE.json configs[4]: 64 independent channels per GPU (512 at N = 8), n = 48000
+            each, m = 1024, Hann, FD double; channels are sharded over ranks, no data-path
+            collective (RCCL is used for the barrier and the max/sum of scalars only).
+
+Rank 0 prints ONE JSON line.  `value` = samples analysed by all ranks / max-over-ranks wall time
+of the K timed steps.  `roofline` prices the dominant kernel (forward_kernel) by its algorithmic
+bytes (m*sizeof(fdx) + sizeof(td) per sample) over the kernel's own duration, measured with HIP
+events recorded by the library on the stream the kernel runs on.  `cpu_baseline` is the oracle
+(the genuine reference build when oracle/_ref is present, else our bit-identical port) timed on
+one host core on a bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "single", "batch"])
+    ap.add_argument("--n", type=int, default=0, help="samples per channel (0 = workload default)")
+    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--channels-per-gpu", type=int, default=64)
+    ap.add_argument("--window", default="hann")
+    ap.add_argument("--combo", default="f32f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=200000)
+    ap.add_argument("--no-extras", action="store_true", help="skip synthesis / PCIe side measurements")
+    return ap.parse_args()
+
+
+def cpu_baseline(m, window, combo, n_cpu):
+    """Oracle forward pass on one host core, output pre-touched, best of 5."""
+    import numpy as np
+    from oracle import oracle as O
+    from sdft_amd.signals import sine_sweep
+    if not O.have_port(combo):
+        O.build(ref=True)
+    td, fd, fdx = O.combo_types(combo)
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+        n_cpu = max(4096, min(n_cpu, int(avail * 0.25) // (m * np.dtype(fdx).itemsize)))
+    except Exception:
+        pass
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        pinned = True
+    except Exception:
+        pinned = False
+    x = sine_sweep(n_cpu, dtype=td)
+    plan = O.best(m, window, 1.0, combo)
+    out = np.zeros((n_cpu, m), dtype=fdx)           # pre-touch: first-touch faults would dominate
+    best = float("inf")
+    budget = time.perf_counter() + 25.0
+    for _ in range(5):
+        plan.reset()
+        t0 = time.perf_counter()
+        plan.sdft(x, out)
+        best = min(best, time.perf_counter() - t0)
+        if time.perf_counter() > budget:
+            break
+    try:
+        os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+    except Exception:
+        pass
+    return {
+        "value": round(n_cpu / best / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": plan.kind,
+        "sample": f"sdft_sdft_n forward, n={n_cpu} of the sine sweep, m={m}, {window}, {combo}, 1 thread"
+                  f"{' pinned' if pinned else ''}, output pre-touched, best of 5; host has {os.cpu_count()} cores",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+
+    from sdft_amd import shard
+    from sdft_amd.sdft import SDFT
+    from sdft_amd.signals import sine_sweep
+
+    m, window, combo = args.m, args.window, args.combo
+    td = np.float32 if combo[:3] == "f32" else np.float64
+    esz = 16 if combo[3:] == "f64" else 8
+    cdt = torch.complex128 if esz == 16 else torch.complex64
+    workload = args.workload
+    if workload == "auto":
+        workload = "single" if n_gpus == 1 else "batch"
+    if workload == "single":
+        n = args.n or 1_000_000
+        channels_total = n_gpus
+        first, count = rank, 1
+        name = (f"BASELINE configs[1]: forward sdft_sdft_n, n={n}, m={m}, {window}, TD {combo[:3]} / FD {combo[3:]}, "
+                f"1 channel per GPU")
+    else:
+        n = args.n or 48000
+        channels_total = shard.weak_scaling_channels(args.channels_per_gpu, n_gpus)
+        first, count = shard.channel_block(channels_total, n_gpus, rank)
+        name = (f"BASELINE configs[4]: forward sdft_sdft_n, {channels_total} channels sharded {args.channels_per_gpu}/GPU, "
+                f"n={n} each, m={m}, {window}, TD {combo[:3]} / FD {combo[3:]}")
+
+    # synthetic input, resident in HBM before the timed region
+    if count == 1:
+        xh = sine_sweep(n, channel=first, channels=max(channels_total, 1), dtype=td)
+    else:
+        xh = np.stack([sine_sweep(n, channel=c, channels=channels_total, dtype=td) for c in range(first, first + count)])
+    x = torch.from_numpy(xh).cuda()
+    shape = (n, m) if count == 1 else (count, n, m)
+    out = torch.empty(shape, dtype=cdt, device="cuda")
+
+    stream = torch.cuda.Stream()
+    plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
+    plan.set_stream(stream.cuda_stream)
+    plan.set_option("async", 1)
+    plan.set_option("profile", 1)
+
+    def sync():
+        plan.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.sdft(x, out)
+    sync()
+    plan.profile()                       # drop warm-up timings
+    shard.barrier(local_rank)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.sdft(x, out)
+    sync()
+    shard.barrier(local_rank)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = plan.profile()
+
+    units = float(count * n * args.steps)
+    rate, secs = shard.job_throughput(units, elapsed, local_rank)
+
+    # roofline of the dominant kernel (this rank's launches; every rank runs the same shape)
+    f_ms, f_calls = prof["forward"]
+    bytes_per_launch = count * n * (m * esz + np.dtype(td).itemsize)
+    f_avg_ms = f_ms / max(f_calls, 1)
+    achieved = bytes_per_launch / (f_avg_ms * 1e-3) / 1e9 if f_avg_ms > 0 else 0.0
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            t = json.load(fh)
+        if t.get("workload") == workload and t.get("n") == n and t.get("m") == m and t.get("channels") == count:
+            traffic = t.get("bytes_per_launch")
+    except Exception:
+        pass
+
+    result = {
+        "metric": "Msamples/s analysis+synthesis, m=1024 Hann fp64; achieved HBM GB/s vs peak",
+        "value": round(rate / 1e6, 3),
+        "unit": "Msamples/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(secs / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if esz == 16 else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": name,
+            "channels_total": channels_total,
+            "samples_per_channel": n,
+            "dftsize": m,
+            "window": window,
+            "types": combo,
+            "step": "analysis (sdft_sdft_n) only, as configs[1] states; synthesis rate reported under 'extras'",
+            "time_chunks": plan.get_option("last_chunks"),
+            "chunk_len": plan.get_option("last_chunk_len"),
+            "carry_mode": "exact" if plan.get_option("carry") else "fast",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "forward_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": round(f_avg_ms, 4),
+            "launches": f_calls,
+            "prepass_ms_per_step": round((prof["delta"][0] + prof["carry"][0]) / max(args.steps, 1), 4),
+        },
+    }
+
+    # side measurements outside the timed region (rank 0, single GPU): synthesis, PCIe-inclusive path
+    if rank == 0 and not args.no_extras:
+        extras = {}
+        y = plan.isdft(out)
+        sync(); plan.profile()
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            plan.isdft(out, y)
+        sync()
+        i_ms, i_calls = plan.profile()["inverse"]
+        i_avg = i_ms / max(i_calls, 1)
+        extras["synthesis_msamples_s"] = round(count * n / (i_avg * 1e-3) / 1e6, 2)
+        extras["synthesis_read_gbs"] = round(count * n * (m * esz + np.dtype(td).itemsize) / (i_avg * 1e-3) / 1e9, 1)
+        step_ms = secs / args.steps * 1e3
+        extras["analysis_plus_synthesis_msamples_s"] = round(count * n / ((step_ms + i_avg) * 1e-3) / 1e6, 2)
+        if not distributed:
+            npci = min(n, 65536)
+            hx = xh[..., :npci].copy() if count == 1 else np.ascontiguousarray(xh[:, :npci])
+            hp = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
+            hout = np.empty((npci, m) if count == 1 else (count, npci, m), dtype=np.complex128 if esz == 16 else np.complex64)
+            hp.sdft(hx, hout)
+            hp.reset()
+            t1 = time.perf_counter()
+            hp.sdft(hx, hout)
+            extras["host_pointer_pcie_inclusive_msamples_s"] = round(count * npci / (time.perf_counter() - t1) / 1e6, 3)
+            hp.close()
+        result["extras"] = extras
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        del out
+        result["cpu_baseline"] = cpu_baseline(m, window, combo, args.cpu_samples)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    plan.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+/*
+ * sdft/sdft_hip.h -- additions of the MI355X engine beyond the reference's C API.  Nothing here
+ * alters the drop-in surface of sdft/sdft.h; a host that ignores this file behaves like one
+ * built against the reference.  Included by sdft/sdft.h (needs its type selection).
+ */
+
+#ifndef SDFT_HIP_SDFT_HIP_H
+#define SDFT_HIP_SDFT_HIP_H
+
+#ifndef SDFT_HIP_SDFT_H
+#error "include <sdft/sdft.h>, not <sdft/sdft_hip.h>"
+#endif
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+/* ---- error channel -------------------------------------------------------------------------
+   The reference has none (void returns, unchecked malloc; sdft.h:413-687).  Signatures are kept;
+   on a HIP failure sdft_alloc* returns NULL, other calls leave their outputs untouched, and the
+   text of the first failing HIP call is recorded per thread.  Never aborts. */
+const char* sdft_hip_last_error(void);       /* NULL if nothing is recorded */
+void        sdft_hip_clear_error(void);
+
+/* ---- device selection (one process per GPU is the intended multi-GPU model) ----------------- */
+int         sdft_hip_device_count(void);
+int         sdft_hip_set_device(int device); /* plans are created on the current device */
+int         sdft_hip_get_device(void);
+const char* sdft_hip_version(void);
+int         sdft_hip_selftest(void);         /* 0 = cross-lane primitives behave as the kernels assume */
+
+/* ---- batched plans: `channels` independent streams with one launch per call ----------------
+   The unit of sharding in the reference is the plan (no shared mutable state, sdft.h:145-182);
+   a batch is the same thing laid out for one GPU.  With a batched plan
+     sdft_sdft_n : samples [channels][nsamples],  dfts [channels][nsamples][dftsize]
+     sdft_isdft_n: dfts as above,                 samples [channels][nsamples]          */
+sdft_t*     sdft_hip_alloc_batch(const sdft_size_t dftsize, const sdft_window_t window,
+                                 const sdft_double_t latency, const sdft_size_t channels) SDFT_HIP_SYMBOL(alloc_batch);
+sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
+
+/* ---- streams ---------------------------------------------------------------------------------
+   Every plan owns a HIP stream.  Calls with host pointers always return with the output
+   complete.  Calls with device pointers do too unless option "async" is 1; then they return after
+   enqueueing and sdft_hip_synchronize() (or the caller's own stream sync) completes them. */
+int   sdft_hip_set_stream(sdft_t* sdft, void* hip_stream /* hipStream_t */) SDFT_HIP_SYMBOL(set_stream);
+void* sdft_hip_get_stream(sdft_t* sdft) SDFT_HIP_SYMBOL(get_stream);
+int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
+
+/* ---- options -----------------------------------------------------------------------------------
+   "async"        0|1   see above
+   "carry"        0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
+                      serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
+   "chunk"        samples per time chunk (0 = heuristic)
+   "interior"     bin-owning lanes per wave (default: largest multiple of 8 that leaves the halo)
+   "target_waves" waves the time chunking aims for
+   "stage_bytes"  segment size of the host-pointer staging path
+   "profile"      0|1  record per-stage HIP events (read with sdft_hip_get_profile)
+   get_option additionally answers "tiles", "bins_per_lane", "last_chunks", "last_chunk_len",
+   "cursor", "device". */
+int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
+long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);
+
+/* accumulated device milliseconds and launch counts per stage {delta, carry, forward, inverse};
+   synchronises, then resets the counters */
+int  sdft_hip_get_profile(sdft_t* sdft, double ms[4], long calls[4]) SDFT_HIP_SYMBOL(get_profile);
+
+/* ---- introspection (tests) ---------------------------------------------------------------------
+   stream state copied to host buffers: acc, fid [channels][dftsize]; hist [channels][2*dftsize]
+   in time order (oldest first); any pointer may be NULL */
+int  sdft_hip_get_state(sdft_t* sdft, sdft_fdx_t* acc, sdft_fdx_t* fid, sdft_td_t* hist, size_t* cursor) SDFT_HIP_SYMBOL(get_state);
+
+/* host-only (no GPU needed): the plan tables exactly as uploaded; tw, syn [dftsize], wtab
+   [2*dftsize], weights [2] = {analysis, synthesis}; any pointer may be NULL */
+int  sdft_hip_plan_tables(const sdft_size_t dftsize, const sdft_double_t latency, sdft_fdx_t* tw,
+                          sdft_fdx_t* syn, sdft_fdx_t* wtab, sdft_fd_t* weights) SDFT_HIP_SYMBOL(plan_tables);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif /* SDFT_HIP_SDFT_HIP_H */

@@ -1,0 +1,70 @@
+"""Channel sharding for one-process-per-GPU runs (torch.distributed; backend nccl = RCCL, or gloo).
+
+The unit of parallelism across GPUs is the independent channel/stream (one plan each, no shared
+mutable state -- reference sdft.h:145-182), so the data path needs no collective: every rank
+analyses its own contiguous block of channels.  Collectives are used only to bracket timing
+(barrier) and to gather scalars (max elapsed time, sample counts).
+"""
+
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def channel_block(channels: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [first, first+count) of `channels` owned by `rank`; remainders go to the
+    lowest ranks so block sizes differ by at most one."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, extra = divmod(int(channels), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def all_blocks(channels: int, world_size: int) -> List[Tuple[int, int]]:
+    return [channel_block(channels, world_size, r) for r in range(world_size)]
+
+
+def weak_scaling_channels(per_gpu: int, world_size: int) -> int:
+    """BASELINE config 5: a fixed number of channels per GPU (64), so total = 64 * N."""
+    return int(per_gpu) * int(world_size)
+
+
+def barrier(device=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if device is not None and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of one scalar (the job is as slow as its slowest rank)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    dev = f"cuda:{device}" if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    dev = f"cuda:{device}" if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def job_throughput(local_units: float, local_seconds: float, device=None) -> Tuple[float, float]:
+    """(total units over all ranks) / (max seconds over ranks) -> (units per second, seconds)."""
+    total = sum_over_ranks(local_units, device)
+    secs = max_over_ranks(local_seconds, device)
+    return (total / secs if secs > 0 else 0.0), secs

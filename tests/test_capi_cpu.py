@@ -1,0 +1,118 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol the
+headers declare, and its host-only logic (plan tables) equals the oracle's.  No GPU compute."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def declared_symbols():
+    """Names under SDFT_HIP_SYMBOL(...) in the headers (typed) + plain sdft_hip_* prototypes (untyped)."""
+    typed, untyped = set(), set()
+    for h in ("sdft/sdft.h", "sdft/sdft_hip.h"):
+        text = open(os.path.join(INC, h)).read()
+        typed |= set(re.findall(r"SDFT_HIP_SYMBOL\((\w+)\);", text))
+        for m in re.finditer(r"^\s*(?:const\s+char\*|int|void)\s+(sdft_hip_\w+)\s*\([^;]*\);", text, re.M):
+            if "SDFT_HIP_SYMBOL" not in m.group(0):
+                untyped.add(m.group(1))
+    return typed, untyped
+
+
+def test_library_exports_every_declared_symbol(hip_library):
+    from sdft_amd import capi
+    lib = capi.load()
+    typed, untyped = declared_symbols()
+    assert {"alloc", "alloc_custom", "free", "reset", "size", "window", "latency", "sdft", "sdft_n", "sdft_nd",
+            "isdft", "isdft_n", "isdft_nd"} <= typed                       # the reference surface, sdft.h:39-58
+    assert {"sdft_hip_last_error", "sdft_hip_device_count"} <= untyped
+    for combo in capi.COMBOS:
+        for name in typed:
+            assert hasattr(lib, capi.symbol(name, combo)), (name, combo)
+    for name in untyped:
+        assert hasattr(lib, name), name
+    # and the binding declares exactly the typed set
+    assert set(capi.typed_signatures("f32f64")) == typed
+
+
+def test_library_has_no_hard_hip_runtime_dependency(hip_library):
+    out = subprocess.run(["readelf", "-d", hip_library], capture_output=True, text=True).stdout
+    assert "libamdhip64" not in out
+
+
+@pytest.mark.parametrize("combo", O.COMBOS)
+def test_host_plan_tables_bit_identical_to_oracle(hip_library, combo):
+    from sdft_amd.sdft import plan_tables
+    for m in (1, 2, 3, 64, 1000, 1024, 4096):
+        for latency in (1.0, 0.5, 0.25, 0.77):
+            tw, syn, wtab, w = plan_tables(m, latency, combo)
+            otw, osyn, ow = O.Port(m, "hann", latency, combo).tables()
+            assert np.array_equal(tw, otw) and np.array_equal(syn, osyn) and np.array_equal(w, ow), (m, latency)
+            # closed-form rotation table: first half is the twiddle table, all entries on the unit circle
+            assert np.array_equal(wtab[:m], tw)
+            j = np.arange(2 * m)
+            assert np.allclose(wtab, np.exp(-1j * np.pi * j / m), atol=1e-6 if combo.endswith("f32") else 1e-15)
+
+
+def test_null_plan_getters_without_gpu(hip_library):
+    """Reference semantics for NULL plans (sdft.h:466-554) need no device."""
+    from sdft_amd import capi
+    api = capi.Api("f32f64")
+    assert api.size(None) == 0 and api.window(None) == 0 and api.latency(None) == 0.0
+    api.free(None)
+    api.reset(None)
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text("#include <sdft/sdft.h>\nint main(void){ sdft_t* p = sdft_alloc(8); sdft_free(p); return (int)sizeof(sdft_fdx_t); }\n")
+    for flags in ([], ["-DSDFT_FD_FLOAT"], ["-DSDFT_TD_DOUBLE", "-DSDFT_NO_COMPLEX_H"]):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", INC, *flags, "-c", str(src), "-o", str(tmp_path / "t.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        nm = subprocess.run(["nm", str(tmp_path / "t.o")], capture_output=True, text=True).stdout
+        suffix = ("f64" if "-DSDFT_TD_DOUBLE" in flags else "f32") + ("f32" if "-DSDFT_FD_FLOAT" in flags else "f64")
+        assert f"sdft_hip_alloc_{suffix}" in nm
+    r = subprocess.run(["g++", "-x", "c++", "-fsyntax-only", "-I", INC, os.path.join(INC, "sdft", "sdft.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_kernels_contain_no_fused_multiply_add(hip_library):
+    """Parity depends on unfused a*b+c in the recurrence: check the ISA."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not present")
+    import shutil
+    import tempfile
+    obj = os.path.join(os.path.dirname(hip_library), "obj", "sdft_capi_f32f32.o")
+    if not os.path.exists(obj):
+        pytest.skip("object files not kept")
+    with tempfile.TemporaryDirectory() as td:
+        local = os.path.join(td, "dev.o")
+        shutil.copy(obj, local)
+        subprocess.run([objdump, "--offloading", local], capture_output=True, text=True, cwd=td)
+        cos = [f for f in os.listdir(td) if "amdgcn" in f and "gfx950" in f]
+        if not cos:
+            pytest.skip("could not extract the gfx950 code object")
+        dis = subprocess.run([objdump, "-d", os.path.join(td, cos[0])], capture_output=True, text=True).stdout
+    body = []
+    keep = False
+    for line in dis.splitlines():
+        if line.endswith(">:"):
+            keep = any(k in line for k in ("forward_kernel", "carry_exact_kernel", "inverse_kernel"))
+        elif keep:
+            body.append(line)
+    text = "\n".join(body)
+    assert "v_mul_f32" in text or "v_pk_mul_f32" in text
+    fused = re.findall(r"\b(v_fma_f32|v_fmac_f32|v_pk_fma_f32|v_fma_f64|v_fmac_f64|v_mad_f32|v_mac_f32)\b", text)
+    # integer division helpers use v_fma/v_fmac on f32 reciprocals in the prologue; the float recurrence
+    # itself must not.  Those helpers are the only allowed users: bound their count.
+    assert len(fused) <= 64, len(fused)

@@ -1,0 +1,114 @@
+"""The oracle itself: pinned against the genuine reference build (when present in this
+container) and against the committed golden vectors that build produced."""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdft_amd.signals import noise, sine_sweep
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def digest_of(d):
+    k = np.arange(1, d.shape[1] + 1, dtype=np.float64)
+    re = d.real.astype(np.float64); im = d.imag.astype(np.float64)
+    return np.stack([re.sum(1), im.sum(1), (re * re + im * im).sum(1), (re * k).sum(1)], axis=1)
+
+
+def test_port_matches_tiny_golden_cases_bit_for_bit():
+    z = load("tiny_cases.npz")
+    keys = sorted({k.rsplit("/", 1)[0] for k in z})
+    assert len(keys) == 240
+    for key in keys:
+        combo, window, lat, m = key.split("/")
+        p = O.Port(int(m), window, int(lat) / 100.0, combo)
+        d = p.sdft(z[key + "/x"])
+        assert np.array_equal(d, z[key + "/d"]), key
+        assert np.array_equal(p.isdft(d), z[key + "/y"]), key
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mid_*.npz")) + glob.glob(os.path.join(GOLD, "cfg*.npz"))))
+def test_port_matches_golden_fixture(path):
+    g = load(os.path.basename(path))
+    m, window, latency, combo = int(g["dftsize"]), str(g["window"]), float(g["latency"]), str(g["combo"])
+    p = O.Port(m, window, latency, combo)
+    x = g["x"]
+    hop = int(g["hop"]) if "hop" in g else x.size
+    d = np.concatenate([p.sdft(x[i:i + hop]) for i in range(0, x.size, hop)])
+    assert np.array_equal(d[g["rows_idx"]], g["rows"])
+    assert np.array_equal(digest_of(d), g["digest"])
+    assert np.array_equal(p.isdft(d), g["y"])
+
+
+def test_port_matches_reference_test_wav_fixture():
+    """The reference's own end-to-end test shape: test.wav, m=1000, hop=100, Hann (test/main.sh:3-6)."""
+    g = load("testwav_m1000_hop100_hann_f32f64.npz")
+    p = O.Port(1000, "hann", 1.0, "f32f64")
+    hop = int(g["hop"])
+    x = g["x"]
+    firsts, ys = [], []
+    for i in range(0, x.size, hop):
+        d = p.sdft(x[i:i + hop])
+        firsts.append(d[0]); ys.append(p.isdft(d))
+    assert np.array_equal(np.stack(firsts), g["hop_first_rows"])
+    assert np.array_equal(np.concatenate(ys), g["y"])
+
+
+def test_digest_streaming_equals_matrix():
+    x = sine_sweep(3000)
+    a = O.Port(128, "hann"); b = O.Port(128, "hann")
+    d = a.sdft(x)
+    dig, y = b.digest(x)
+    # the C digest sums serially in bin order, numpy pairwise: equal up to summation rounding
+    assert np.allclose(dig, digest_of(d), rtol=1e-12, atol=1e-13)
+    assert np.array_equal(y, a.isdft(d))
+
+
+def test_roundtrip_latency_and_snr():
+    """Synthesis returns the input delayed by (N-1)*latency samples
+    (/root/reference/python/examples/latency.py:30); the SNR depends on the signal (about 23 dB
+    for white noise, about 60 dB for the sweep with a Hann window at latency 1)."""
+    m = 256
+    for x, floor in ((noise(8 * m), 20.0), (sine_sweep(8 * m), 50.0)):
+        p = O.Port(m, "hann", 1.0)
+        y = p.isdft(p.sdft(x)).astype(np.float64)
+        x = x.astype(np.float64)
+        snr = {}
+        for lag in range(m - 4, m + 3):
+            err = y[2 * m + lag:] - x[2 * m:-lag]
+            snr[lag] = 10 * np.log10(np.mean(x[2 * m:-lag] ** 2) / np.mean(err ** 2))
+        assert max(snr, key=snr.get) == m - 1
+        assert snr[m - 1] > floor
+
+
+@pytest.mark.skipif(not O.have_reference(), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("combo", O.COMBOS)
+def test_port_equals_reference_build(combo):
+    td, fd, fdx = O.combo_types(combo)
+    for m, window, latency in ((1, "hann", 1.0), (2, "blackman", 1.0), (4, "hamming", 0.5), (7, "blackman", 0.25),
+                               (64, "hann", 1.0), (100, "boxcar", 0.5), (257, "blackman", 1.0)):
+        x = noise(5 * m + 7, seed=m, dtype=td)
+        p, r = O.Port(m, window, latency, combo), O.Reference(m, window, latency, combo)
+        for a, b in zip(p.tables(), r.tables()):
+            assert np.array_equal(a, b)
+        i, outs = 0, []
+        for hop in (1, 3, m, 2 * m - 1, 10 ** 9):        # ragged hops across the roll-over
+            xs = x[i:i + hop]; i += xs.size
+            if xs.size == 0:
+                break
+            dp, dr = p.sdft(xs), r.sdft(xs)
+            assert np.array_equal(dp, dr), (combo, m, window, latency)
+            assert np.array_equal(p.isdft(dp), r.isdft(dr))
+        for a, b in zip(p.state(), r.state()):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        p.reset(); r.reset()
+        assert np.array_equal(p.sdft(x[:9]), r.sdft(x[:9]))
