@@ -33,6 +33,24 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "sweep":
+        run(1000000, 1024)
+        run(48000, 1024)
+        for kw in ({"nt_store": 1}, {"interior": 48}, {"interior": 40}, {"interior": 32}, {"target_waves": 8192}, {"target_waves": 32768},
+                   {"target_waves": 8192, "nt_store": 1}, {"chunk": 2048}, {"chunk": 4096}):
+            run(1000000, 1024, **kw)
+        for kw in ({"chunk": 128}, {"chunk": 256}, {"chunk": 512}, {"chunk": 1024}):
+            run(48000, 1024, **kw)
+        run(48000, 1024, channels=64)
+        run(48000, 2048, channels=16)
+        import torch
+        out = torch.empty((1000000, 1024), dtype=torch.complex128, device="cuda")
+        for _ in range(3): out.zero_()
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): out.zero_()
+        e1.record(); torch.cuda.synchronize()
+        print("torch zero_ 16.4GB:", e0.elapsed_time(e1) / 10, "ms ->", 16.384e9 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e12, "TB/s")
     if which == "base":
         run(48000, 1024)
         run(1000000, 1024)

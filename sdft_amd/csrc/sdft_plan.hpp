@@ -136,6 +136,7 @@ class Plan
   long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
   size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
   bool profile = false;
+  long opt_nt = 0;               // non-temporal matrix stores
 
   // device-resident stream state
   DevBuf<fdx> d_tw, d_syn, d_wtab, d_acc, d_fid;
@@ -286,12 +287,12 @@ class Plan
     const long min_len = 64;
     if (opt_chunk <= 0 && n < 512) { chunks = 1; len = (long)n; return; }   // short hops stay serial (and bit-exact)
     long want = (long)((target + (long)(channels * tiles()) - 1) / (long)(channels * tiles()));
-    if (opt_chunk > 0) len = opt_chunk;
+    if (opt_chunk > 0) len = (carry_mode == CARRY_FAST) ? ((opt_chunk + kSumBlock - 1) / kSumBlock) * kSumBlock : opt_chunk;
     else
     {
       want = std::max(1L, std::min(want, (long)(n / min_len)));
       len = (long)((n + want - 1) / want);
-      len = ((len + kGroup - 1) / kGroup) * kGroup;        // whole scalar-load groups
+      len = ((len + kGroup - 1) / kGroup) * kGroup;        // whole scalar-load groups (and sum blocks)
     }
     len = std::max(1L, std::min(len, (long)n));
     chunks = (long)((n + len - 1) / len);
@@ -352,7 +353,8 @@ class Plan
     {
       hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
-      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3(bin_blocks, (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)((nb + kWave - 1) / kWave), (unsigned)channels),
+                         dim3(kWave * kScanSlices), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
       use_seed = false;
     }
@@ -369,6 +371,7 @@ class Plan
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
     fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor;
     fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
+    fa.nt_store = (int)opt_nt;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
     launch_forward(fa, (unsigned)blocks);
