@@ -29,6 +29,12 @@ int         sdft_hip_get_device(void);
 const char* sdft_hip_version(void);
 int         sdft_hip_selftest(void);         /* 0 = cross-lane primitives behave as the kernels assume */
 
+/* measurement aid: average ms of a store-only kernel over `bytes` of device memory.
+   pattern 0 = linear fill; pattern 1 = the forward kernel's tiling (rows of `row_slots` 16-byte
+   slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave) */
+double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
+                                   unsigned chunk_len, int reps);
+
 /* ---- batched plans: `channels` independent streams with one launch per call ----------------
    The unit of sharding in the reference is the plan (no shared mutable state, sdft.h:145-182);
    a batch is the same thing laid out for one GPU.  With a batched plan

@@ -33,6 +33,29 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "ceiling2":
+        from sdft_amd import capi
+        lib = capi.load()
+        nbytes = 1000000 * 1024 * 16
+        buf = torch.empty(nbytes // 16, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        for lanes in (16, 32, 56, 64):
+            for ln in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+                ms = lib.sdft_hip_store_ceiling(buf.data_ptr(), nbytes, 1, 1024, lanes, ln, 5)
+                tiles = (1024 + lanes - 1) // lanes; chunks = (1000000 + ln - 1) // ln
+                print(f"store-only lanes={lanes} len={ln} waves={tiles*chunks}: {ms:.3f} ms -> {nbytes / ms / 1e9:.2f} TB/s", flush=True)
+    if which == "ceiling":
+        from sdft_amd import capi
+        lib = capi.load()
+        nbytes = 1000000 * 1024 * 16
+        buf = torch.empty(nbytes // 16, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        for name, args in (("linear", (0, 1024, 64, 1)), ("tiled 64 lanes len1160", (1, 1024, 64, 1160)), ("tiled 56 lanes len1160", (1, 1024, 56, 1160)),
+                           ("tiled 62 lanes len1160", (1, 1024, 62, 1160)), ("tiled 64 lanes len4096", (1, 1024, 64, 4096)), ("tiled 64 lanes len256", (1, 1024, 64, 256)),
+                           ("linear again", (0, 1024, 64, 1))):
+            ms = lib.sdft_hip_store_ceiling(buf.data_ptr(), nbytes, args[0], args[1], args[2], args[3], 10)
+            print(f"store ceiling {name}: {ms:.3f} ms -> {nbytes / ms / 1e9:.2f} TB/s", flush=True)
+        run(1000000, 1024)
     if which == "sweep":
         run(1000000, 1024)
         run(48000, 1024)

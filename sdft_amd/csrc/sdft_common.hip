@@ -45,9 +45,75 @@ bool lane_selftest()
   return ok;
 }
 
+// ------------------------------------------------------------------------------------------
+// Achievable-write ceiling (measurement aid): a kernel that does nothing but the
+// forward kernel's store stream.  pattern 0: plain linear grid-stride fill, 16 B per lane.
+// pattern 1: the forward kernel's own geometry -- every wave owns `lanes` consecutive 16-byte
+// slots of a row of `row_slots` slots and walks `chunk_len` consecutive rows.
+// ------------------------------------------------------------------------------------------
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kBlock) void store_linear_kernel(v2f64* dst, size_t slots)
+{
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  v2f64 v; v.x = (double)threadIdx.x; v.y = 1.0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) dst[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void store_tiled_kernel(v2f64* dst, size_t rows, unsigned row_slots, unsigned lanes,
+                                                            unsigned chunk_len, unsigned tiles, unsigned chunks)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long wave = (unsigned long long)blockIdx.x * kWavesPerBlock + wib;
+  if (wave >= (unsigned long long)tiles * chunks) return;
+  const unsigned tile = (unsigned)(wave % tiles), chunk = (unsigned)(wave / tiles);
+  const size_t t0 = (size_t)chunk * chunk_len;
+  const size_t t1 = t0 + chunk_len < rows ? t0 + chunk_len : rows;
+  const unsigned slot = tile * lanes + lane;
+  if (lane >= (int)lanes || slot >= row_slots) return;
+  v2f64 v; v.x = (double)lane; v.y = (double)tile;
+  v2f64* p = dst + t0 * row_slots + slot;
+  for (size_t t = t0; t < t1; ++t) { *p = v; p += row_slots; v.x += 1.0; }
+}
+
 }  // namespace sdfthip
 
 extern "C" {
+
+// Times `reps` launches of the store-only kernel over `bytes` of device memory at `dst`;
+// returns the average milliseconds per launch (negative on error).
+double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
+                              unsigned chunk_len, int reps)
+{
+  using namespace sdfthip;
+  const size_t slots = bytes / 16;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  auto launch = [&]() {
+    if (pattern == 0)
+      hipLaunchKernelGGL(store_linear_kernel, dim3(256 * 8), dim3(kBlock), 0, 0, (v2f64*)dst, slots);
+    else
+    {
+      const size_t rows = slots / row_slots;
+      const unsigned tiles = (row_slots + lanes - 1) / lanes;
+      const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
+      const unsigned long long waves = (unsigned long long)tiles * chunks;
+      hipLaunchKernelGGL(store_tiled_kernel, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, 0,
+                         (v2f64*)dst, rows, row_slots, lanes, chunk_len, tiles, chunks);
+    }
+  };
+  launch();
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1, 0);
+  if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (double)ms / (reps > 0 ? reps : 1);
+}
 
 // NULL when no error has been recorded on this thread since the last clear
 const char* sdft_hip_last_error(void) { return sdfthip::g_has_error ? sdfthip::g_error.c_str() : nullptr; }
