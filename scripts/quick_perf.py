@@ -33,6 +33,34 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "v2":
+        for rep in range(2):
+            run(1000000, 1024)
+            run(1000000, 1024, rows_kernel=0)
+        for ch in (488, 976, 1952, 3904, 7808):
+            run(1000000, 1024, chunk=ch)
+        run(48000, 1024)
+        run(48000, 1024, rows_kernel=0)
+        for ch in (96, 192, 376):
+            run(48000, 1024, chunk=ch)
+        run(48000, 1024, channels=64)
+        run(48000, 1024, channels=64, rows_kernel=0)
+        run(262144, 2048, "blackman", "f32f32")
+    if which == "ceiling3":
+        from sdft_amd import capi
+        lib = capi.load()
+        nbytes = 1000000 * 1024 * 16
+        buf = torch.empty(nbytes // 16, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for ln in (488, 976, 1160, 1952, 2320, 3000, 3904, 4096, 5000, 7800):
+                for sync in (0, 8):
+                    ms = lib.sdft_hip_store_ceiling(buf.data_ptr(), nbytes, 2, 1024, sync, ln, 5)
+                    print(f"rowgroup len={ln} sync={sync} blocks={(1000000 + ln - 1) // ln}: {ms:.3f} ms -> {nbytes / ms / 1e9:.2f} TB/s", flush=True)
+            for lanes in (56, 64):
+                for ln in (1160, 2320, 3000, 5000):
+                    ms = lib.sdft_hip_store_ceiling(buf.data_ptr(), nbytes, 1, 1024, lanes, ln, 5)
+                    print(f"tiled lanes={lanes} len={ln}: {ms:.3f} ms -> {nbytes / ms / 1e9:.2f} TB/s", flush=True)
     if which == "ceiling2":
         from sdft_amd import capi
         lib = capi.load()

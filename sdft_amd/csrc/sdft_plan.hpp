@@ -137,6 +137,8 @@ class Plan
   size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
+  long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
 
   // device-resident stream state
   DevBuf<fdx> d_tw, d_syn, d_wtab, d_acc, d_fid;
@@ -280,9 +282,27 @@ class Plan
     const long per = interior_lanes() * bins_per_lane();
     return (long)((nbins + per - 1) / per);
   }
-  // time chunking: enough waves to fill 256 CUs, chunks not shorter than min_len samples
-  void choose_chunks(size_t n, long& chunks, long& len) const
+  bool rows_kernel_ok(bool row_pointers) const
   {
+    return opt_rows_kernel && !row_pointers && nbins >= 64 && nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane());
+  }
+  long row_waves() const { return (long)((nbins + (size_t)(kWave * bins_per_lane()) - 1) / (size_t)(kWave * bins_per_lane())); }
+
+  // time chunking: enough waves to fill 256 CUs, chunks not shorter than min_len samples
+  void choose_chunks(size_t n, long& chunks, long& len, bool rows_kernel = false) const
+  {
+    if (rows_kernel && opt_chunk <= 0 && n >= 512)
+    {
+      // row-group kernel: one workgroup per (channel, chunk); aim at a few workgroups per CU
+      const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves()) : 1024;
+      long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
+      want = std::max(1L, std::min(want, (long)(n / 64)));
+      len = (long)((n + want - 1) / want);
+      len = ((len + kGroup - 1) / kGroup) * kGroup;
+      len = std::max(1L, std::min(len, (long)n));
+      chunks = (long)((n + len - 1) / len);
+      return;
+    }
     const long target = opt_target_waves > 0 ? opt_target_waves : 16384;
     const long min_len = 64;
     if (opt_chunk <= 0 && n < 512) { chunks = 1; len = (long)n; return; }   // short hops stay serial (and bit-exact)
@@ -307,9 +327,11 @@ class Plan
     const size_t nb = nbins, span = 2 * nbins;
     SDFT_TRY(hipSetDevice(device));
 
+    const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
-    choose_chunks(n, chunks, len);
+    choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
+    last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
 
     if (!d_delta.reserve(channels * n)) return false;
@@ -374,12 +396,26 @@ class Plan
     fa.nt_store = (int)opt_nt;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    launch_forward(fa, (unsigned)blocks);
+    if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)chunks), (unsigned)(row_waves() * kWave));
+    else launch_forward(fa, (unsigned)blocks);
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
 
     cursor = (cursor + n) % span;
     return true;
+  }
+
+  void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
+  {
+    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
+    const dim3 g(blocks), b(threads);
+    switch (window)
+    {
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN>), g, b, 0, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING>), g, b, 0, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN>), g, b, 0, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR>), g, b, 0, stream, fa); break;
+    }
   }
 
   template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)

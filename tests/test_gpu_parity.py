@@ -177,3 +177,26 @@ def test_config1_shape_n48000():
         assert rel_err(got, want) <= 1e-11
         assert rel_err(y.cpu().numpy(), yref) <= 1e-6
         assert np.allclose(got.real.sum(axis=1), dig[:, 0], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("combo,m", [("f32f64", 64), ("f32f64", 1000), ("f32f64", 1024), ("f32f64", 127), ("f32f32", 2048),
+                                     ("f32f32", 130), ("f64f64", 512), ("f64f32", 1001)])
+@pytest.mark.parametrize("window", ["hann", "blackman", "boxcar", "hamming"])
+def test_row_group_kernel_equals_tile_kernel_and_oracle(combo, m, window):
+    """The two forward kernels (row-group with LDS halo exchange / independent tiles with halo lanes)
+    must agree bit for bit with each other for the same carries, and with the oracle."""
+    td, fd, fdx = O.combo_types(combo)
+    n = 3000
+    x = noise(n, seed=11, dtype=td)
+    want = O.best(m, window, 1.0, combo).sdft(x)
+    got = {}
+    for rows_kernel in (1, 0):
+        with make(m, window, 1.0, combo, chunk=504, carry=1, rows_kernel=rows_kernel) as p:
+            got[rows_kernel] = p.sdft(x)
+            assert p.get_option("last_kernel") == (2 if rows_kernel else 1)
+            assert p.get_option("last_chunks") == 6
+            x2 = noise(100, seed=12, dtype=td)           # state written by the last chunk
+            got[(rows_kernel, "next")] = p.sdft(x2)
+    assert np.array_equal(got[1], got[0])
+    assert np.array_equal(got[1], want), rel_err(got[1], want)
+    assert np.array_equal(got[(1, "next")], got[(0, "next")])
