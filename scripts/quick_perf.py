@@ -46,6 +46,14 @@ if __name__ == "__main__":
         run(48000, 1024, channels=64)
         run(48000, 1024, channels=64, rows_kernel=0)
         run(262144, 2048, "blackman", "f32f32")
+    if which == "f32":
+        run(262144, 4096, "blackman", "f32f32")
+        run(262144, 2048, "blackman", "f32f32")
+        run(262144, 1024, "hann", "f32f32")
+        run(48000, 1024, "hann", "f32f32", channels=64)
+        run(1000000, 1024, carry=1)
+        run(48000, 1024)
+        run(1000000, 1024)
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

@@ -43,7 +43,8 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
+          extra_flags=tuple(os.environ.get("SDFT_HIP_EXTRA_FLAGS", "").split())) -> str:
     """Compile (if stale) and return the path of libsdft_hip.so."""
     if not force and not _stale():
         return LIB

@@ -276,39 +276,162 @@ __global__ __launch_bounds__(kWave * kScanSlices) void carry_scan_kernel(CarryAr
 // sequence of acc and fid and records both at every chunk start.  Used for FD float, where the
 // 1e-4 parity bar is tighter than float's own accumulation error.
 // ------------------------------------------------------------------------------------------
-template <typename FD>
-__global__ __launch_bounds__(kBlock) void carry_exact_kernel(CarryArgs<FD> a)
+// The pass is a serial dependency chain, n steps long, with only N-fold parallelism, so what
+// counts is instructions and latency per step on a wave that is alone on its SIMD:
+//  * the real and imaginary part of a bin live in a lane pair (even lane: re, odd lane: im):
+//      acc += fid * delta                          1 mul + 1 add
+//      fid' = fid*T1 + partner(fid)*T2             2 mul + 1 add, partner via DPP quad_perm
+//    with T1 = tw.re and T2 = -tw.im (re lane) / +tw.im (im lane): 5 VALU ops per step instead
+//    of 10, and exactly the reference's roundings (a + (-b) == a - b, addition commutes);
+//  * one wave per workgroup, 32 bins per wave: the N/32 waves spread over as many SIMDs;
+//  * the wave-uniform differences are staged through LDS in blocks of kExactBlock samples
+//    (coalesced vector load of the next block is in flight while the current one is consumed;
+//    LDS broadcasts return in order, so the compiler can wait with counted lgkmcnt).
+constexpr int kExactBlock = 512;
+
+SDFT_D int lane_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false); }
+SDFT_D float partner(float v) { return __int_as_float(lane_partner(__float_as_int(v))); }
+SDFT_D double partner(double v)
 {
-  const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+  const int lo = lane_partner(__double2loint(v)), hi = lane_partner(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <typename FD>
+__global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
+{
+  constexpr int EB = kExactBlock;
+  constexpr int PER = EB / kWave;                       // samples staged per lane
+  __shared__ FD stage[2][EB];
+
+  const int lane = threadIdx.x;
+  const int comp = lane & 1;
+  const unsigned bin = blockIdx.x * (kWave / 2) + (lane >> 1);
   const size_t ch = blockIdx.y;
-  const unsigned kk = k < a.nbins ? k : a.nbins - 1;
+  const bool valid = bin < a.nbins;
+  const unsigned kk = valid ? bin : a.nbins - 1;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
-  BinState<FD> s;
-  s.acc = a.acc_state[ch * a.nbins + kk];
-  s.fid = a.fid_state[ch * a.nbins + kk];
-  s.tw = a.tw[kk];
-  const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
-  unsigned c = a.cursor0;
-  size_t t = 0;
-  for (unsigned j = 0; j < a.chunks; ++j)
+
+  const cx<FD> tw = a.tw[kk];
+  const cx<FD> acc0 = a.acc_state[ch * a.nbins + kk];
+  const cx<FD> fid0 = a.fid_state[ch * a.nbins + kk];
+  const FD T1 = tw.re;
+  const FD T2 = comp ? tw.im : -tw.im;
+  const FD one = comp ? (FD)0 : (FD)1;
+  FD acc = comp ? acc0.im : acc0.re;
+  FD f = comp ? fid0.im : fid0.re;
+
+  FD* carry = reinterpret_cast<FD*>(a.carry);
+  FD* seed = reinterpret_cast<FD*>(a.seed);
+  const FD* d = a.delta + ch * a.n;
+  const size_t total = (size_t)(a.chunks - 1) * a.chunk_len;     // the main kernel runs the last chunk itself
+
+  auto fetch = [&](size_t base, FD (&r)[PER])
   {
-    if (k < a.nbins)
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
     {
-      const size_t o = (ch * a.chunks + j) * a.nbins + k;
-      a.carry[o] = s.acc;
-      a.seed[o] = s.fid;
+      const size_t i = base + (size_t)lane * PER + q;
+      r[q] = (i < total) ? d[i] : (FD)0;
     }
-    if (j + 1 == a.chunks) break;               // the main kernel runs the last chunk itself
-    const size_t t1 = t + a.chunk_len;
-    while (t < t1)
+  };
+  auto put = [&](int buf, const FD (&r)[PER])
+  {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) stage[buf][lane * PER + q] = r[q];
+  };
+  auto dump = [&](unsigned j)
+  {
+    if (valid)
     {
-      size_t run = maxc - c;
-      if (run > t1 - t) run = t1 - t;
-      for (size_t i = 0; i < run; ++i) advance_normal(s, d[t + i]);
-      t += run; c += (unsigned)run;
-      if (t < t1) { advance_wrap(s, d[t]); ++t; c = 0; }
+      const size_t o = (((ch * a.chunks + j) * a.nbins) + bin) * 2 + comp;
+      carry[o] = acc;
+      seed[o] = f;
     }
+  };
+
+  unsigned c = a.cursor0;
+  unsigned j = 0;
+  size_t next_dump = 0;
+  FD regs[PER];
+  fetch(0, regs);
+  put(0, regs);
+  for (size_t base = 0; base < total; base += EB)
+  {
+    const int buf = (int)((base / EB) & 1);
+    const bool more = base + EB < total;
+    if (more) fetch(base + EB, regs);                    // global loads in flight during the block
+    __syncthreads();                                     // single-wave group: orders the LDS writes
+    const unsigned m = (total - base < (size_t)EB) ? (unsigned)(total - base) : (unsigned)EB;
+    unsigned u = 0;
+    while (u < m)
+    {
+      if (base + u == next_dump) { dump(j); ++j; next_dump += a.chunk_len; }
+      unsigned run = m - u;
+      if ((size_t)run > next_dump - (base + u)) run = (unsigned)(next_dump - (base + u));
+      if (run > maxc - c) run = maxc - c;
+      if (run == 0)
+      {
+        // roll-over step (sdft.h:572-573)
+        acc = acc + f * stage[buf][u];
+        f = one;
+        ++u; c = 0;
+        continue;
+      }
+      auto step = [&](FD dl)
+      {
+        if constexpr (sizeof(FD) == 4)
+        {
+          // Pinned sequence (the compiler's packed-math version runs a ~48-cycle dependent chain):
+          // five single-pass VALU ops; `f` was written by the last instruction of the previous
+          // step and is read through DPP by the third one here, i.e. behind two independent
+          // VALU instructions = the two wait states a DPP read of a fresh VGPR needs.
+          float p, m1, m2;
+          asm volatile(
+              "v_mul_f32 %[p], %[f], %[dl]\n\t"
+              "v_mul_f32 %[m1], %[f], %[t1]\n\t"
+              "v_mul_f32_dpp %[m2], %[f], %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_add_f32 %[acc], %[acc], %[p]\n\t"
+              "v_add_f32 %[f], %[m1], %[m2]"
+              : [p] "=&v"(p), [m1] "=&v"(m1), [m2] "=&v"(m2), [acc] "+v"(acc), [f] "+v"(f)
+              : [dl] "v"(dl), [t1] "v"(T1), [t2] "v"(T2));
+        }
+        else
+        {
+          const FD g = partner(f);
+          acc = acc + f * dl;                            // sdft.h:583
+          const FD m1 = f * T1;
+          const FD m2 = g * T2;
+          f = m1 + m2;                                   // sdft.h:584
+        }
+      };
+      constexpr int R = 8;                               // LDS reads are pipelined R samples ahead
+      unsigned i = 0;
+      if (run >= (unsigned)R)
+      {
+        FD cur[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) cur[q] = stage[buf][u + q];
+        for (; i + 2 * R <= run; i += R)
+        {
+          FD nxt[R];
+#pragma unroll
+          for (int q = 0; q < R; ++q) nxt[q] = stage[buf][u + i + R + q];
+#pragma unroll
+          for (int q = 0; q < R; ++q) step(cur[q]);
+#pragma unroll
+          for (int q = 0; q < R; ++q) cur[q] = nxt[q];
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) step(cur[q]);
+        i += R;
+      }
+      for (; i < run; ++i) step(stage[buf][u + i]);
+      u += run; c += run;
+    }
+    if (more) put(buf ^ 1, regs);
   }
+  dump(j);                                               // carry-in of the last chunk (j == chunks-1)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -296,7 +296,7 @@ class Plan
       // row-group kernel: one workgroup per (channel, chunk); aim at a few workgroups per CU
       const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves()) : 1024;
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
-      want = std::max(1L, std::min(want, (long)(n / 64)));
+      want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;
       len = std::max(1L, std::min(len, (long)n));
@@ -368,7 +368,8 @@ class Plan
     }
     else if (exact)
     {
-      hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3(bin_blocks, (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3((unsigned)((nb + kWave / 2 - 1) / (kWave / 2)), (unsigned)channels),
+                         dim3(kWave), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
     }
     else
