@@ -109,10 +109,16 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # one rank per GPU; SDFT_BENCH_BACKEND=gloo lets several ranks share a GPU for functional tests
+    backend = os.environ.get("SDFT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
@@ -219,7 +225,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "forward_kernel",
+            "kernel": "forward_rows_kernel" if plan.get_option("last_kernel") == 2 else "forward_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -54,6 +54,17 @@ if __name__ == "__main__":
         run(1000000, 1024, carry=1)
         run(48000, 1024)
         run(1000000, 1024)
+    if which == "v21":
+        for rep in range(2):
+            run(1000000, 1024)
+            run(1000000, 1024)
+        run(1000000, 1024, rows_kernel=0)
+        run(48000, 1024)
+        run(48000, 1024, channels=64)
+        run(48000, 1024, channels=64)
+        run(262144, 2048, "blackman", "f32f32")
+        run(1000000, 1000)
+        run(1000000, 1024, "blackman")
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

@@ -73,6 +73,27 @@ SDFT_D int lane_from_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1
 SDFT_D int lane_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 #endif
 
+// Variants with an explicit fill value: a whole-wave shift leaves lane 0 (from_below) / lane 63
+// (from_above) without a source lane; with bound_ctrl off that lane keeps `old`.  The row-group
+// kernel passes the neighbouring wave's edge bin there, so crossing a wave boundary costs no
+// select.
+SDFT_D int lane_from_below_fill(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
+SDFT_D int lane_from_above_fill(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false); }
+SDFT_D float from_below_fill(float old, float v) { return __int_as_float(lane_from_below_fill(__float_as_int(old), __float_as_int(v))); }
+SDFT_D float from_above_fill(float old, float v) { return __int_as_float(lane_from_above_fill(__float_as_int(old), __float_as_int(v))); }
+SDFT_D double from_below_fill(double old, double v)
+{
+  const int lo = lane_from_below_fill(__double2loint(old), __double2loint(v));
+  const int hi = lane_from_below_fill(__double2hiint(old), __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+SDFT_D double from_above_fill(double old, double v)
+{
+  const int lo = lane_from_above_fill(__double2loint(old), __double2loint(v));
+  const int hi = lane_from_above_fill(__double2hiint(old), __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 SDFT_D float from_below(float v) { return __int_as_float(lane_from_below(__float_as_int(v))); }
 SDFT_D float from_above(float v) { return __int_as_float(lane_from_above(__float_as_int(v))); }
 SDFT_D double from_below(double v)
@@ -85,6 +106,8 @@ SDFT_D double from_above(double v)
   const int lo = lane_from_above(__double2loint(v)), hi = lane_from_above(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+template <typename T> SDFT_D cx<T> from_below_fill(cx<T> o, cx<T> z) { return cmake<T>(from_below_fill(o.re, z.re), from_below_fill(o.im, z.im)); }
+template <typename T> SDFT_D cx<T> from_above_fill(cx<T> o, cx<T> z) { return cmake<T>(from_above_fill(o.re, z.re), from_above_fill(o.im, z.im)); }
 template <typename T> SDFT_D cx<T> from_below(cx<T> z) { return cmake<T>(from_below(z.re), from_below(z.im)); }
 template <typename T> SDFT_D cx<T> from_above(cx<T> z) { return cmake<T>(from_above(z.re), from_above(z.im)); }
 
@@ -674,19 +697,27 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 (row-group form)  forward for rows that fit one workgroup: N <= 1024*BPL bins.
+// K1 (row-group form)  forward for rows that fit one workgroup: 8 <= N <= 1024*BPL bins.
 //
 // One workgroup = all bins of one (channel, time chunk): wave w owns bins [64*BPL*w, 64*BPL*(w+1)),
-// every lane owns BPL adjacent bins, no halo lanes, no redundant recurrences.  The waves of the
-// group advance in lockstep, kGroup samples at a time:
-//   phase A  run the recurrence for kGroup samples, keep the demodulated bins in registers and
-//            publish the wave's outer lanes (0, 1, 62, 63) to LDS;
-//   barrier  (one per group; the edge buffer is double-buffered)
-//   phase B  window: inner neighbours by DPP wave shifts, neighbours across a wave boundary from
-//            LDS, spectrum edges by conjugate mirroring (sdft.h:589-595); then each wave stores its
-//            1 KiB of the row -- the group writes whole rows back to back, which is the store
-//            stream HBM likes best (store-only kernel: 5.85 TB/s vs 5.5 TB/s for independent tiles).
-// Requires N >= 4 (single reflections only); smaller N use forward_kernel.
+// every lane owns BPL adjacent bins; there are no halo lanes and no redundant recurrences (lanes
+// past bin N-1 in a partial last wave run the mirrored bins, as in forward_kernel, so that the
+// in-wave shifts see the right neighbours).  The waves advance in lockstep, kGroup samples at a
+// time:
+//   phase A  recurrence for kGroup samples; the demodulated bins stay in registers; the bins a
+//            neighbouring wave needs -- or, at the two ends of the spectrum, their conjugate
+//            mirror images (sdft.h:589-595) -- are published to LDS edge slots.  Every lane
+//            issues one unconditional ds_write per owned bin: lanes without a publishing role
+//            write to a private dummy slot, so there is no branching;
+//   barrier  one per group (the edge slots are double-buffered);
+//   phase B  window: neighbours by DPP whole-wave shifts whose fill value (what lane 0 / lane 63
+//            receive) is the neighbouring wave's edge bin read from LDS by a broadcast ds_read --
+//            no selects; then every wave stores its 1 KiB of the row.  The group writes whole
+//            rows back to back, the store stream HBM likes best (store-only kernel: 5.85 TB/s vs
+//            5.5 TB/s for independent tiles).
+// A fused-multiply-add variant of the arithmetic was measured (2.70 vs 2.70 ms at n=1e6, N=1024)
+// and dropped: the kernel is not bound by fp64 issue, and unfused arithmetic keeps "same carry-in
+// => bit-identical to the reference" true for every path.
 // ------------------------------------------------------------------------------------------
 constexpr int kRowWavesMax = 16;
 
@@ -695,8 +726,11 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 {
   constexpr int H = win_halo<WIN>::value;
   constexpr int G = kGroup;
-  // edge[buf][u][wave][slot]: slot 0,1 = first two bins of the wave, 2,3 = last two bins
-  __shared__ cx<FD> edge[2][G][kRowWavesMax][4];
+  constexpr int HS = 2;                                   // edge slots per side (H <= 2)
+  // edgeL[buf][u][wave][i] = bin (first bin of the wave) - 1 - i, edgeR[..][i] = (last bin) + 1 + i
+  __shared__ cx<FD> edgeL[2][G][kRowWavesMax][HS];
+  __shared__ cx<FD> edgeR[2][G][kRowWavesMax][HS];
+  __shared__ cx<FD> dummy[kWave * kRowWavesMax];          // write-only sink for lanes without a role
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -710,87 +744,115 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
-  const long kfirst = ((long)wave * kWave + lane) * BPL;
+  const long wfirst = (long)wave * kWave * BPL;           // first bin of this wave
+  const long wlast = wfirst + (long)kWave * BPL - 1;      // last (possibly virtual) bin of this wave
+  const long kfirst = wfirst + (long)lane * BPL;
   BinState<FD> s[BPL];
-  bool keep[BPL];
+  bool keep[BPL], flip[BPL];
+  // publishing role of each owned bin: LDS destination (element offset inside one [buf][u] slab,
+  // -1 = dummy) and whether the published value is conjugated
+  cx<FD>* pub[BPL];
+  bool pubflip[BPL];
   const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
 #pragma unroll
   for (int b = 0; b < BPL; ++b)
   {
     const long k = kfirst + b;
+    const long kk = reflect_bin(k, nbins, flip[b]);
     keep[b] = k < nbins;
-    const long kk = keep[b] ? k : nbins - 1;
     s[b].tw = a.tw[kk];
     s[b].acc = a.carry[cbase + kk];
     s[b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+
+    pub[b] = &dummy[threadIdx.x];
+    pubflip[b] = false;
+    if (H >= 1 && keep[b])
+    {
+#pragma unroll
+      for (int i = 0; i < HS; ++i)
+      {
+        // next wave's left edge: bins wlast, wlast-1 (only real bins publish)
+        if (wave + 1 < nwaves && k == wlast - i) pub[b] = &edgeL[0][0][wave + 1][i];
+        // previous wave's right edge: bins wfirst, wfirst+1
+        if (wave > 0 && k == wfirst + i) pub[b] = &edgeR[0][0][wave - 1][i];
+        // spectrum ends: mirror images of the virtual bins -1-i and (wlast of the last wave)+1+i
+        if (wave == 0)
+        {
+          bool f; const long r = reflect_bin(-1 - i, nbins, f);
+          if (k == r) { pub[b] = &edgeL[0][0][0][i]; pubflip[b] = f; }
+        }
+        if (wave + 1 == nwaves)
+        {
+          bool f; const long r = reflect_bin(wlast + 1 + i, nbins, f);
+          if (k == r) { pub[b] = &edgeR[0][0][wave][i]; pubflip[b] = f; }
+        }
+      }
+    }
   }
-  // lane roles (constant over time)
-  const long klast = kfirst + BPL - 1;                 // last bin of this lane
-  const bool has_prev = wave > 0, has_next = (wave + 1 < nwaves);
-  const bool bin0 = (kfirst == 0), binN1 = (klast == nbins - 1 || kfirst == nbins - 1);
-  (void)bin0; (void)binN1;
+  constexpr size_t kSlabU = (size_t)kRowWavesMax * HS;    // elements between consecutive u
+  constexpr size_t kSlabBuf = (size_t)G * kSlabU;         // elements between the two buffers
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
   const bool nt = a.nt_store != 0;
   cx<FD>* dst = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + kfirst;
 
-  // window + store of one sample; e[] = X[kfirst-2 .. klast+2]
-  auto finish = [&](const cx<FD> (&x)[BPL], int buf, int u)
+  auto publish = [&](const cx<FD> (&x)[BPL], int buf, int u)
   {
-    cx<FD> e[BPL + 4] = {};
-#pragma unroll
-    for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
-    if constexpr (H >= 1)
-    {
-      e[1] = from_below(x[BPL - 1]);
-      e[BPL + 2] = from_above(x[0]);
-      if (lane == 0 && has_prev) e[1] = edge[buf][u][wave - 1][3];
-      if (lane == kWave - 1 && has_next) e[BPL + 2] = edge[buf][u][wave + 1][0];
-    }
-    if constexpr (H >= 2)
-    {
-      if constexpr (BPL >= 2)
-      {
-        e[0] = from_below(x[BPL - 2]);
-        e[BPL + 3] = from_above(x[1]);
-        if (lane == 0 && has_prev) e[0] = edge[buf][u][wave - 1][2];
-        if (lane == kWave - 1 && has_next) e[BPL + 3] = edge[buf][u][wave + 1][1];
-      }
-      else
-      {
-        e[0] = from_below(e[1]);
-        e[BPL + 3] = from_above(e[BPL + 2]);
-        if (has_prev)
-        {
-          if (lane == 0) e[0] = edge[buf][u][wave - 1][2];
-          if (lane == 1) e[0] = edge[buf][u][wave - 1][3];
-        }
-        if (has_next)
-        {
-          if (lane == kWave - 1) e[BPL + 3] = edge[buf][u][wave + 1][1];
-          if (lane == kWave - 2) e[BPL + 3] = edge[buf][u][wave + 1][0];
-        }
-      }
-    }
-    // spectrum edges: X[-i] = conj X[i], X[N-1+i] = conj X[N-1-i]
     if constexpr (H >= 1)
     {
 #pragma unroll
       for (int b = 0; b < BPL; ++b)
       {
-        const long k = kfirst + b;
-        // left of bin k is e[b+1], e[b]; right is e[b+3], e[b+4]
-        if (k == 0) { e[b + 1] = cconj(e[b + 3]); if constexpr (H >= 2) e[b] = cconj(e[b + 4]); }
-        if constexpr (H >= 2) { if (k == 1) e[b] = cconj(e[b + 2]); }
-        if (k == nbins - 1) { e[b + 3] = cconj(e[b + 1]); if constexpr (H >= 2) e[b + 4] = cconj(e[b]); }
-        if constexpr (H >= 2) { if (k == nbins - 2) e[b + 4] = cconj(e[b + 2]); }
+        cx<FD> v = x[b];
+        if (flip[b] != pubflip[b]) v.im = -v.im;          // lane constant: becomes a sign-bit xor
+        const bool real_slot = (pub[b] != &dummy[threadIdx.x]);
+        cx<FD>* p = pub[b] + (real_slot ? (size_t)buf * kSlabBuf + (size_t)u * kSlabU : 0);
+        *p = v;
+      }
+    }
+  };
+
+  auto finish = [&](const cx<FD> (&xin)[BPL], int buf, int u)
+  {
+    cx<FD> x[BPL];
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) { x[b] = xin[b]; if (flip[b]) x[b].im = -x[b].im; }
+    cx<FD> e[BPL + 4] = {};
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
+    if constexpr (H >= 1)
+    {
+      const cx<FD> l0 = edgeL[buf][u][wave][0], r0 = edgeR[buf][u][wave][0];      // broadcast reads
+      if constexpr (BPL == 1)
+      {
+        e[1] = from_below_fill(l0, x[0]);
+        e[3] = from_above_fill(r0, x[0]);
+        if constexpr (H >= 2)
+        {
+          const cx<FD> l1 = edgeL[buf][u][wave][1], r1 = edgeR[buf][u][wave][1];
+          e[0] = from_below_fill(l1, e[1]);               // lane 1 receives lane 0's e[1] = l0
+          e[4] = from_above_fill(r1, e[3]);
+        }
+      }
+      else
+      {
+        e[1] = from_below_fill(l0, x[BPL - 1]);
+        e[BPL + 2] = from_above_fill(r0, x[0]);
+        if constexpr (H >= 2)
+        {
+          const cx<FD> l1 = edgeL[buf][u][wave][1], r1 = edgeR[buf][u][wave][1];
+          e[0] = from_below_fill(l1, x[BPL - 2]);
+          e[BPL + 3] = from_above_fill(r1, x[1]);
+        }
       }
     }
     cx<FD> y[BPL];
 #pragma unroll
     for (int b = 0; b < BPL; ++b)
+    {
       y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+    }
     if constexpr (BPL == 2)
     {
       if (a.vec_store)
@@ -820,21 +882,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     dst += a.nbins;
   };
 
-  auto publish = [&](const cx<FD> (&x)[BPL], int buf, int u)
+  auto advance = [&](BinState<FD>& st, FD dl, bool wrap) -> cx<FD>
   {
-    if constexpr (H >= 1)
-    {
-      if constexpr (BPL == 1)
-      {
-        if (lane < 2) edge[buf][u][wave][lane] = x[0];
-        if (lane >= kWave - 2) edge[buf][u][wave][lane - (kWave - 4)] = x[0];
-      }
-      else
-      {
-        if (lane == 0) { edge[buf][u][wave][0] = x[0]; edge[buf][u][wave][1] = x[1]; }
-        if (lane == kWave - 1) { edge[buf][u][wave][2] = x[BPL - 2]; edge[buf][u][wave][3] = x[BPL - 1]; }
-      }
-    }
+    return wrap ? step_wrap(st, dl) : step_normal(st, dl);
   };
 
   int buf = 0;
@@ -853,7 +903,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       for (int u = 0; u < G; ++u)
       {
 #pragma unroll
-        for (int b = 0; b < BPL; ++b) xs[u][b] = step_normal(s[b], dl[u]);
+        for (int b = 0; b < BPL; ++b) xs[u][b] = advance(s[b], dl[u], false);
         publish(xs[u], buf, u);
       }
       c += G;
@@ -866,18 +916,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         if (u < m)
         {
           const FD dl = d[t + u];
-          if (c == maxc)
-          {
+          const bool wrap = (c == maxc);
 #pragma unroll
-            for (int b = 0; b < BPL; ++b) xs[u][b] = step_wrap(s[b], dl);
-            c = 0;
-          }
-          else
-          {
-#pragma unroll
-            for (int b = 0; b < BPL; ++b) xs[u][b] = step_normal(s[b], dl);
-            ++c;
-          }
+          for (int b = 0; b < BPL; ++b) xs[u][b] = advance(s[b], dl, wrap);
+          c = wrap ? 0 : c + 1;
           publish(xs[u], buf, u);
         }
       }

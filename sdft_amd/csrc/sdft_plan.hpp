@@ -138,6 +138,7 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
 
   // device-resident stream state
@@ -284,7 +285,7 @@ class Plan
   }
   bool rows_kernel_ok(bool row_pointers) const
   {
-    return opt_rows_kernel && !row_pointers && nbins >= 64 && nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane());
+    return opt_rows_kernel && !row_pointers && nbins >= 8 && nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane());
   }
   long row_waves() const { return (long)((nbins + (size_t)(kWave * bins_per_lane()) - 1) / (size_t)(kWave * bins_per_lane())); }
 
