@@ -65,6 +65,15 @@ if __name__ == "__main__":
         run(262144, 2048, "blackman", "f32f32")
         run(1000000, 1000)
         run(1000000, 1024, "blackman")
+    if which == "fft":
+        for rep in range(2):
+            run(1000000, 1024)
+            run(1000000, 1024, fft_carry=0)
+        run(48000, 1024)
+        run(48000, 1024, fft_carry=0)
+        run(48000, 1024, channels=64)
+        run(48000, 1024, channels=64, fft_carry=0)
+        run(48000, 2048, channels=16)
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

@@ -259,6 +259,54 @@ __global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
     a.carry[(ch * a.chunks + j) * a.nbins + k] = s;
 }
 
+// K1a (FFT form, N a power of two): the same partial sums are the first N bins of a 2N-point DFT
+// of the chunk -- W[j] = exp(-2*pi*i*j/(2N)) is exactly its twiddle table, and chunks longer
+// than 2N fold onto themselves because W has period 2N:
+//   S[k] = W[k*c0] * sum_{v<2N} ( sum_q delta[v + 2N*q] ) * W[k*v].
+// One workgroup per (chunk, channel): fold the chunk into LDS, radix-2 decimation-in-frequency
+// in place (log2(2N) barriers), read bin k from its bit-reversed slot.  O(N log N) per chunk
+// instead of O(L*N): 149 us -> ~15 us at n = 1e6, N = 1024.
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsigned log2m)
+{
+  extern __shared__ __align__(16) unsigned char fft_lds_raw[];
+  cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw);
+  const unsigned m = 1u << log2m;                        // 2N
+  const unsigned j = blockIdx.x;                         // chunk 0 .. chunks-2 (full length)
+  const size_t ch = blockIdx.y;
+  const size_t t0 = (size_t)j * a.chunk_len;
+  const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
+  const FD* d = a.delta + ch * a.n + t0;
+
+  for (unsigned v = threadIdx.x; v < m; v += kBlock)
+  {
+    FD acc = (FD)0;
+    for (size_t u = v; u < a.chunk_len; u += m) acc += d[u];
+    x[v] = cmake<FD>(acc, (FD)0);
+  }
+  __syncthreads();
+  for (unsigned st = 0; st < log2m; ++st)
+  {
+    const unsigned half = m >> (st + 1);
+    for (unsigned i = threadIdx.x; i < (m >> 1); i += kBlock)
+    {
+      const unsigned pos = i & (half - 1);
+      const unsigned lo = ((i - pos) << 1) + pos, hi = lo + half;
+      const cx<FD> p = x[lo], q = x[hi];
+      const cx<FD> w = a.wtab[(size_t)pos << st];       // exp(-2*pi*i*pos/(2*half))
+      x[lo] = cadd(p, q);
+      x[hi] = cmul(csub(p, q), w);
+    }
+    __syncthreads();
+  }
+  for (unsigned k = threadIdx.x; k < a.nbins; k += kBlock)
+  {
+    const unsigned r = __brev(k) >> (32 - log2m);
+    const cx<FD> rot = a.wtab[(size_t)(((unsigned long long)k * c0) % m)];
+    a.carry[(ch * a.chunks + j) * a.nbins + k] = cmul(x[r], rot);
+  }
+}
+
 // K1b: exclusive scan over chunks, in place: carry[j] = acc_state + sum_{i<j} partial[i].
 // Two levels: 16 waves of a workgroup each own a contiguous slice of the chunks of 64 bins,
 // slice totals are combined through LDS.  (partial[chunks-1] does not exist and is not read.)

@@ -138,6 +138,7 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
 
@@ -375,7 +376,16 @@ class Plan
     }
     else
     {
-      hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
+      // partial sums per chunk: FFT form when 2N is a power of two (and fits LDS), direct sums otherwise
+      const size_t span_bytes = span * sizeof(fdx);
+      const bool pow2 = (span & (span - 1)) == 0 && span >= 2;
+      if (opt_fft_carry && pow2 && span_bytes <= (size_t)64 * 1024)
+      {
+        unsigned lg = 0; while (((size_t)1 << lg) < span) ++lg;
+        hipLaunchKernelGGL((chunk_fft_kernel<FD>), dim3((unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), span_bytes, stream, ca, lg);
+      }
+      else
+        hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
       hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)((nb + kWave - 1) / kWave), (unsigned)channels),
                          dim3(kWave * kScanSlices), 0, stream, ca);

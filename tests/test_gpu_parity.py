@@ -200,3 +200,24 @@ def test_row_group_kernel_equals_tile_kernel_and_oracle(combo, m, window):
     assert np.array_equal(got[1], got[0])
     assert np.array_equal(got[1], want), rel_err(got[1], want)
     assert np.array_equal(got[(1, "next")], got[(0, "next")])
+
+
+@pytest.mark.parametrize("m,chunk", [(1024, 512), (1024, 3000), (256, 600), (64, 128), (512, 5000)])
+def test_fft_carry_equals_direct_sums(m, chunk):
+    """Chunk partial sums by the in-LDS FFT (power-of-two N) vs the direct sums vs the oracle, incl.
+    chunks longer than 2N (folding) and a second call that continues from a non-zero cursor."""
+    n = 20000
+    x = noise(n, seed=21)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = ref.sdft(x)
+    x2 = sine_sweep(7000)
+    want2 = ref.sdft(x2)
+    outs = {}
+    for fft in (1, 0):
+        with make(m, "hann", 1.0, "f32f64", chunk=chunk, carry=0, fft_carry=fft) as p:
+            outs[fft] = (p.sdft(x), p.sdft(x2))
+            assert p.get_option("last_chunks") > 1
+    for fft in (1, 0):
+        assert rel_err(outs[fft][0], want) <= 1e-11, (fft, rel_err(outs[fft][0], want))
+        assert rel_err(outs[fft][1], want2) <= 1e-11, (fft, rel_err(outs[fft][1], want2))
+    assert rel_err(outs[1][0], outs[0][0]) <= 1e-12
