@@ -238,9 +238,27 @@ def main():
         },
     }
 
-    # side measurements outside the timed region (rank 0, single GPU): synthesis, PCIe-inclusive path
+    # side measurements outside the timed region (rank 0, single GPU): store-only ceiling,
+    # synthesis, PCIe-inclusive path
     if rank == 0 and not args.no_extras:
         extras = {}
+        # achievable-write ceiling: kernels that do nothing but the store stream,
+        # (a) plain linear fill, (b) the forward kernel's own shape (one workgroup per time chunk
+        # writing whole rows in lockstep, barrier every 8 rows), over the same output buffer
+        from sdft_amd import capi
+        lib = capi.load()
+        if esz == 16 and m % 64 == 0 and m <= 1024:
+            nbytes = count * n * m * esz
+            sync()
+            lin = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 0, m, 64, 1, 5)
+            grp = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 2, m, 8, max(int(plan.get_option("last_chunk_len")), 1), 5)
+            torch.cuda.synchronize()
+            best_ms = min(x for x in (lin, grp) if x > 0)
+            result["roofline"]["store_only_ceiling"] = {
+                "linear_fill_gbs": round(nbytes / (lin * 1e-3) / 1e9, 1),
+                "row_lockstep_gbs": round(nbytes / (grp * 1e-3) / 1e9, 1),
+                "frac_of_best_store_only": round(achieved / (nbytes / (best_ms * 1e-3) / 1e9), 4),
+            }
         y = plan.isdft(out)
         sync(); plan.profile()
         reps = max(3, min(args.steps, 10))

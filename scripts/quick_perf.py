@@ -74,6 +74,49 @@ if __name__ == "__main__":
         run(48000, 1024, channels=64)
         run(48000, 1024, channels=64, fft_carry=0)
         run(48000, 2048, channels=16)
+    if which == "ab":
+        for rep in range(3):
+            run(1000000, 1024)
+            if os.environ.get("SDFT_HIP_LIBRARY") is None:
+                run(1000000, 1024, fused=1)
+        run(48000, 1024, channels=64)
+    if which == "align":
+        n, m = 1000000, 1024
+        x = torch.from_numpy(sine_sweep(n)).cuda()
+        extra = 64 * 1024 * 1024 // 16
+        for trial in range(3):
+            big = torch.empty(n * m + extra, dtype=torch.complex128, device="cuda")
+            print("base address mod 2^30:", hex(big.data_ptr() % (1 << 30)), "mod 2MB:", hex(big.data_ptr() % (1 << 21)), flush=True)
+            p = SDFT(m); p.set_option("profile", 1); p.set_option("async", 1)
+            for off_bytes in (0, 256, 4096, 65536, 1 << 20, (1 << 21) + 4096, 16 << 20, 0):
+                off = off_bytes // 16
+                out = big[off:off + n * m].view(n, m)
+                for _ in range(2): p.sdft(x, out)
+                p.synchronize(); p.profile()
+                for _ in range(5): p.sdft(x, out)
+                p.synchronize(); pr = p.profile()
+                print(f"  offset {off_bytes:>9} B: fwd {pr['forward'][0] / pr['forward'][1]:.3f} ms", flush=True)
+            p.close(); del big, out
+            junk = torch.empty((trial + 1) * 3_000_000_000 // 16, dtype=torch.complex128, device="cuda")   # perturb the next allocation
+    if which == "align2":
+        n, m = 1000000, 1024
+        x = torch.from_numpy(sine_sweep(n)).cuda()
+        slack = 2 << 30
+        big = torch.empty((n * m * 16 + slack) // 16, dtype=torch.complex128, device="cuda")
+        base = big.data_ptr()
+        print("base", hex(base), flush=True)
+        p = SDFT(m); p.set_option("profile", 1); p.set_option("async", 1)
+        G1 = 1 << 30
+        up = (-base) % G1
+        for name, off_bytes in (("1GB aligned", up), ("1GB+2MB", up + (2 << 20)), ("1GB+16MB", up + (16 << 20)), ("1GB+256MB", up + (256 << 20)),
+                                ("1GB+512MB", up + (512 << 20)), ("1GB+768MB+2MB", up + (770 << 20)), ("base", 0), ("1GB aligned", up)):
+            off = off_bytes // 16
+            out = big[off:off + n * m].view(n, m)
+            for _ in range(2): p.sdft(x, out)
+            p.synchronize(); p.profile()
+            for _ in range(5): p.sdft(x, out)
+            p.synchronize(); pr = p.profile()
+            print(f"  {name:>14} addr {hex(out.data_ptr())}: fwd {pr['forward'][0] / pr['forward'][1]:.3f} ms", flush=True)
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

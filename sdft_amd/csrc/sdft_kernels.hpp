@@ -177,6 +177,27 @@ template <typename FD> SDFT_D cx<FD> step_wrap(BinState<FD>& s, FD delta)
   s.fid = cmake<FD>((FD)1, (FD)0);
   return s.acc;
 }
+// Fused-multiply-add forms of the same step, selectable for the chunk-parallel FD double path
+// (option "fused"; its carry-in already differs from the serial reference in summation order):
+// 16 instead of 24 fp64 operations per bin-sample for a Hann window.  Never used in exact-carry
+// mode or for single-chunk calls, which stay bit-identical to the reference.
+template <typename FD> SDFT_D cx<FD> step_normal_fused(BinState<FD>& s, FD delta)
+{
+  s.acc.re = __builtin_fma(s.fid.re, delta, s.acc.re);
+  s.acc.im = __builtin_fma(s.fid.im, delta, s.acc.im);
+  const FD nr = __builtin_fma(s.fid.re, s.tw.re, -(s.fid.im * s.tw.im));
+  const FD ni = __builtin_fma(s.fid.re, s.tw.im, s.fid.im * s.tw.re);
+  s.fid.re = nr; s.fid.im = ni;
+  return cmake<FD>(__builtin_fma(s.acc.re, nr, s.acc.im * ni), __builtin_fma(s.acc.im, nr, -(s.acc.re * ni)));
+}
+template <typename FD> SDFT_D cx<FD> step_wrap_fused(BinState<FD>& s, FD delta)
+{
+  s.acc.re = __builtin_fma(s.fid.re, delta, s.acc.re);
+  s.acc.im = __builtin_fma(s.fid.im, delta, s.acc.im);
+  s.fid = cmake<FD>((FD)1, (FD)0);
+  return s.acc;
+}
+
 // recurrence without the demodulation (carry passes)
 template <typename FD> SDFT_D void advance_normal(BinState<FD>& s, FD delta)
 {
@@ -535,6 +556,35 @@ template <typename FD, int WIN> SDFT_D cx<FD> window_tap(cx<FD> m2, cx<FD> m1, c
   }
 }
 
+// fused variant (see step_normal_fused); w is weight*0.25 for Hann, weight otherwise
+template <typename FD, int WIN> SDFT_D cx<FD> window_tap_fused(cx<FD> m2, cx<FD> m1, cx<FD> c0, cx<FD> p1, cx<FD> p2, FD w)
+{
+  if constexpr (WIN == WIN_HANN)
+  {
+    const cx<FD> b = cadd(m1, p1);                        // ((c0+c0) - b) * w  ==  c0*(2w) - b*w
+    const FD w2 = w + w;
+    return cmake<FD>(__builtin_fma(c0.re, w2, -(b.re * w)), __builtin_fma(c0.im, w2, -(b.im * w)));
+  }
+  else if constexpr (WIN == WIN_HAMMING)
+  {
+    const cx<FD> b = cadd(m1, p1);
+    const FD wa = (FD)(0.54) * w, wb = (FD)(0.23) * w;
+    return cmake<FD>(__builtin_fma(c0.re, wa, -(b.re * wb)), __builtin_fma(c0.im, wa, -(b.im * wb)));
+  }
+  else if constexpr (WIN == WIN_BLACKMAN)
+  {
+    const cx<FD> b = cadd(m1, p1);
+    const cx<FD> d = cadd(m2, p2);
+    const FD wa = (FD)(0.42) * w, wb = (FD)(0.25) * w, wd = (FD)(0.04) * w;
+    return cmake<FD>(__builtin_fma(d.re, wd, __builtin_fma(c0.re, wa, -(b.re * wb))),
+                     __builtin_fma(d.im, wd, __builtin_fma(c0.im, wa, -(b.im * wb))));
+  }
+  else
+  {
+    return cscale(c0, w);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1  forward: recurrence + mirror + window + coalesced store of the (n, N) matrix
 // ------------------------------------------------------------------------------------------
@@ -754,31 +804,31 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 // time:
 //   phase A  recurrence for kGroup samples; the demodulated bins stay in registers; the bins a
 //            neighbouring wave needs -- or, at the two ends of the spectrum, their conjugate
-//            mirror images (sdft.h:589-595) -- are published to LDS edge slots.  Every lane
-//            issues one unconditional ds_write per owned bin: lanes without a publishing role
-//            write to a private dummy slot, so there is no branching;
+//            mirror images (sdft.h:589-595) -- are published to LDS edge slots by the few lanes
+//            that own them (exec-masked ds_write, scalar bookkeeping only);
 //   barrier  one per group (the edge slots are double-buffered);
 //   phase B  window: neighbours by DPP whole-wave shifts whose fill value (what lane 0 / lane 63
 //            receive) is the neighbouring wave's edge bin read from LDS by a broadcast ds_read --
 //            no selects; then every wave stores its 1 KiB of the row.  The group writes whole
 //            rows back to back, the store stream HBM likes best (store-only kernel: 5.85 TB/s vs
 //            5.5 TB/s for independent tiles).
-// A fused-multiply-add variant of the arithmetic was measured (2.70 vs 2.70 ms at n=1e6, N=1024)
-// and dropped: the kernel is not bound by fp64 issue, and unfused arithmetic keeps "same carry-in
-// => bit-identical to the reference" true for every path.
+// FUSED selects fused-multiply-add arithmetic (option "fused", chunk-parallel FD double path only).
 // ------------------------------------------------------------------------------------------
 constexpr int kRowWavesMax = 16;
+#ifndef SDFT_ROW_GROUP
+#define SDFT_ROW_GROUP 8
+#endif
+constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockstep group (one barrier each)
 
-template <typename FD, int BPL, int WIN>
+template <typename FD, int BPL, int WIN, bool FUSED>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a)
 {
   constexpr int H = win_halo<WIN>::value;
-  constexpr int G = kGroup;
+  constexpr int G = kRowGroup;
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
   // edgeL[buf][u][wave][i] = bin (first bin of the wave) - 1 - i, edgeR[..][i] = (last bin) + 1 + i
   __shared__ cx<FD> edgeL[2][G][kRowWavesMax][HS];
   __shared__ cx<FD> edgeR[2][G][kRowWavesMax][HS];
-  __shared__ cx<FD> dummy[kWave * kRowWavesMax];          // write-only sink for lanes without a role
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -800,7 +850,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // publishing role of each owned bin: LDS destination (element offset inside one [buf][u] slab,
   // -1 = dummy) and whether the published value is conjugated
   cx<FD>* pub[BPL];
-  bool pubflip[BPL];
+  bool pubflip[BPL], has_role[BPL];
   const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
 #pragma unroll
   for (int b = 0; b < BPL; ++b)
@@ -812,27 +862,27 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     s[b].acc = a.carry[cbase + kk];
     s[b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
 
-    pub[b] = &dummy[threadIdx.x];
-    pubflip[b] = false;
+    pub[b] = &edgeL[0][0][0][0];
+    pubflip[b] = false; has_role[b] = false;
     if (H >= 1 && keep[b])
     {
 #pragma unroll
       for (int i = 0; i < HS; ++i)
       {
         // next wave's left edge: bins wlast, wlast-1 (only real bins publish)
-        if (wave + 1 < nwaves && k == wlast - i) pub[b] = &edgeL[0][0][wave + 1][i];
+        if (wave + 1 < nwaves && k == wlast - i) { pub[b] = &edgeL[0][0][wave + 1][i]; has_role[b] = true; }
         // previous wave's right edge: bins wfirst, wfirst+1
-        if (wave > 0 && k == wfirst + i) pub[b] = &edgeR[0][0][wave - 1][i];
+        if (wave > 0 && k == wfirst + i) { pub[b] = &edgeR[0][0][wave - 1][i]; has_role[b] = true; }
         // spectrum ends: mirror images of the virtual bins -1-i and (wlast of the last wave)+1+i
         if (wave == 0)
         {
           bool f; const long r = reflect_bin(-1 - i, nbins, f);
-          if (k == r) { pub[b] = &edgeL[0][0][0][i]; pubflip[b] = f; }
+          if (k == r) { pub[b] = &edgeL[0][0][0][i]; pubflip[b] = f; has_role[b] = true; }
         }
         if (wave + 1 == nwaves)
         {
           bool f; const long r = reflect_bin(wlast + 1 + i, nbins, f);
-          if (k == r) { pub[b] = &edgeR[0][0][wave][i]; pubflip[b] = f; }
+          if (k == r) { pub[b] = &edgeR[0][0][wave][i]; pubflip[b] = f; has_role[b] = true; }
         }
       }
     }
@@ -843,7 +893,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
   const bool nt = a.nt_store != 0;
-  cx<FD>* dst = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + kfirst;
+  cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + wfirst;     // wave-uniform
+  const unsigned lane_off = (unsigned)(lane * BPL);
 
   auto publish = [&](const cx<FD> (&x)[BPL], int buf, int u)
   {
@@ -852,11 +903,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 #pragma unroll
       for (int b = 0; b < BPL; ++b)
       {
-        cx<FD> v = x[b];
-        if (flip[b] != pubflip[b]) v.im = -v.im;          // lane constant: becomes a sign-bit xor
-        const bool real_slot = (pub[b] != &dummy[threadIdx.x]);
-        cx<FD>* p = pub[b] + (real_slot ? (size_t)buf * kSlabBuf + (size_t)u * kSlabU : 0);
-        *p = v;
+        if (has_role[b])                                  // a handful of lanes per wave (exec mask)
+        {
+          cx<FD> v = x[b];
+          if (flip[b] != pubflip[b]) v.im = -v.im;
+          pub[b][(size_t)buf * kSlabBuf + (size_t)u * kSlabU] = v;
+        }
       }
     }
   };
@@ -899,8 +951,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 #pragma unroll
     for (int b = 0; b < BPL; ++b)
     {
-      y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+      if constexpr (FUSED) y[b] = window_tap_fused<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+      else y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
     }
+    // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit offset: the
+    // row advance is scalar arithmetic, no per-lane 64-bit pointer bump
+    cx<FD>* p = row + lane_off;
     if constexpr (BPL == 2)
     {
       if (a.vec_store)
@@ -909,13 +965,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         {
           using V = typename StoreVec<FD, 2>::type;
           V v; v.x = y[0].re; v.y = y[0].im; v.z = y[1].re; v.w = y[1].im;
-          store_vec(reinterpret_cast<V*>(dst), v, nt);
+          store_vec(reinterpret_cast<V*>(p), v, nt);
         }
       }
       else
       {
-        if (keep[0]) dst[0] = y[0];
-        if (keep[1]) dst[1] = y[1];
+        if (keep[0]) p[0] = y[0];
+        if (keep[1]) p[1] = y[1];
       }
     }
     else
@@ -924,15 +980,16 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       {
         using V = typename StoreVec<FD, 1>::type;
         V v; v.x = y[0].re; v.y = y[0].im;
-        store_vec(reinterpret_cast<V*>(dst), v, nt);
+        store_vec(reinterpret_cast<V*>(p), v, nt);
       }
     }
-    dst += a.nbins;
+    row += a.nbins;
   };
 
   auto advance = [&](BinState<FD>& st, FD dl, bool wrap) -> cx<FD>
   {
-    return wrap ? step_wrap(st, dl) : step_normal(st, dl);
+    if constexpr (FUSED) return wrap ? step_wrap_fused(st, dl) : step_normal_fused(st, dl);
+    else return wrap ? step_wrap(st, dl) : step_normal(st, dl);
   };
 
   int buf = 0;

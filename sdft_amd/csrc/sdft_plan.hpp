@@ -138,6 +138,8 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
+  long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
@@ -300,7 +302,7 @@ class Plan
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
       want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
       len = (long)((n + want - 1) / want);
-      len = ((len + kGroup - 1) / kGroup) * kGroup;
+      len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
       len = std::max(1L, std::min(len, (long)n));
       chunks = (long)((n + len - 1) / len);
       return;
@@ -408,7 +410,11 @@ class Plan
     fa.nt_store = (int)opt_nt;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)chunks), (unsigned)(row_waves() * kWave));
+    // fused arithmetic only where the result is not claimed bit-identical: FD double with carries
+    // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
+    const bool fused = use_rows && opt_fused && sizeof(FD) == 8 && !use_seed;
+    last_fused = fused;
+    if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)chunks), (unsigned)(row_waves() * kWave), fused);
     else launch_forward(fa, (unsigned)blocks);
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
@@ -417,17 +423,22 @@ class Plan
     return true;
   }
 
-  void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
+  template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
   {
     constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
     const dim3 g(blocks), b(threads);
     switch (window)
     {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN>), g, b, 0, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING>), g, b, 0, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN>), g, b, 0, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR>), g, b, 0, stream, fa); break;
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED>), g, b, 0, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED>), g, b, 0, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED>), g, b, 0, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED>), g, b, 0, stream, fa); break;
     }
+  }
+  void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads, bool fused)
+  {
+    if constexpr (sizeof(FD) == 8) { if (fused) { launch_forward_rows_t<true>(fa, blocks, threads); return; } }
+    launch_forward_rows_t<false>(fa, blocks, threads);
   }
 
   template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
