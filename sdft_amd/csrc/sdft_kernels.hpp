@@ -223,10 +223,13 @@ template <typename FD> struct CarryArgs
   const cx<FD>* wtab;         // [2N]
   cx<FD>* carry;              // [channels][chunks][N]
   cx<FD>* seed;               // [channels][chunks][N]   (exact mode only)
-  const cx<FD>* acc_state;    // [channels][N]
+  const cx<FD>* acc_state;    // [channels][N]  state at the first chunk of this launch
   const cx<FD>* fid_state;    // [channels][N]
+  cx<FD>* acc_next;           // [channels][N]  exact pass: state after the last chunk of this launch
+  cx<FD>* fid_next;           //                (nullptr when the launch ends with the call's last chunk)
   size_t n;
   unsigned nbins, chunks, chunk_len, cursor0;
+  unsigned chunk0, launch_chunks;   // exact pass: this launch covers chunks [chunk0, chunk0 + launch_chunks)
 };
 
 // Closed form instead of the rotation recurrence: with W[j] = exp(-i*pi*j/N) (period 2N, so the
@@ -412,12 +415,18 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
   const FD one = comp ? (FD)0 : (FD)1;
   FD acc = comp ? acc0.im : acc0.re;
   FD f = comp ? fid0.im : fid0.re;
+  FD pend = (FD)0;                 // float path: product not yet added to acc (acc_true = acc + pend)
+  auto drain = [&]() { acc = acc + pend; pend = (FD)0; };
 
   FD* carry = reinterpret_cast<FD*>(a.carry);
   FD* seed = reinterpret_cast<FD*>(a.seed);
-  const FD* d = a.delta + ch * a.n;
-  const size_t total = (size_t)(a.chunks - 1) * a.chunk_len;     // the main kernel runs the last chunk itself
-
+  // this launch: chunks [chunk0, chunk0 + launch_chunks); every chunk is dumped at its start and then
+  // run, except the call's very last chunk, which the forward kernel runs itself
+  const unsigned jend = a.chunk0 + a.launch_chunks;
+  const bool ends_call = (jend == a.chunks);
+  const size_t tbase = (size_t)a.chunk0 * a.chunk_len;
+  const FD* d = a.delta + ch * a.n + tbase;
+  const size_t total = (size_t)(a.launch_chunks - (ends_call ? 1 : 0)) * a.chunk_len;
   auto fetch = [&](size_t base, FD (&r)[PER])
   {
 #pragma unroll
@@ -442,8 +451,8 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
     }
   };
 
-  unsigned c = a.cursor0;
-  unsigned j = 0;
+  unsigned c = (unsigned)(((size_t)a.cursor0 + tbase) % span);
+  unsigned j = a.chunk0;
   size_t next_dump = 0;
   FD regs[PER];
   fetch(0, regs);
@@ -458,13 +467,14 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
     unsigned u = 0;
     while (u < m)
     {
-      if (base + u == next_dump) { dump(j); ++j; next_dump += a.chunk_len; }
+      if (base + u == next_dump) { drain(); dump(j); ++j; next_dump += a.chunk_len; }
       unsigned run = m - u;
       if ((size_t)run > next_dump - (base + u)) run = (unsigned)(next_dump - (base + u));
       if (run > maxc - c) run = maxc - c;
       if (run == 0)
       {
         // roll-over step (sdft.h:572-573)
+        drain();
         acc = acc + f * stage[buf][u];
         f = one;
         ++u; c = 0;
@@ -474,18 +484,20 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
       {
         if constexpr (sizeof(FD) == 4)
         {
-          // Pinned sequence (the compiler's packed-math version runs a ~48-cycle dependent chain):
-          // five single-pass VALU ops; `f` was written by the last instruction of the previous
-          // step and is read through DPP by the third one here, i.e. behind two independent
-          // VALU instructions = the two wait states a DPP read of a fresh VGPR needs.
-          float p, m1, m2;
+          // Pinned sequence (the compiler's packed-math version runs a ~48-cycle dependent chain).
+          // Five single-pass VALU ops ordered so that nothing depends on its predecessor: the
+          // accumulator add is delayed by one step (`pend` holds fid*delta of the previous step;
+          // the order of additions into acc is unchanged), so the instruction after the write of
+          // `f` does not read it, and the DPP read of `f` sits behind two VALU instructions = the
+          // two wait states a DPP read of a fresh VGPR needs.
+          float m1, m2;
           asm volatile(
-              "v_mul_f32 %[p], %[f], %[dl]\n\t"
+              "v_add_f32 %[acc], %[acc], %[pend]\n\t"
               "v_mul_f32 %[m1], %[f], %[t1]\n\t"
               "v_mul_f32_dpp %[m2], %[f], %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-              "v_add_f32 %[acc], %[acc], %[p]\n\t"
+              "v_mul_f32 %[pend], %[f], %[dl]\n\t"
               "v_add_f32 %[f], %[m1], %[m2]"
-              : [p] "=&v"(p), [m1] "=&v"(m1), [m2] "=&v"(m2), [acc] "+v"(acc), [f] "+v"(f)
+              : [m1] "=&v"(m1), [m2] "=&v"(m2), [acc] "+v"(acc), [f] "+v"(f), [pend] "+v"(pend)
               : [dl] "v"(dl), [t1] "v"(T1), [t2] "v"(T2));
         }
         else
@@ -523,7 +535,17 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
     }
     if (more) put(buf ^ 1, regs);
   }
-  dump(j);                                               // carry-in of the last chunk (j == chunks-1)
+  drain();
+  if (ends_call) dump(j);                                // carry-in of the call's last chunk
+  else if (valid)
+  {
+    // hand the running state to the next segment's launch
+    FD* an = reinterpret_cast<FD*>(a.acc_next);
+    FD* fn = reinterpret_cast<FD*>(a.fid_next);
+    const size_t o = ((ch * a.nbins) + bin) * 2 + comp;
+    an[o] = acc;
+    fn[o] = f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -603,6 +625,7 @@ template <typename FD> struct ForwardArgs
   size_t n;
   unsigned long long total_waves;
   unsigned nbins, chunks, chunk_len, tiles, interior_lanes, cursor0;
+  unsigned chunk0, launch_chunks;   // this launch covers time chunks [chunk0, chunk0 + launch_chunks)
   int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
   int nt_store;               // non-temporal hint on the matrix stores
   FD wscale;                  // weight (or weight*0.25 for Hann)
@@ -636,8 +659,8 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 
   const unsigned tile = (unsigned)(wave % a.tiles);
   const unsigned long long rest = wave / a.tiles;
-  const unsigned chunk = (unsigned)(rest % a.chunks);
-  const size_t ch = (size_t)(rest / a.chunks);
+  const unsigned chunk = a.chunk0 + (unsigned)(rest % a.launch_chunks);
+  const size_t ch = (size_t)(rest / a.launch_chunks);
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
@@ -833,8 +856,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  const unsigned chunk = blockIdx.x % a.chunks;
-  const size_t ch = blockIdx.x / a.chunks;
+  const unsigned chunk = a.chunk0 + blockIdx.x % a.launch_chunks;
+  const size_t ch = blockIdx.x / a.launch_chunks;
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;

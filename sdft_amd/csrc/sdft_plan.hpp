@@ -150,6 +150,15 @@ class Plan
   int hist_cur = 0;
   size_t cursor = 0;             // reference cursor (:153)
 
+  // exact-carry mode overlaps the serial pass with the forward kernel: the pass runs on `aux`
+  // in time segments, each segment's forward launch on `stream` waits for its event
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> seg_events;
+  hipEvent_t ev_delta = nullptr;
+  DevBuf<fdx> d_run_acc[2], d_run_fid[2];
+  long opt_segments = 0;         // 0 = heuristic
+  long last_segments = 1;
+
   // workspace
   DevBuf<FD> d_delta;
   DevBuf<fdx> d_carry, d_seed;
@@ -199,6 +208,11 @@ class Plan
     d_tw.release(); d_syn.release(); d_wtab.release(); d_acc.release(); d_fid.release();
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
     d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release();
+    d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
+    if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
+    for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
+    seg_events.clear();
+    if (ev_delta) { (void)hipEventDestroy(ev_delta); ev_delta = nullptr; }
     for (int st = 0; st < ST_COUNT; ++st)
     {
       for (hipEvent_t e : ev_pool[st]) (void)hipEventDestroy(e);
@@ -356,8 +370,10 @@ class Plan
     if (!prof_end(ST_DELTA)) return false;
 
     // carries
+    long segments = 1;
     if (!prof_begin(ST_CARRY)) return false;
     CarryArgs<FD> ca;
+    ca.acc_next = nullptr; ca.fid_next = nullptr; ca.chunk0 = 0; ca.launch_chunks = (unsigned)chunks;
     ca.delta = d_delta.p; ca.tw = d_tw.p; ca.wtab = d_wtab.p; ca.carry = d_carry.p; ca.seed = d_seed.p;
     ca.acc_state = d_acc.p; ca.fid_state = d_fid.p; ca.n = n;
     ca.nbins = (unsigned)nb; ca.chunks = (unsigned)chunks; ca.chunk_len = (unsigned)len; ca.cursor0 = (unsigned)cursor;
@@ -372,9 +388,38 @@ class Plan
     }
     else if (exact)
     {
-      hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3((unsigned)((nb + kWave / 2 - 1) / (kWave / 2)), (unsigned)channels),
-                         dim3(kWave), 0, stream, ca);
-      SDFT_TRY(hipGetLastError());
+      // time segments: the serial pass of segment s+1 (few waves, latency-bound) runs on `aux`
+      // while the forward kernel of segment s streams the matrix on `stream`
+      segments = opt_segments > 0 ? opt_segments : (chunks >= 32 ? 8 : 1);
+      segments = std::max(1L, std::min(segments, chunks));
+      if (segments > 1)
+      {
+        if (!aux) SDFT_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        if (!ev_delta) SDFT_TRY(hipEventCreateWithFlags(&ev_delta, hipEventDisableTiming));
+        while ((long)seg_events.size() < segments)
+        {
+          hipEvent_t e; SDFT_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          seg_events.push_back(e);
+        }
+        for (int q = 0; q < 2; ++q)
+          if (!d_run_acc[q].reserve(channels * nb) || !d_run_fid[q].reserve(channels * nb)) return false;
+        SDFT_TRY(hipEventRecord(ev_delta, stream));                 // delta (and everything before) done
+        SDFT_TRY(hipStreamWaitEvent(aux, ev_delta, 0));
+      }
+      const unsigned eblocks = (unsigned)((nb + kWave / 2 - 1) / (kWave / 2));
+      for (long sg = 0; sg < segments; ++sg)
+      {
+        const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
+        CarryArgs<FD> cs = ca;
+        cs.chunk0 = (unsigned)j0; cs.launch_chunks = (unsigned)(j1 - j0);
+        cs.acc_state = sg == 0 ? d_acc.p : d_run_acc[(sg - 1) & 1].p;
+        cs.fid_state = sg == 0 ? d_fid.p : d_run_fid[(sg - 1) & 1].p;
+        cs.acc_next = d_run_acc[sg & 1].p; cs.fid_next = d_run_fid[sg & 1].p;
+        hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3(eblocks, (unsigned)channels), dim3(kWave), 0,
+                           segments > 1 ? aux : stream, cs);
+        SDFT_TRY(hipGetLastError());
+        if (segments > 1) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
+      }
     }
     else
     {
@@ -409,13 +454,22 @@ class Plan
     fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
     fa.nt_store = (int)opt_nt;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
-    const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    // fused arithmetic only where the result is not claimed bit-identical: FD double with carries
-    // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
-    const bool fused = use_rows && opt_fused && sizeof(FD) == 8 && !use_seed;
-    last_fused = fused;
-    if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)chunks), (unsigned)(row_waves() * kWave), fused);
-    else launch_forward(fa, (unsigned)blocks);
+    last_segments = segments;
+    for (long sg = 0; sg < segments; ++sg)
+    {
+      const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
+      fa.chunk0 = (unsigned)j0; fa.launch_chunks = (unsigned)(j1 - j0);
+      fa.total_waves = (unsigned long long)channels * (unsigned long long)(j1 - j0) * (unsigned long long)ntiles;
+      if (segments > 1) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[sg], 0));
+      const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+      // fused arithmetic only where the result is not claimed bit-identical: FD double with carries
+      // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
+      const bool fused = use_rows && opt_fused && sizeof(FD) == 8 && !use_seed;
+      last_fused = fused;
+      if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused);
+      else launch_forward(fa, (unsigned)blocks);
+      SDFT_TRY(hipGetLastError());
+    }
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
 

@@ -99,16 +99,19 @@ def test_fast_carry_double_chunked(window):
 
 @pytest.mark.parametrize("combo", ["f32f32", "f64f32", "f32f64"])
 @pytest.mark.parametrize("window", ["hann", "blackman"])
-def test_exact_carry_chunked_bit_exact(combo, window):
-    """Exact-carry mode: time chunks seeded by the serial pre-pass reproduce the reference bit for bit."""
+@pytest.mark.parametrize("segments", [1, 3, 7, 30])
+def test_exact_carry_chunked_bit_exact(combo, window, segments):
+    """Exact-carry mode: time chunks seeded by the serial pre-pass reproduce the reference bit for bit,
+    also when the pass runs in time segments on the auxiliary stream, overlapped with the forward
+    launches of earlier segments."""
     td, fd, fdx = O.combo_types(combo)
     m, n = 256, 6000
     x = noise(n, dtype=td)
     ref = O.best(m, window, 1.0, combo)
     want = ref.sdft(x)
-    with make(m, window, 1.0, combo, chunk=200, carry=1) as p:
+    with make(m, window, 1.0, combo, chunk=200, carry=1, segments=segments) as p:
         got = p.sdft(x)
-        assert p.get_option("last_chunks") == 30
+        assert p.get_option("last_chunks") == 30 and p.get_option("last_segments") == segments
         assert np.array_equal(got, want), rel_err(got, want)
         x2 = noise(777, seed=5, dtype=td)
         assert np.array_equal(p.sdft(x2), ref.sdft(x2))
