@@ -398,6 +398,9 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
   constexpr int EB = kExactBlock;
   constexpr int PER = EB / kWave;                       // samples staged per lane
   __shared__ FD stage[2][EB];
+  // This wave is a serial chain that the whole call waits for, and it shares its SIMD with
+  // forward-kernel waves of earlier segments: let it win every issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
 
   const int lane = threadIdx.x;
   const int comp = lane & 1;
@@ -415,8 +418,7 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
   const FD one = comp ? (FD)0 : (FD)1;
   FD acc = comp ? acc0.im : acc0.re;
   FD f = comp ? fid0.im : fid0.re;
-  FD pend = (FD)0;                 // float path: product not yet added to acc (acc_true = acc + pend)
-  auto drain = [&]() { acc = acc + pend; pend = (FD)0; };
+  auto drain = [&]() {};
 
   FD* carry = reinterpret_cast<FD*>(a.carry);
   FD* seed = reinterpret_cast<FD*>(a.seed);
@@ -484,21 +486,25 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
       {
         if constexpr (sizeof(FD) == 4)
         {
-          // Pinned sequence (the compiler's packed-math version runs a ~48-cycle dependent chain).
-          // Five single-pass VALU ops ordered so that nothing depends on its predecessor: the
-          // accumulator add is delayed by one step (`pend` holds fid*delta of the previous step;
-          // the order of additions into acc is unchanged), so the instruction after the write of
-          // `f` does not read it, and the DPP read of `f` sits behind two VALU instructions = the
-          // two wait states a DPP read of a fresh VGPR needs.
-          float m1, m2;
+          // Pinned, packed sequence on the register pair v[40:41] = {fid component, acc component}:
+          //   q        = {f*T1, f*delta}                 v_pk_mul_f32 (f broadcast to both halves)
+          //   v40      = partner(f) * T2                 v_mul_f32_dpp, in place (f is consumed)
+          //   v[40:41] = q + {partner(f)*T2, acc}        v_pk_add_f32  ->  {f', acc'}
+          // Packed f32 mul/add round each half like the scalar ops, so the results are the
+          // reference's bit for bit.  The s_nop supplies the second wait state the DPP read of
+          // v40 needs after the v_pk_add of the previous step (the v_pk_mul is the first).
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          v2f e; e.x = f; e.y = acc;
+          v2f td; td.x = T1; td.y = dl;
+          v2f q;
           asm volatile(
-              "v_add_f32 %[acc], %[acc], %[pend]\n\t"
-              "v_mul_f32 %[m1], %[f], %[t1]\n\t"
-              "v_mul_f32_dpp %[m2], %[f], %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-              "v_mul_f32 %[pend], %[f], %[dl]\n\t"
-              "v_add_f32 %[f], %[m1], %[m2]"
-              : [m1] "=&v"(m1), [m2] "=&v"(m2), [acc] "+v"(acc), [f] "+v"(f), [pend] "+v"(pend)
-              : [dl] "v"(dl), [t1] "v"(T1), [t2] "v"(T2));
+              "v_pk_mul_f32 %[q], v[40:41], %[td] op_sel_hi:[0,1]\n\t"
+              "s_nop 0\n\t"
+              "v_mul_f32_dpp v40, v40, %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+              "v_pk_add_f32 v[40:41], %[q], v[40:41]"
+              : [q] "=&v"(q), "+{v[40:41]}"(e)
+              : [td] "v"(td), [t2] "v"(T2));
+          f = e.x; acc = e.y;
         }
         else
         {
@@ -511,11 +517,64 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
       };
       constexpr int R = 8;                               // LDS reads are pipelined R samples ahead
       unsigned i = 0;
-      if (run >= (unsigned)R)
+      if constexpr (sizeof(FD) == 4)
+      {
+        // Hand-written inner loop for long runs, 32 samples per trip: the differences come
+        // straight from memory over the scalar unit (two alternating s_load_dwordx16 bursts, the
+        // next one in flight while the current one is consumed), and a step is four VALU
+        // instructions on pinned registers, v[40:41] = {fid component, acc component}:
+        //   v42 = f*T1 ; v43 = f*delta ; v40 = partner(f)*T2 (DPP, in place) ;
+        //   v[40:41] = v[42:43] + v[40:41]  ->  {f', acc'}
+        // The two multiplies between the packed add and the DPP read of v40 are the two wait
+        // states that read needs.  Same roundings as the scalar formulation (bit-exact tests).
+        // The burst prefetch reads up to 64 floats past the run: the delta buffer is padded.
+        if (run >= 32u)
+        {
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          v2f e; e.x = f; e.y = acc;
+          unsigned trips = run / 32u;
+          const FD* src = d + base + u;
+          asm volatile(
+              "s_load_dwordx16 s[64:79], s[96:97], 0x0\n\t"
+              "s_waitcnt lgkmcnt(0)\n"
+              "1:\n\t"
+              "s_load_dwordx16 s[80:95], s[96:97], 0x40\n\t"
+#define SDFT_EXACT_STEP(sr)                                                                          \
+              "v_mul_f32 v42, v40, %[t1]\n\t"                                                        \
+              "v_mul_f32 v43, " sr ", v40\n\t"                                                       \
+              "v_mul_f32_dpp v40, v40, %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     \
+              "v_pk_add_f32 v[40:41], v[42:43], v[40:41]\n\t"
+              SDFT_EXACT_STEP("s64") SDFT_EXACT_STEP("s65") SDFT_EXACT_STEP("s66") SDFT_EXACT_STEP("s67")
+              SDFT_EXACT_STEP("s68") SDFT_EXACT_STEP("s69") SDFT_EXACT_STEP("s70") SDFT_EXACT_STEP("s71")
+              SDFT_EXACT_STEP("s72") SDFT_EXACT_STEP("s73") SDFT_EXACT_STEP("s74") SDFT_EXACT_STEP("s75")
+              SDFT_EXACT_STEP("s76") SDFT_EXACT_STEP("s77") SDFT_EXACT_STEP("s78") SDFT_EXACT_STEP("s79")
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "s_load_dwordx16 s[64:79], s[96:97], 0x80\n\t"
+              SDFT_EXACT_STEP("s80") SDFT_EXACT_STEP("s81") SDFT_EXACT_STEP("s82") SDFT_EXACT_STEP("s83")
+              SDFT_EXACT_STEP("s84") SDFT_EXACT_STEP("s85") SDFT_EXACT_STEP("s86") SDFT_EXACT_STEP("s87")
+              SDFT_EXACT_STEP("s88") SDFT_EXACT_STEP("s89") SDFT_EXACT_STEP("s90") SDFT_EXACT_STEP("s91")
+              SDFT_EXACT_STEP("s92") SDFT_EXACT_STEP("s93") SDFT_EXACT_STEP("s94") SDFT_EXACT_STEP("s95")
+#undef SDFT_EXACT_STEP
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "s_add_u32 s96, s96, 0x80\n\t"
+              "s_addc_u32 s97, s97, 0\n\t"
+              "s_sub_u32 s98, s98, 1\n\t"
+              "s_cmp_lg_u32 s98, 0\n\t"
+              "s_cbranch_scc1 1b"
+              : "+{v[40:41]}"(e), "+{s[96:97]}"(src), "+{s98}"(trips)
+              : [t1] "v"(T1), [t2] "v"(T2)
+              : "v42", "v43", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
+                "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+                "s92", "s93", "s94", "s95", "scc", "memory");
+          f = e.x; acc = e.y;
+          i = (run / 32u) * 32u;
+        }
+      }
+      if (run - i >= (unsigned)R)
       {
         FD cur[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) cur[q] = stage[buf][u + q];
+        for (int q = 0; q < R; ++q) cur[q] = stage[buf][u + i + q];
         for (; i + 2 * R <= run; i += R)
         {
           FD nxt[R];

@@ -317,6 +317,7 @@ class Plan
       want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
+      if (carry_mode == CARRY_EXACT) len = ((len + 31) / 32) * 32;   // whole trips of the exact pass's inner loop
       len = std::max(1L, std::min(len, (long)n));
       chunks = (long)((n + len - 1) / len);
       return;
@@ -331,6 +332,7 @@ class Plan
       want = std::max(1L, std::min(want, (long)(n / min_len)));
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;        // whole scalar-load groups (and sum blocks)
+      if (carry_mode == CARRY_EXACT) len = ((len + 31) / 32) * 32;   // whole trips of the exact pass's inner loop
     }
     len = std::max(1L, std::min(len, (long)n));
     chunks = (long)((n + len - 1) / len);
@@ -352,7 +354,7 @@ class Plan
     last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
 
-    if (!d_delta.reserve(channels * n)) return false;
+    if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
     const bool exact = (carry_mode == CARRY_EXACT);
     if ((exact || chunks == 1) && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
