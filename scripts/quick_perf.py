@@ -117,6 +117,15 @@ if __name__ == "__main__":
             for _ in range(5): p.sdft(x, out)
             p.synchronize(); pr = p.profile()
             print(f"  {name:>14} addr {hex(out.data_ptr())}: fwd {pr['forward'][0] / pr['forward'][1]:.3f} ms", flush=True)
+    if which == "slots":
+        for rep in range(2):
+            run(262144, 4096, "blackman", "f32f32")
+            run(262144, 4096, "blackman", "f32f32", row_slots_max=1)
+            run(48000, 2048, channels=16)
+            run(48000, 2048, channels=16, row_slots_max=1)
+        run(262144, 2048, "hann")
+        run(262144, 2048, "hann", row_slots_max=1)
+        run(1000000, 1024)
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

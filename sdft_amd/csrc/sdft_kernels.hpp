@@ -902,19 +902,27 @@ constexpr int kRowWavesMax = 16;
 #endif
 constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockstep group (one barrier each)
 
-template <typename FD, int BPL, int WIN, bool FUSED>
+// Rows longer than 1024*BPL bins: every lane owns S "slots"; slot q of physical wave w is the
+// virtual wave v = q*nwaves + w, which covers bins [64*BPL*v, 64*BPL*(v+1)).  Edge slots in LDS
+// are indexed by virtual wave, so slot boundaries are crossed exactly like wave boundaries.  The
+// lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
+constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
+
+template <typename FD, int BPL, int WIN, bool FUSED, int S>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a)
 {
   constexpr int H = win_halo<WIN>::value;
-  constexpr int G = kRowGroup;
+  constexpr int G = (kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2;   // keeps registers roughly constant
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
-  // edgeL[buf][u][wave][i] = bin (first bin of the wave) - 1 - i, edgeR[..][i] = (last bin) + 1 + i
-  __shared__ cx<FD> edgeL[2][G][kRowWavesMax][HS];
-  __shared__ cx<FD> edgeR[2][G][kRowWavesMax][HS];
+  constexpr int VW = kRowWavesMax * S;                    // virtual waves
+  // edgeL[buf][u][v][i] = bin (first bin of virtual wave v) - 1 - i, edgeR[..][i] = (last bin) + 1 + i
+  __shared__ cx<FD> edgeL[2][G][VW][HS];
+  __shared__ cx<FD> edgeR[2][G][VW][HS];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
+  const int nv = nwaves * S;
   const unsigned chunk = a.chunk0 + blockIdx.x % a.launch_chunks;
   const size_t ch = blockIdx.x / a.launch_chunks;
 
@@ -924,145 +932,163 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
-  const long wfirst = (long)wave * kWave * BPL;           // first bin of this wave
-  const long wlast = wfirst + (long)kWave * BPL - 1;      // last (possibly virtual) bin of this wave
-  const long kfirst = wfirst + (long)lane * BPL;
-  BinState<FD> s[BPL];
-  bool keep[BPL], flip[BPL];
-  // publishing role of each owned bin: LDS destination (element offset inside one [buf][u] slab,
-  // -1 = dummy) and whether the published value is conjugated
-  cx<FD>* pub[BPL];
-  bool pubflip[BPL], has_role[BPL];
+  const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
+  BinState<FD> s[S][BPL];
+  bool keep[S][BPL], flip[S][BPL];
+  // publishing role of each owned bin: LDS destination and whether the published value is conjugated
+  cx<FD>* pub[S][BPL];
+  bool pubflip[S][BPL], has_role[S][BPL];
   const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
 #pragma unroll
-  for (int b = 0; b < BPL; ++b)
+  for (int q = 0; q < S; ++q)
   {
-    const long k = kfirst + b;
-    const long kk = reflect_bin(k, nbins, flip[b]);
-    keep[b] = k < nbins;
-    s[b].tw = a.tw[kk];
-    s[b].acc = a.carry[cbase + kk];
-    s[b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
-
-    pub[b] = &edgeL[0][0][0][0];
-    pubflip[b] = false; has_role[b] = false;
-    if (H >= 1 && keep[b])
-    {
+    const int v = q * nwaves + wave;
+    const long wfirst = (long)v * kWave * BPL;            // first bin of this virtual wave
+    const long wlast = wfirst + (long)kWave * BPL - 1;
 #pragma unroll
-      for (int i = 0; i < HS; ++i)
+    for (int b = 0; b < BPL; ++b)
+    {
+      const long k = wfirst + (long)lane * BPL + b;
+      const long kk = reflect_bin(k, nbins, flip[q][b]);
+      keep[q][b] = k < nbins;
+      s[q][b].tw = a.tw[kk];
+      s[q][b].acc = a.carry[cbase + kk];
+      s[q][b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+
+      pub[q][b] = &edgeL[0][0][0][0];
+      pubflip[q][b] = false; has_role[q][b] = false;
+      if (H >= 1)
       {
-        // next wave's left edge: bins wlast, wlast-1 (only real bins publish)
-        if (wave + 1 < nwaves && k == wlast - i) { pub[b] = &edgeL[0][0][wave + 1][i]; has_role[b] = true; }
-        // previous wave's right edge: bins wfirst, wfirst+1
-        if (wave > 0 && k == wfirst + i) { pub[b] = &edgeR[0][0][wave - 1][i]; has_role[b] = true; }
-        // spectrum ends: mirror images of the virtual bins -1-i and (wlast of the last wave)+1+i
-        if (wave == 0)
+        // neighbour roles hold for real bins and for in-group mirror lanes alike (a row may end
+        // one bin into a virtual wave: its neighbour still needs two bins from it)
+#pragma unroll
+        for (int i = 0; i < HS; ++i)
         {
-          bool f; const long r = reflect_bin(-1 - i, nbins, f);
-          if (k == r) { pub[b] = &edgeL[0][0][0][i]; pubflip[b] = f; has_role[b] = true; }
+          // next virtual wave's left edge: bins wlast, wlast-1
+          if (v + 1 < nv && k == wlast - i) { pub[q][b] = &edgeL[0][0][v + 1][i]; has_role[q][b] = true; }
+          // previous virtual wave's right edge: bins wfirst, wfirst+1
+          if (v > 0 && k == wfirst + i) { pub[q][b] = &edgeR[0][0][v - 1][i]; has_role[q][b] = true; }
         }
-        if (wave + 1 == nwaves)
+#pragma unroll
+        for (int i = 0; i < HS; ++i)
         {
-          bool f; const long r = reflect_bin(wlast + 1 + i, nbins, f);
-          if (k == r) { pub[b] = &edgeR[0][0][wave][i]; pubflip[b] = f; has_role[b] = true; }
+          // spectrum ends: mirror images of the virtual bins -1-i and vlast_bin+1+i
+          bool f0; const long r0 = reflect_bin(-1 - i, nbins, f0);
+          if (k == r0) { pub[q][b] = &edgeL[0][0][0][i]; pubflip[q][b] = f0; has_role[q][b] = true; }
+          // (the right-hand images are consumed only if the group's last lanes own real bins, i.e.
+          // fewer than H virtual bins follow bin N-1; otherwise in-wave mirror lanes serve them and a
+          // bin must not lose its other role to a publish nobody reads)
+          if (vlast_bin - (nbins - 1) < H)
+          {
+            bool f1; const long r1 = reflect_bin(vlast_bin + 1 + i, nbins, f1);
+            if (k == r1) { pub[q][b] = &edgeR[0][0][nv - 1][i]; pubflip[q][b] = f1; has_role[q][b] = true; }
+          }
         }
       }
     }
   }
-  constexpr size_t kSlabU = (size_t)kRowWavesMax * HS;    // elements between consecutive u
+  constexpr size_t kSlabU = (size_t)VW * HS;              // elements between consecutive u
   constexpr size_t kSlabBuf = (size_t)G * kSlabU;         // elements between the two buffers
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
   const bool nt = a.nt_store != 0;
-  cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + wfirst;     // wave-uniform
-  const unsigned lane_off = (unsigned)(lane * BPL);
+  cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins;     // wave-uniform row base
+  const unsigned lane_off = (unsigned)((wave * kWave + lane) * BPL);
+  const unsigned slot_stride = (unsigned)(nwaves * kWave * BPL);
 
-  auto publish = [&](const cx<FD> (&x)[BPL], int buf, int u)
+  auto publish = [&](const cx<FD> (&x)[S][BPL], int buf, int u)
   {
     if constexpr (H >= 1)
     {
 #pragma unroll
-      for (int b = 0; b < BPL; ++b)
-      {
-        if (has_role[b])                                  // a handful of lanes per wave (exec mask)
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int b = 0; b < BPL; ++b)
         {
-          cx<FD> v = x[b];
-          if (flip[b] != pubflip[b]) v.im = -v.im;
-          pub[b][(size_t)buf * kSlabBuf + (size_t)u * kSlabU] = v;
+          if (has_role[q][b])                             // a handful of lanes per wave (exec mask)
+          {
+            cx<FD> v = x[q][b];
+            if (flip[q][b] != pubflip[q][b]) v.im = -v.im;
+            pub[q][b][(size_t)buf * kSlabBuf + (size_t)u * kSlabU] = v;
+          }
         }
-      }
     }
   };
 
-  auto finish = [&](const cx<FD> (&xin)[BPL], int buf, int u)
+  auto finish = [&](const cx<FD> (&xin)[S][BPL], int buf, int u)
   {
-    cx<FD> x[BPL];
 #pragma unroll
-    for (int b = 0; b < BPL; ++b) { x[b] = xin[b]; if (flip[b]) x[b].im = -x[b].im; }
-    cx<FD> e[BPL + 4] = {};
-#pragma unroll
-    for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
-    if constexpr (H >= 1)
+    for (int q = 0; q < S; ++q)
     {
-      const cx<FD> l0 = edgeL[buf][u][wave][0], r0 = edgeR[buf][u][wave][0];      // broadcast reads
-      if constexpr (BPL == 1)
+      const int v = q * nwaves + wave;
+      cx<FD> x[BPL];
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) { x[b] = xin[q][b]; if (flip[q][b]) x[b].im = -x[b].im; }
+      cx<FD> e[BPL + 4] = {};
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
+      if constexpr (H >= 1)
       {
-        e[1] = from_below_fill(l0, x[0]);
-        e[3] = from_above_fill(r0, x[0]);
-        if constexpr (H >= 2)
+        const cx<FD> l0 = edgeL[buf][u][v][0], r0 = edgeR[buf][u][v][0];        // broadcast reads
+        if constexpr (BPL == 1)
         {
-          const cx<FD> l1 = edgeL[buf][u][wave][1], r1 = edgeR[buf][u][wave][1];
-          e[0] = from_below_fill(l1, e[1]);               // lane 1 receives lane 0's e[1] = l0
-          e[4] = from_above_fill(r1, e[3]);
+          e[1] = from_below_fill(l0, x[0]);
+          e[3] = from_above_fill(r0, x[0]);
+          if constexpr (H >= 2)
+          {
+            const cx<FD> l1 = edgeL[buf][u][v][1], r1 = edgeR[buf][u][v][1];
+            e[0] = from_below_fill(l1, e[1]);             // lane 1 receives lane 0's e[1] = l0
+            e[4] = from_above_fill(r1, e[3]);
+          }
+        }
+        else
+        {
+          e[1] = from_below_fill(l0, x[BPL - 1]);
+          e[BPL + 2] = from_above_fill(r0, x[0]);
+          if constexpr (H >= 2)
+          {
+            const cx<FD> l1 = edgeL[buf][u][v][1], r1 = edgeR[buf][u][v][1];
+            e[0] = from_below_fill(l1, x[BPL - 2]);
+            e[BPL + 3] = from_above_fill(r1, x[1]);
+          }
+        }
+      }
+      cx<FD> y[BPL];
+#pragma unroll
+      for (int b = 0; b < BPL; ++b)
+      {
+        if constexpr (FUSED) y[b] = window_tap_fused<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+        else y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+      }
+      // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit offset: the
+      // row advance is scalar arithmetic, no per-lane 64-bit pointer bump
+      cx<FD>* p = row + (lane_off + (unsigned)q * slot_stride);
+      if constexpr (BPL == 2)
+      {
+        if (a.vec_store)
+        {
+          if (keep[q][0])
+          {
+            using V = typename StoreVec<FD, 2>::type;
+            V vv; vv.x = y[0].re; vv.y = y[0].im; vv.z = y[1].re; vv.w = y[1].im;
+            store_vec(reinterpret_cast<V*>(p), vv, nt);
+          }
+        }
+        else
+        {
+          if (keep[q][0]) p[0] = y[0];
+          if (keep[q][1]) p[1] = y[1];
         }
       }
       else
       {
-        e[1] = from_below_fill(l0, x[BPL - 1]);
-        e[BPL + 2] = from_above_fill(r0, x[0]);
-        if constexpr (H >= 2)
+        if (keep[q][0])
         {
-          const cx<FD> l1 = edgeL[buf][u][wave][1], r1 = edgeR[buf][u][wave][1];
-          e[0] = from_below_fill(l1, x[BPL - 2]);
-          e[BPL + 3] = from_above_fill(r1, x[1]);
+          using V = typename StoreVec<FD, 1>::type;
+          V vv; vv.x = y[0].re; vv.y = y[0].im;
+          store_vec(reinterpret_cast<V*>(p), vv, nt);
         }
-      }
-    }
-    cx<FD> y[BPL];
-#pragma unroll
-    for (int b = 0; b < BPL; ++b)
-    {
-      if constexpr (FUSED) y[b] = window_tap_fused<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
-      else y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
-    }
-    // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit offset: the
-    // row advance is scalar arithmetic, no per-lane 64-bit pointer bump
-    cx<FD>* p = row + lane_off;
-    if constexpr (BPL == 2)
-    {
-      if (a.vec_store)
-      {
-        if (keep[0])
-        {
-          using V = typename StoreVec<FD, 2>::type;
-          V v; v.x = y[0].re; v.y = y[0].im; v.z = y[1].re; v.w = y[1].im;
-          store_vec(reinterpret_cast<V*>(p), v, nt);
-        }
-      }
-      else
-      {
-        if (keep[0]) p[0] = y[0];
-        if (keep[1]) p[1] = y[1];
-      }
-    }
-    else
-    {
-      if (keep[0])
-      {
-        using V = typename StoreVec<FD, 1>::type;
-        V v; v.x = y[0].re; v.y = y[0].im;
-        store_vec(reinterpret_cast<V*>(p), v, nt);
       }
     }
     row += a.nbins;
@@ -1079,7 +1105,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   while (t < t1)                       // all waves of the group take identical trip counts
   {
     const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
-    cx<FD> xs[G][BPL];
+    cx<FD> xs[G][S][BPL];
     // phase A
     if (m == G && c + G <= maxc)
     {
@@ -1090,7 +1116,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       for (int u = 0; u < G; ++u)
       {
 #pragma unroll
-        for (int b = 0; b < BPL; ++b) xs[u][b] = advance(s[b], dl[u], false);
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) xs[u][q][b] = advance(s[q][b], dl[u], false);
         publish(xs[u], buf, u);
       }
       c += G;
@@ -1105,7 +1133,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           const FD dl = d[t + u];
           const bool wrap = (c == maxc);
 #pragma unroll
-          for (int b = 0; b < BPL; ++b) xs[u][b] = advance(s[b], dl, wrap);
+          for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) xs[u][q][b] = advance(s[q][b], dl, wrap);
           c = wrap ? 0 : c + 1;
           publish(xs[u], buf, u);
         }
@@ -1123,12 +1153,15 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   if (chunk + 1 == a.chunks)
   {
 #pragma unroll
-    for (int b = 0; b < BPL; ++b)
-      if (keep[b])
-      {
-        a.acc_state[ch * a.nbins + kfirst + b] = s[b].acc;
-        a.fid_state[ch * a.nbins + kfirst + b] = s[b].fid;
-      }
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int b = 0; b < BPL; ++b)
+        if (keep[q][b])
+        {
+          const size_t k = (size_t)(q * nwaves + wave) * kWave * BPL + (size_t)lane * BPL + b;
+          a.acc_state[ch * a.nbins + k] = s[q][b].acc;
+          a.fid_state[ch * a.nbins + k] = s[q][b].fid;
+        }
   }
 }
 

@@ -138,6 +138,7 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
   long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
@@ -302,9 +303,21 @@ class Plan
   }
   bool rows_kernel_ok(bool row_pointers) const
   {
-    return opt_rows_kernel && !row_pointers && nbins >= 8 && nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane());
+    return opt_rows_kernel && !row_pointers && nbins >= 8 &&
+           nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane()) * (size_t)std::min<long>(kRowSlotsMax, std::max<long>(1, opt_row_slots_max));
   }
-  long row_waves() const { return (long)((nbins + (size_t)(kWave * bins_per_lane()) - 1) / (size_t)(kWave * bins_per_lane())); }
+  // slots per lane (1, 2 or 4) and physical waves of the row group
+  long row_slots() const
+  {
+    const size_t per = (size_t)(kWave * kRowWavesMax * bins_per_lane());
+    const long need = (long)((nbins + per - 1) / per);
+    return need <= 1 ? 1 : 2;
+  }
+  long row_waves() const
+  {
+    const size_t per = (size_t)(kWave * bins_per_lane()) * (size_t)row_slots();
+    return (long)((nbins + per - 1) / per);
+  }
 
   // time chunking: enough waves to fill 256 CUs, chunks not shorter than min_len samples
   void choose_chunks(size_t n, long& chunks, long& len, bool rows_kernel = false) const
@@ -312,7 +325,8 @@ class Plan
     if (rows_kernel && opt_chunk <= 0 && n >= 512)
     {
       // row-group kernel: one workgroup per (channel, chunk); aim at a few workgroups per CU
-      const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves()) : 1024;
+      const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves())
+                                                      : 1024;
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
       want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
       len = (long)((n + want - 1) / want);
@@ -392,7 +406,9 @@ class Plan
     {
       // time segments: the serial pass of segment s+1 (few waves, latency-bound) runs on `aux`
       // while the forward kernel of segment s streams the matrix on `stream`
-      segments = opt_segments > 0 ? opt_segments : (chunks >= 32 ? 8 : 1);
+      // up to 8 segments, each forward launch still filling the chip (>= 256 workgroups)
+      const long launch_blocks = use_rows ? (long)channels * chunks : (long)channels * chunks * ntiles / kWavesPerBlock;
+      segments = opt_segments > 0 ? opt_segments : std::max(1L, std::min(8L, launch_blocks / 256));
       segments = std::max(1L, std::min(segments, chunks));
       if (segments > 1)
       {
@@ -479,16 +495,24 @@ class Plan
     return true;
   }
 
-  template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
+  template <bool FUSED, int S> void launch_forward_rows_ts(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
   {
     constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
     const dim3 g(blocks), b(threads);
     switch (window)
     {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED>), g, b, 0, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED>), g, b, 0, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED>), g, b, 0, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED>), g, b, 0, stream, fa); break;
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S>), g, b, 0, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S>), g, b, 0, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S>), g, b, 0, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S>), g, b, 0, stream, fa); break;
+    }
+  }
+  template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
+  {
+    switch (row_slots())
+    {
+      case 1:  launch_forward_rows_ts<FUSED, 1>(fa, blocks, threads); break;
+      default: launch_forward_rows_ts<FUSED, 2>(fa, blocks, threads); break;
     }
   }
   void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads, bool fused)

@@ -85,6 +85,20 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_cpp_facade_compiles_for_all_type_pairs(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text("#include <sdft/sdft.h>\n"
+                   "template <class T, class F> int use() { sdft::SDFT<T, F> s(8, sdft::Window::Blackman, 0.5); std::complex<F> d[8]; T y;"
+                   " s.sdft(T(1), d); y = s.isdft(d); s.reset(); return (int)s.size() + (int)y; }\n"
+                   "int main() { return use<float, double>() + use<float, float>() + use<double, double>() + use<double, float>(); }\n")
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(INC, "cpp"), "-c", str(src), "-o", str(tmp_path / "t.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", str(tmp_path / "t.o")], capture_output=True, text=True).stdout
+    for suf in ("f32f64", "f32f32", "f64f64", "f64f32"):
+        assert f"sdft_hip_sdft_n_{suf}" in nm or f"sdft_hip_sdft_{suf}" in nm
+
+
 def test_kernels_contain_no_fused_multiply_add(hip_library):
     """Parity depends on unfused a*b+c in the recurrence: check the ISA."""
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"

@@ -56,3 +56,32 @@ def test_c_host_streaming(tmp_path, hip_library, flags, combo):
     tol = 1e-6 if combo.endswith("f64") else 1e-4
     want_y = np.concatenate(ys)
     assert np.abs(got_y - want_y).max() <= tol * np.abs(want_y).max()
+
+
+@pytest.mark.parametrize("t,f,combo", [("float", "double", "f32f64"), ("double", "double", "f64f64"), ("float", "float", "f32f32")])
+def test_cpp_facade_host(tmp_path, hip_library, t, f, combo):
+    """C++ host using sdft::SDFT<T, F> (include/sdft/sdft.hpp, the reference's C++ interface) in the
+    shape of the reference's cpp/examples/bench.cpp, compared with the oracle."""
+    td, fd, fdx = O.combo_types(combo)
+    libdir = os.path.dirname(hip_library)
+    rt = hip_runtime_dir()
+    exe = tmp_path / "host_bench"
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", f"-DHOST_T={t}", f"-DHOST_F={f}", "-I", os.path.join(ROOT, "include", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "host_bench.cpp"), "-o", str(exe),
+           "-L", libdir, "-lsdft_hip", "-L", rt, "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m, n = 1000, 441                      # hops below 512 samples: serial path, bit-identical
+    x = noise(n, seed=9, dtype=td)
+    x.tofile(tmp_path / "x.raw")
+    r = subprocess.run([str(exe), str(m), "1", "1", str(tmp_path / "x.raw"), str(tmp_path / "y.raw"), str(tmp_path / "d.raw")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CPP-HOST ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    ref = O.best(m, "hann", 1.0, combo)
+    want = ref.sdft(x)
+    got = np.fromfile(tmp_path / "d.raw", dtype=fdx).reshape(n, m)
+    assert np.array_equal(got, want)
+    want_y = ref.isdft(want)
+    got_y = np.fromfile(tmp_path / "y.raw", dtype=td)
+    tol = 1e-6 if combo.endswith("f64") else 1e-4
+    assert np.abs(got_y - want_y).max() <= tol * np.abs(want_y).max()

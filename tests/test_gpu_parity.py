@@ -183,7 +183,10 @@ def test_config1_shape_n48000():
 
 
 @pytest.mark.parametrize("combo,m", [("f32f64", 64), ("f32f64", 1000), ("f32f64", 1024), ("f32f64", 127), ("f32f32", 2048),
-                                     ("f32f32", 130), ("f64f64", 512), ("f64f32", 1001)])
+                                     ("f32f32", 130), ("f64f64", 512), ("f64f32", 1001),
+                                     # two slots per lane (rows longer than one pass of the 16 waves)
+                                     ("f32f64", 2048), ("f32f64", 1025), ("f32f64", 1500), ("f32f32", 4096), ("f32f32", 2049),
+                                     ("f64f32", 3001)])
 @pytest.mark.parametrize("window", ["hann", "blackman", "boxcar", "hamming"])
 def test_row_group_kernel_equals_tile_kernel_and_oracle(combo, m, window):
     """The two forward kernels (row-group with LDS halo exchange / independent tiles with halo lanes)
