@@ -126,6 +126,27 @@ if __name__ == "__main__":
         run(262144, 2048, "hann")
         run(262144, 2048, "hann", row_slots_max=1)
         run(1000000, 1024)
+    if which == "inv2":
+        for rep in range(2):
+            for rw in (16, 32, 64):
+                run(1000000, 1024, inverse_rows=rw)
+            run(1000000, 1024, exact_inverse=0)
+        for rw in (16, 32, 64):
+            run(262144, 4096, "blackman", "f32f32", inverse_rows=rw)
+        for rw in (16, 32, 64):
+            run(48000, 1024, channels=64, inverse_rows=rw)
+        for rw in (16, 32):
+            run(48000, 1000, inverse_rows=rw)
+    if which == "inv":
+        for rep in range(2):
+            run(1000000, 1024)
+            run(1000000, 1024, exact_inverse=0)
+        run(262144, 4096, "blackman", "f32f32")
+        run(262144, 4096, "blackman", "f32f32", exact_inverse=0)
+        run(48000, 1024, channels=64)
+        run(48000, 1024, channels=64, exact_inverse=0)
+        run(48000, 1000)
+        run(48000, 1000, exact_inverse=0)
     if which == "ceiling3":
         from sdft_amd import capi
         lib = capi.load()

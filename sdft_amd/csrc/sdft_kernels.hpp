@@ -1221,4 +1221,108 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K2 (exact order)  inverse with the reference's summation order (sdft.h:641-651: one accumulator
+// per row, bins added in ascending order), at streaming bandwidth: a wave owns RW consecutive rows
+// and, in the summation phase, lane r adds row r's terms strictly in bin order.  Tiles of RW rows x
+// 256 bytes are fetched with 16-byte loads (one instruction = four 256-byte row segments), the
+// scalar each bin contributes -- re(X)*(+-1) for latency 1, re(X * twiddle) otherwise -- goes to a
+// padded LDS tile, and the next tile's loads are in flight while the current one is summed.
+// Result: bit-identical to the reference for every type.  RW = 64 for long calls, 16 when there
+// are too few rows to fill the chip with 64-row groups.
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD, bool LAT1, int RW>
+__global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, FD> a)
+{
+  constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load (1 for f64, 2 for f32)
+  constexpr int C = 16 * BPL;                            // bins per tile row = 256 bytes
+  constexpr int RPI = 4;                                 // rows per load instruction (16 lanes each)
+  constexpr int NI = RW / RPI;                           // load instructions per tile
+  using V = typename StoreVec<FD, (sizeof(cx<FD>) == 16 ? 1 : 2)>::type;   // 16-byte vector
+  __shared__ FD tile[kWavesPerBlock][RW][C + 1];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t ngroups_per_ch = (a.n + RW - 1) / RW;
+  const size_t ngroups = ngroups_per_ch * a.channels;
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  const int sub = lane >> 4, seg = lane & 15;            // load phase: row within the instruction, 16-byte slot
+  const bool vec_ok = (BPL == 1) || ((a.nbins % 2 == 0) && !a.in_rows && (a.in_stride % 2 == 0));
+
+  for (size_t g = (size_t)blockIdx.x * kWavesPerBlock + wib; g < ngroups; g += nwaves)
+  {
+    const size_t ch = g / ngroups_per_ch;
+    const size_t r0 = (g - ch * ngroups_per_ch) * RW;
+    const cx<FD>* base = a.in + ch * a.in_stride;
+
+    auto fetch = [&](unsigned k0, cx<FD> (&v)[NI][BPL])
+    {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+      {
+        const size_t r = r0 + (size_t)(RPI * i + sub);
+        const unsigned k = k0 + (unsigned)seg * BPL;
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) v[i][b] = cmake<FD>((FD)0, (FD)0);
+        if (r < a.n && k < a.nbins)
+        {
+          const cx<FD>* rowp = a.in_rows ? a.in_rows[ch * a.n + r] : base + r * (size_t)a.nbins;
+          if (BPL == 2 && vec_ok && k + 1 < a.nbins)
+          {
+            const V q = *reinterpret_cast<const V*>(rowp + k);
+            v[i][0] = cmake<FD>((FD)q[0], (FD)q[1]);
+            if constexpr (BPL == 2) v[i][1] = cmake<FD>((FD)q[2], (FD)q[3]);
+          }
+          else
+          {
+#pragma unroll
+            for (int b = 0; b < BPL; ++b)
+              if (k + b < a.nbins) v[i][b] = rowp[k + b];
+          }
+        }
+      }
+    };
+    auto stage = [&](unsigned k0, const cx<FD> (&v)[NI][BPL])
+    {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int b = 0; b < BPL; ++b)
+        {
+          const unsigned k = k0 + (unsigned)seg * BPL + b;
+          FD term;
+          if constexpr (LAT1) term = v[i][b].re * ((k & 1u) ? (FD)(-1) : (FD)(+1));            // sdft.h:643
+          else { const cx<FD> s = a.syn[k < a.nbins ? k : 0]; term = v[i][b].re * s.re - v[i][b].im * s.im; }   // re of :650
+          tile[wib][RPI * i + sub][seg * BPL + b] = term;
+        }
+    };
+
+    FD sum = (FD)0;
+    cx<FD> cur[NI][BPL];
+    fetch(0, cur);
+    for (unsigned k0 = 0; k0 < a.nbins; k0 += C)
+    {
+      stage(k0, cur);
+      if (k0 + C < a.nbins) fetch(k0 + C, cur);          // in flight during the summation below
+      __builtin_amdgcn_wave_barrier();
+      const unsigned cnt = (a.nbins - k0 < (unsigned)C) ? a.nbins - k0 : (unsigned)C;
+      if (lane < RW)
+      {
+        if (cnt == (unsigned)C)
+        {
+#pragma unroll
+          for (int c = 0; c < C; ++c) sum += tile[wib][lane][c];
+        }
+        else
+        {
+          for (unsigned c = 0; c < cnt; ++c) sum += tile[wib][lane][c];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const size_t r = r0 + lane;
+    if (lane < RW && r < a.n) a.y[ch * a.y_stride + r] = (TD)(sum * a.sweight);     // sdft.h:654-656
+  }
+}
+
 }  // namespace sdfthip

@@ -138,6 +138,8 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
+  long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
   long last_fused = 0;
@@ -550,7 +552,29 @@ class Plan
     const size_t total_rows = channels * n;
     size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = std::min(blocks, (size_t)256 * 8 * 4);
-    if (latency == 1)                                                           // :639 exact compare
+    if (opt_exact_inverse)
+    {
+      // the reference's summation order: a wave per 64 rows (16 rows when the call is short)
+      const bool lat1 = (latency == 1);                                         // :639 exact compare
+      // measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16: 2.82, 64: 3.6 (130 VGPRs);
+      // float bins and short calls do best with 16
+      const long rw = opt_inverse_rows > 0 ? opt_inverse_rows
+                                           : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16);
+      size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
+      eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
+      const dim3 g((unsigned)eb), b(kBlock);
+      if (rw >= 32)
+      {
+        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 32>), g, b, 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 32>), g, b, 0, stream, ia);
+      }
+      else
+      {
+        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 16>), g, b, 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 16>), g, b, 0, stream, ia);
+      }
+    }
+    else if (latency == 1)                                                      // :639 exact compare
       hipLaunchKernelGGL((inverse_kernel<TD, FD, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
     else
       hipLaunchKernelGGL((inverse_kernel<TD, FD, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);

@@ -227,3 +227,31 @@ def test_fft_carry_equals_direct_sums(m, chunk):
         assert rel_err(outs[fft][0], want) <= 1e-11, (fft, rel_err(outs[fft][0], want))
         assert rel_err(outs[fft][1], want2) <= 1e-11, (fft, rel_err(outs[fft][1], want2))
     assert rel_err(outs[1][0], outs[0][0]) <= 1e-12
+
+
+@pytest.mark.parametrize("combo", O.COMBOS)
+@pytest.mark.parametrize("latency", [1.0, 0.5])
+def test_inverse_is_bit_identical(combo, latency):
+    """The default inverse sums the bins of a row in the reference's order (LDS transpose kernel):
+    y is bit-identical for every type, ragged sizes, host and device pointers, batches."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    for m, n in ((1, 5), (7, 70), (100, 333), (1000, 129), (1024, 4100), (2050, 64)):
+        x = noise(n, seed=m, dtype=td)
+        ref = O.best(m, "hann", latency, combo)
+        d = ref.sdft(x)
+        want = ref.isdft(d)
+        with make(m, "hann", latency, combo) as p:
+            assert np.array_equal(p.isdft(d), want), (combo, latency, m, n)
+            got = p.isdft(torch.from_numpy(d).cuda()).cpu().numpy()
+            assert np.array_equal(got, want), (combo, latency, m, n)
+            p.set_option("exact_inverse", 0)                       # wave-parallel sum: inside the bar, not identical
+            assert rel_err(p.isdft(d), want) <= TOL[combo[3:]]
+    ch, m, n = 3, 96, 200
+    xb = np.stack([noise(n, seed=c, dtype=td) for c in range(ch)])
+    refs = [O.best(m, "hann", latency, combo) for _ in range(ch)]
+    db = np.stack([refs[c].sdft(xb[c]) for c in range(ch)])
+    with make(m, "hann", latency, combo, channels=ch) as p:
+        yb = p.isdft(db)
+    for c in range(ch):
+        assert np.array_equal(yb[c], refs[c].isdft(db[c]))
