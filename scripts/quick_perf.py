@@ -126,6 +126,24 @@ if __name__ == "__main__":
         run(262144, 2048, "hann")
         run(262144, 2048, "hann", row_slots_max=1)
         run(1000000, 1024)
+    if which == "hop":
+        import time as _t
+        for m, hop in ((1000, 100), (1024, 256), (1024, 1)):
+            for where in ("device", "host"):
+                p = SDFT(m)
+                if len(sys.argv) > 2: p.set_option("pointers", 1 if where == "device" else 2)
+                n = hop * 400
+                xh = sine_sweep(n)
+                if where == "device":
+                    x = torch.from_numpy(xh).cuda(); out = torch.empty((hop, m), dtype=torch.complex128, device="cuda"); y = torch.empty(hop, dtype=torch.float32, device="cuda")
+                else:
+                    x = xh; out = np.empty((hop, m), dtype=np.complex128); y = np.empty(hop, dtype=np.float32)
+                for i in range(0, 20 * hop, hop): p.sdft(x[i:i + hop], out); p.isdft(out, y)
+                torch.cuda.synchronize(); t0 = _t.perf_counter()
+                for i in range(20 * hop, n, hop): p.sdft(x[i:i + hop], out); p.isdft(out, y)
+                torch.cuda.synchronize(); dt = (_t.perf_counter() - t0) / (n // hop - 20)
+                print(f"hop streaming m={m} hop={hop} {where} pointers: {dt * 1e6:.1f} us per hop (sdft_n + isdft_n) -> {hop / dt / 1e6:.3f} Msamples/s", flush=True)
+                p.close()
     if which == "inv2":
         for rep in range(2):
             for rw in (16, 32, 64):

@@ -137,7 +137,9 @@ SDFT_HD long reflect_bin(long k, long nbins, bool& flip)
 template <typename TD, typename FD>
 __global__ __launch_bounds__(kBlock) void delta_kernel(const TD* __restrict__ x, size_t x_stride,
                                                        const TD* __restrict__ hist_in, TD* __restrict__ hist_out,
-                                                       FD* __restrict__ delta, size_t n, size_t span /*2N*/)
+                                                       FD* __restrict__ delta, size_t n, size_t span /*2N*/,
+                                                       const cx<FD>* __restrict__ acc_state, const cx<FD>* __restrict__ fid_state,
+                                                       cx<FD>* __restrict__ carry0, cx<FD>* __restrict__ seed0)
 {
   const size_t ch = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -155,6 +157,14 @@ __global__ __launch_bounds__(kBlock) void delta_kernel(const TD* __restrict__ x,
     // element i of the new history = element (n + i) of the concatenation hist ++ x, minus span
     const size_t j = n + i;
     hist_out[ch * span + i] = (j >= span) ? xs[j - span] : hi[j];
+  }
+  // single-chunk calls: the stream state is the carry; copied here (instead of two extra copy
+  // launches) because halo lanes / mirror publishers read bins whose owner may already have
+  // written the new state
+  if (carry0 && i < span / 2)
+  {
+    carry0[ch * (span / 2) + i] = acc_state[ch * (span / 2) + i];
+    seed0[ch * (span / 2) + i] = fid_state[ch * (span / 2) + i];
   }
 }
 

@@ -138,6 +138,7 @@ class Plan
   bool profile = false;
   long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_pointers = 0;         // 0 = detect per call (hipPointerGetAttributes), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
@@ -380,8 +381,10 @@ class Plan
     {
       const size_t work = std::max(n, span);
       dim3 grid((unsigned)((work + kBlock - 1) / kBlock), (unsigned)channels);
+      const bool single = (chunks == 1);
       hipLaunchKernelGGL((delta_kernel<TD, FD>), grid, dim3(kBlock), 0, stream, x, x_stride,
-                         d_hist[hist_cur].p, d_hist[hist_cur ^ 1].p, d_delta.p, n, span);
+                         d_hist[hist_cur].p, d_hist[hist_cur ^ 1].p, d_delta.p, n, span,
+                         (const fdx*)d_acc.p, (const fdx*)d_fid.p, single ? d_carry.p : (fdx*)nullptr, single ? d_seed.p : (fdx*)nullptr);
       SDFT_TRY(hipGetLastError());
       hist_cur ^= 1;
     }
@@ -399,10 +402,7 @@ class Plan
     bool use_seed = true;
     if (chunks == 1)
     {
-      // single chunk: the stream state is the carry (copied, because halo lanes of other tiles
-      // read bins whose owner may already have written the new state)
-      SDFT_TRY(hipMemcpyAsync(d_carry.p, d_acc.p, channels * nb * sizeof(fdx), hipMemcpyDeviceToDevice, stream));
-      SDFT_TRY(hipMemcpyAsync(d_seed.p, d_fid.p, channels * nb * sizeof(fdx), hipMemcpyDeviceToDevice, stream));
+      // single chunk: the stream state is the carry; delta_kernel has already copied it
     }
     else if (exact)
     {
@@ -598,7 +598,8 @@ class Plan
   bool sdft_n(size_t n, const TD* x, fdx* dfts)
   {
     if (n == 0 || nbins == 0) return true;
-    const bool xd = is_device_pointer(x), od = is_device_pointer(dfts);
+    const bool xd = opt_pointers ? opt_pointers == 1 : is_device_pointer(x);
+    const bool od = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
     if (xd && od)
       return forward_device(n, x, n, dfts, n * nbins, nullptr) && finish();
 
@@ -679,7 +680,8 @@ class Plan
   bool isdft_n(size_t n, const fdx* dfts, TD* y)
   {
     if (n == 0) return true;
-    const bool id = is_device_pointer(dfts), yd = is_device_pointer(y);
+    const bool id = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
+    const bool yd = opt_pointers ? opt_pointers == 1 : is_device_pointer(y);
     if (nbins == 0)
     {
       // empty spectrum: the reference returns (td)(0 * 2)
