@@ -1,0 +1,73 @@
+"""Runs every BASELINE.json config shape on one GPU through the C-ABI (device pointers) and prints a
+markdown table: per-stage device times (HIP events recorded by the library), Msamples/s and
+achieved bandwidth against the algorithmic bytes.  Development/report aid; bench.py is the
+contract benchmark.
+
+    python scripts/config_report.py > profiles/rNN_configs.md
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from sdft_amd.sdft import SDFT
+from sdft_amd.signals import sine_sweep
+
+ROWS = []
+
+
+def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True):
+    td = np.float32 if combo[:3] == "f32" else np.float64
+    esz = 16 if combo[3:] == "f64" else 8
+    cdt = torch.complex128 if esz == 16 else torch.complex64
+    free, _ = torch.cuda.mem_get_info()
+    if channels * n * m * esz * 1.05 > free:
+        ROWS.append(f"| {label} | skipped: needs {channels * n * m * esz / 1e9:.0f} GB |" + " |" * 8)
+        return
+    xh = sine_sweep(n, dtype=td) if channels == 1 else np.stack([sine_sweep(n, channel=c, channels=channels, dtype=td) for c in range(channels)])
+    x = torch.from_numpy(xh).cuda()
+    out = torch.empty((n, m) if channels == 1 else (channels, n, m), dtype=cdt, device="cuda")
+    p = SDFT(m, window, 1.0, combo, channels)
+    p.set_option("profile", 1); p.set_option("async", 1)
+    y = None
+    for _ in range(2):
+        p.sdft(x, out); y = p.isdft(out, y)
+    p.synchronize(); p.profile()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.sdft(x, out)
+    p.synchronize(); wall_f = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.isdft(out, y)
+    p.synchronize(); wall_i = (time.perf_counter() - t0) / reps
+    pr = p.profile()
+    f = pr["forward"][0] / max(pr["forward"][1], 1)          # one event pair per call, all segments
+    c = pr["carry"][0] / max(pr["carry"][1], 1)
+    i = pr["inverse"][0] / max(pr["inverse"][1], 1)
+    byts = channels * n * (m * esz + x.element_size())
+    ROWS.append(f"| {label} | {channels}×{n}×{m} {window} {combo} | {p.get_option('last_chunks')}×{p.get_option('last_chunk_len')}"
+                f" (kernel {p.get_option('last_kernel')}, {'exact' if p.get_option('carry') else 'fast'} carry, {p.get_option('last_segments')} seg)"
+                f" | {wall_f * 1e3:.3f} | {channels * n / wall_f / 1e6:.1f} | {byts / wall_f / 1e12:.2f} | {f:.3f} | {c:.3f}"
+                f" | {wall_i * 1e3:.3f} | {channels * n / wall_i / 1e6:.1f} | {byts / wall_i / 1e12:.2f} |")
+    p.close()
+    del out, x
+
+
+if __name__ == "__main__":
+    run("configs[0] shape (n=48000)", 48000, 1024, "hann", "f32f64")
+    run("configs[1] n=1e6 forward", 1_000_000, 1024, "hann", "f32f64")
+    run("configs[2] m=4096 Blackman FD float round trip", 262144, 4096, "blackman", "f32f32")
+    run("configs[3] 64 ch × m=2048 (FD double, 100.7 GB)", 48000, 2048, "hann", "f32f64", channels=64, reps=3)
+    run("configs[3] 64 ch × m=2048 (FD float, 50.3 GB)", 48000, 2048, "hann", "f32f32", channels=64, reps=3)
+    run("configs[4] one GPU's share: 64 ch × m=1024", 48000, 1024, "hann", "f32f64", channels=64, reps=3)
+    run("reference test shape m=1000", 352800, 1000, "hann", "f32f64")
+    print(f"# BASELINE config shapes on 1× MI355X ({torch.cuda.get_device_name(0)}), device-resident buffers\n")
+    print("forward = sdft_sdft_n (delta + carries + forward kernel, wall per call incl. launches); inverse = sdft_isdft_n.")
+    print("TB/s = algorithmic bytes (N·sizeof(fdx) + sizeof(td) per sample) / wall time.\n")
+    print("| config | shape | time chunks | fwd ms | fwd Msamples/s | fwd TB/s | fwd-kernel ms | carry ms (on main stream) | inv ms | inv Msamples/s | inv TB/s |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    print("\n".join(ROWS))
