@@ -342,17 +342,20 @@ __global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsi
 }
 
 // K1b: exclusive scan over chunks, in place: carry[j] = acc_state + sum_{i<j} partial[i].
-// Two levels: 16 waves of a workgroup each own a contiguous slice of the chunks of 64 bins,
-// slice totals are combined through LDS.  (partial[chunks-1] does not exist and is not read.)
-constexpr int kScanSlices = 16;
+// Two levels: a workgroup owns kScanBins bins; its kScanSlices thread groups each own a
+// contiguous slice of the chunks, slice totals are combined through LDS.  16 bins x 64 slices
+// (256-byte row segments, 64 workgroups at N = 1024) instead of 64 x 16: four times the
+// parallelism for a pass that is pure latency.  (partial[chunks-1] does not exist and is not read.)
+constexpr int kScanSlices = 64;
+constexpr int kScanBins = 16;
 
 template <typename FD>
-__global__ __launch_bounds__(kWave * kScanSlices) void carry_scan_kernel(CarryArgs<FD> a)
+__global__ __launch_bounds__(kScanBins * kScanSlices) void carry_scan_kernel(CarryArgs<FD> a)
 {
-  __shared__ cx<FD> totals[kScanSlices][kWave];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int slice = threadIdx.x >> 6;
-  const unsigned k = blockIdx.x * kWave + lane;
+  __shared__ cx<FD> totals[kScanSlices][kScanBins];
+  const int bin = threadIdx.x % kScanBins;
+  const int slice = threadIdx.x / kScanBins;
+  const unsigned k = blockIdx.x * kScanBins + bin;
   const size_t ch = blockIdx.y;
   const unsigned kk = k < a.nbins ? k : a.nbins - 1;
   const unsigned per = (a.chunks + kScanSlices - 1) / kScanSlices;
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(kWave * kScanSlices) void carry_scan_kernel(CarryAr
 
   cx<FD> sum = cmake<FD>((FD)0, (FD)0);
   for (unsigned j = j0; j < j1 && j + 1 < a.chunks; ++j) sum = cadd(sum, col[(size_t)j * a.nbins]);
-  totals[slice][lane] = sum;
+  totals[slice][bin] = sum;
   __syncthreads();
   cx<FD> run = a.acc_state[ch * a.nbins + kk];
-  for (int s = 0; s < slice; ++s) run = cadd(run, totals[s][lane]);
+  for (int s = 0; s < slice; ++s) run = cadd(run, totals[s][bin]);
   if (k >= a.nbins) return;
   for (unsigned j = j0; j < j1; ++j)
   {

@@ -454,8 +454,8 @@ class Plan
       else
         hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
-      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)((nb + kWave - 1) / kWave), (unsigned)channels),
-                         dim3(kWave * kScanSlices), 0, stream, ca);
+      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)((nb + kScanBins - 1) / kScanBins), (unsigned)channels),
+                         dim3(kScanBins * kScanSlices), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
       use_seed = false;
     }
