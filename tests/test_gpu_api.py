@@ -1,0 +1,160 @@
+"""Behaviour of the C-ABI beyond the numerics: staging, row-pointer tables, streams, threads,
+corner-case arguments.  Everything goes through libsdft_hip.so on a real GPU."""
+
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdft_amd.signals import noise, sine_sweep
+
+pytestmark = pytest.mark.gpu
+
+
+def make(*a, **opts):
+    from sdft_amd.sdft import SDFT
+    p = SDFT(*a)
+    for k, v in opts.items():
+        p.set_option(k, v)
+    return p
+
+
+def test_host_pointer_staging_in_segments_equals_one_call():
+    """Host pointers are staged in segments of `stage_bytes`; the stream state carries over exactly
+    like hop-wise calls, so a tiny staging buffer must give the same matrix (config 1 shape, f64)."""
+    m, n = 256, 5000
+    x = sine_sweep(n)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = ref.sdft(x)
+    with make(m, "hann", 1.0, "f32f64", stage_bytes=300 * m * 16, chunk=1 << 30) as p:   # 300-row segments
+        got = p.sdft(x)
+        y = p.isdft(got)
+    assert np.array_equal(got, want)                     # every segment is a single serial chunk
+    assert np.array_equal(y, ref.isdft(want))
+    # batched plan, host pointers, segmented staging
+    ch = 3
+    xb = np.stack([noise(n, seed=c) for c in range(ch)])
+    with make(m, "hann", 1.0, "f32f64", ch, stage_bytes=ch * 700 * m * 16, chunk=1 << 30) as p:
+        gb = p.sdft(xb)
+        yb = p.isdft(gb)
+    for c in range(ch):
+        r = O.best(m, "hann", 1.0, "f32f64")
+        w = r.sdft(xb[c])
+        assert np.array_equal(gb[c], w) and np.array_equal(yb[c], r.isdft(w))
+
+
+def test_row_pointer_variants_with_device_rows():
+    """sdft_sdft_nd / sdft_isdft_nd (reference sdft.h:622, :681) with rows living on the device:
+    pointer table on the host and on the device."""
+    import torch
+    from sdft_amd.capi import Api
+    m, n = 100, 64
+    x = noise(n, seed=4)
+    ref = O.best(m, "blackman", 0.5, "f32f64")
+    want = ref.sdft(x)
+    want_y = ref.isdft(want)
+    api = Api("f32f64")
+    for table_on_device in (False, True):
+        plan = api.alloc_custom(m, 3, 0.5)
+        assert plan
+        rows = [torch.zeros(m, dtype=torch.complex128, device="cuda") for _ in range(n)]    # scattered rows
+        table = np.array([r.data_ptr() for r in rows], dtype=np.uint64)
+        if table_on_device:
+            tdev = torch.from_numpy(table.view(np.int64)).cuda()
+            tptr = C.c_void_p(tdev.data_ptr())
+        else:
+            tptr = C.c_void_p(table.ctypes.data)
+        api.sdft_nd(plan, n, C.c_void_p(x.ctypes.data), tptr)
+        api.check()
+        got = torch.stack(rows).cpu().numpy()
+        assert np.array_equal(got, want)
+        y = np.empty(n, dtype=np.float32)
+        api.isdft_nd(plan, n, tptr, C.c_void_p(y.ctypes.data))
+        api.check()
+        assert np.array_equal(y, want_y)
+        api.free(plan)
+
+
+def test_caller_stream_and_async_mode():
+    """Device-pointer calls on a caller-owned stream, returning before completion (option async)."""
+    import torch
+    m, n = 512, 30000
+    x = sine_sweep(n)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = ref.sdft(x)
+    s = torch.cuda.Stream()
+    with make(m) as p:
+        p.set_stream(s.cuda_stream)
+        p.set_option("async", 1)
+        xd = torch.from_numpy(x).cuda()
+        torch.cuda.synchronize()
+        d = p.sdft(xd)
+        y = p.isdft(d)
+        s.synchronize()                                   # the caller's own synchronisation completes them
+        assert np.abs(d.cpu().numpy() - want).max() <= 1e-11 * np.abs(want).max()
+        assert np.abs(y.cpu().numpy() - ref.isdft(want)).max() <= 1e-6
+        p.synchronize()
+
+
+def test_independent_plans_in_threads():
+    """Distinct plans share no mutable state (reference sdft.h:145-182): two host threads, two plans."""
+    m, n = 200, 4000
+    results = {}
+
+    def work(tag, seed, window):
+        x = noise(n, seed=seed)
+        with make(m, window, 1.0, "f32f32") as p:
+            got = np.concatenate([p.sdft(x[i:i + 400]) for i in range(0, n, 400)])
+        results[tag] = (got, O.best(m, window, 1.0, "f32f32").sdft(x))
+
+    ts = [threading.Thread(target=work, args=(i, 10 + i, w)) for i, w in enumerate(("hann", "blackman", "hamming"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(results) == 3
+    for got, want in results.values():
+        assert np.array_equal(got, want)
+
+
+def test_corner_arguments():
+    from sdft_amd.capi import Api
+    api = Api("f32f64")
+    # unknown window value -> the reference's default branch = boxcar (sdft.h:394-399)
+    x = noise(50, seed=1)
+    plan = api.alloc_custom(16, 7, 1.0)
+    d = np.empty((50, 16), dtype=np.complex128)
+    api.sdft_n(plan, 50, C.c_void_p(x.ctypes.data), C.c_void_p(d.ctypes.data))
+    assert np.array_equal(d, O.best(16, "boxcar", 1.0, "f32f64").sdft(x))
+    # n = 0 is a no-op; options; getters
+    api.sdft_n(plan, 0, None, None)
+    assert api.set_option(plan, b"no_such_option", 1) == -1
+    assert api.set_option(plan, b"chunk", 64) == 0 and api.get_option(plan, b"chunk") == 64
+    assert api.size(plan) == 16 and api.latency(plan) == 1.0 and api.channels(plan) == 1
+    assert api.get_option(plan, b"bins_per_lane") == 1
+    api.free(plan)
+    # dftsize 0: a plan that analyses nothing and synthesises zeros
+    plan = api.alloc(0)
+    assert plan and api.size(plan) == 0
+    y = np.full(5, 7.0, dtype=np.float32)
+    api.sdft_n(plan, 5, C.c_void_p(x.ctypes.data), None)
+    api.isdft_n(plan, 5, None, C.c_void_p(y.ctypes.data))
+    assert (y == 0).all()
+    api.free(plan)
+    assert api.last_error() is None
+    assert api.lib.sdft_hip_selftest() == 0 and api.lib.sdft_hip_device_count() >= 1
+
+
+def test_reset_mid_stream_and_profile_counters():
+    m = 300
+    x = noise(3000, seed=8)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    with make(m, "hann", 1.0, "f32f64", profile=1, chunk=1 << 30) as p:
+        p.sdft(x[:1234])
+        p.reset(); ref.reset()
+        assert np.array_equal(p.sdft(x[:777]), ref.sdft(x[:777]))
+        prof = p.profile()
+        assert prof["forward"][1] == 2 and prof["delta"][1] == 2 and prof["forward"][0] > 0
+        assert p.profile()["forward"][1] == 0              # counters reset after reading
