@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=200000)
     ap.add_argument("--no-extras", action="store_true", help="skip synthesis / PCIe side measurements")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle with one channel per host core (many-core CPU baseline)")
     return ap.parse_args()
 
 
@@ -289,6 +291,15 @@ def main():
         result["cpu_baseline"] = cpu_baseline(m, window, combo, args.cpu_samples)
     elif rank == 0:
         result["cpu_baseline"] = None
+    if rank == 0 and args.cpu_all_cores:
+        import subprocess
+        procs = min(os.cpu_count() or 1, 64)
+        r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--procs", str(procs), "--n", "16384", "--m", str(m),
+                            "--window", window, "--combo", combo], capture_output=True, text=True, cwd=ROOT, timeout=600)
+        try:
+            result.setdefault("extras", {})["cpu_baseline_all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            result.setdefault("extras", {})["cpu_baseline_all_cores"] = {"error": r.stderr[-300:]}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

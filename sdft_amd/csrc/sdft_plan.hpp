@@ -208,6 +208,7 @@ class Plan
 
   void destroy()
   {
+    (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     d_tw.release(); d_syn.release(); d_wtab.release(); d_acc.release(); d_fid.release();
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
@@ -226,11 +227,15 @@ class Plan
     stream = nullptr;
   }
 
+  // a host driving several GPUs from one process may have switched the current device
+  bool bind() { SDFT_TRY(hipSetDevice(device)); return true; }
+
   // sdft.h:517-529
   bool reset()
   {
     cursor = 0; hist_cur = 0;
     if (nbins == 0) return true;
+    if (!bind()) return false;
     const size_t nb = nbins, span = 2 * nbins;
     SDFT_TRY(hipMemsetAsync(d_hist[0].p, 0, channels * span * sizeof(TD), stream));
     SDFT_TRY(hipMemsetAsync(d_acc.p, 0, channels * nb * sizeof(fdx), stream));
@@ -598,6 +603,7 @@ class Plan
   bool sdft_n(size_t n, const TD* x, fdx* dfts)
   {
     if (n == 0 || nbins == 0) return true;
+    if (!bind()) return false;
     const bool xd = opt_pointers ? opt_pointers == 1 : is_device_pointer(x);
     const bool od = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
     if (xd && od)
@@ -639,6 +645,7 @@ class Plan
   bool sdft_nd(size_t n, const TD* x, fdx** dfts)
   {
     if (n == 0 || nbins == 0) return true;
+    if (!bind()) return false;
     const bool table_on_device = is_device_pointer(dfts);
     bool rows_on_device = false;
     std::vector<fdx*> host_rows;
@@ -680,6 +687,7 @@ class Plan
   bool isdft_n(size_t n, const fdx* dfts, TD* y)
   {
     if (n == 0) return true;
+    if (!bind()) return false;
     const bool id = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
     const bool yd = opt_pointers ? opt_pointers == 1 : is_device_pointer(y);
     if (nbins == 0)
@@ -723,6 +731,7 @@ class Plan
   bool isdft_nd(size_t n, const fdx** dfts, TD* y)
   {
     if (n == 0) return true;
+    if (!bind()) return false;
     if (nbins == 0) return isdft_n(n, nullptr, y);
     const bool table_on_device = is_device_pointer(dfts);
     const bool rows_on_device = table_on_device || is_device_pointer(dfts[0]);
@@ -759,6 +768,7 @@ class Plan
   // state read-back for tests: acc, fid [channels][N]; hist [channels][2N] in time order
   bool get_state(fdx* acc, fdx* fid, TD* hist, size_t* cur)
   {
+    if (!bind()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (nbins)
     {
