@@ -53,16 +53,25 @@ void* sdft_hip_get_stream(sdft_t* sdft) SDFT_HIP_SYMBOL(get_stream);
 int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
 
 /* ---- options -----------------------------------------------------------------------------------
-   "async"        0|1   see above
-   "carry"        0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
-                      serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
-   "chunk"        samples per time chunk (0 = heuristic)
-   "interior"     bin-owning lanes per wave (default: largest multiple of 8 that leaves the halo)
-   "target_waves" waves the time chunking aims for
-   "stage_bytes"  segment size of the host-pointer staging path
-   "profile"      0|1  record per-stage HIP events (read with sdft_hip_get_profile)
-   get_option additionally answers "tiles", "bins_per_lane", "last_chunks", "last_chunk_len",
-   "cursor", "device". */
+   "async"         0|1   see above
+   "carry"         0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
+                       serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
+   "exact_inverse" 1 (default) = synthesis adds the bins of a row in the reference's order
+                       (bit-identical), 0 = wave-parallel tree sum
+   "chunk"         samples per time chunk (0 = heuristic)
+   "segments"      time segments of the exact carry pass overlapped with the forward launches
+   "rows_kernel"   1 (default) = row-group forward kernel when the row fits, 0 = independent tiles
+   "row_slots_max" 1|2   bins-per-lane slots the row-group kernel may use
+   "fused"         1 (default) = FMA arithmetic in the chunk-parallel FD double path
+   "fft_carry"     1 (default) = chunk partial sums by FFT when 2*dftsize is a power of two
+   "interior"      bin-owning lanes per wave of the independent-tile kernel
+   "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
+   "target_waves"  waves the time chunking aims for
+   "pointers"      0 = classify every pointer (hipPointerGetAttributes), 1 = all device, 2 = all host
+   "stage_bytes"   segment size of the host-pointer staging path
+   "profile"       0|1  record per-stage HIP events (read with sdft_hip_get_profile)
+   get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
+   "last_chunk_len", "last_kernel", "last_segments", "last_fused", "cursor", "device". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);
 

@@ -206,8 +206,8 @@ if __name__ == "__main__":
     if which == "sweep":
         run(1000000, 1024)
         run(48000, 1024)
-        for kw in ({"nt_store": 1}, {"interior": 48}, {"interior": 40}, {"interior": 32}, {"target_waves": 8192}, {"target_waves": 32768},
-                   {"target_waves": 8192, "nt_store": 1}, {"chunk": 2048}, {"chunk": 4096}):
+        for kw in ({"interior": 48}, {"interior": 40}, {"interior": 32}, {"target_waves": 8192}, {"target_waves": 32768},
+                   {"chunk": 2048}, {"chunk": 4096}):
             run(1000000, 1024, **kw)
         for kw in ({"chunk": 128}, {"chunk": 256}, {"chunk": 512}, {"chunk": 1024}):
             run(48000, 1024, **kw)

@@ -431,7 +431,6 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
   const FD one = comp ? (FD)0 : (FD)1;
   FD acc = comp ? acc0.im : acc0.re;
   FD f = comp ? fid0.im : fid0.re;
-  auto drain = [&]() {};
 
   FD* carry = reinterpret_cast<FD*>(a.carry);
   FD* seed = reinterpret_cast<FD*>(a.seed);
@@ -482,14 +481,13 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
     unsigned u = 0;
     while (u < m)
     {
-      if (base + u == next_dump) { drain(); dump(j); ++j; next_dump += a.chunk_len; }
+      if (base + u == next_dump) { dump(j); ++j; next_dump += a.chunk_len; }
       unsigned run = m - u;
       if ((size_t)run > next_dump - (base + u)) run = (unsigned)(next_dump - (base + u));
       if (run > maxc - c) run = maxc - c;
       if (run == 0)
       {
         // roll-over step (sdft.h:572-573)
-        drain();
         acc = acc + f * stage[buf][u];
         f = one;
         ++u; c = 0;
@@ -607,7 +605,6 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
     }
     if (more) put(buf ^ 1, regs);
   }
-  drain();
   if (ends_call) dump(j);                                // carry-in of the call's last chunk
   else if (valid)
   {
@@ -699,7 +696,6 @@ template <typename FD> struct ForwardArgs
   unsigned nbins, chunks, chunk_len, tiles, interior_lanes, cursor0;
   unsigned chunk0, launch_chunks;   // this launch covers time chunks [chunk0, chunk0 + launch_chunks)
   int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
-  int nt_store;               // non-temporal hint on the matrix stores
   FD wscale;                  // weight (or weight*0.25 for Hann)
 };
 
@@ -711,12 +707,10 @@ template <typename FD, int BPL> struct StoreVec;
 template <> struct StoreVec<double, 1> { using type = sdft_v2f64; };
 template <> struct StoreVec<float, 2>  { using type = sdft_v4f32; };
 template <> struct StoreVec<float, 1>  { using type = sdft_v2f32; };
-template <> struct StoreVec<double, 2> { using type = sdft_v2f64; };
 
-template <typename V> SDFT_D void store_vec(V* p, V v, bool nt)
-{
-  if (nt) __builtin_nontemporal_store(v, p); else *p = v;
-}
+// (a non-temporal variant of this store was measured on MI355X: 3.205 vs 3.217 ms at n=1e6, N=1024 --
+// no effect on a pure write stream -- and removed)
+template <typename V> SDFT_D void store_vec(V* p, V v) { *p = v; }
 
 template <typename FD, int BPL, int WIN, bool ROWS>
 __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
@@ -762,7 +756,6 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
   const bool last_chunk = (chunk + 1 == a.chunks);
-  const bool nt = a.nt_store != 0;
 
   // destination of this lane's first bin in row t0
   cx<FD>* dst = a.out + ch * a.out_stride + t0 * (size_t)a.nbins + kfirst;
@@ -816,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
         {
           using V = typename StoreVec<FD, 2>::type;
           V v; v.x = y[0].re; v.y = y[0].im; v.z = y[1].re; v.w = y[1].im;
-          store_vec(reinterpret_cast<V*>(p), v, nt);
+          store_vec(reinterpret_cast<V*>(p), v);
         }
       }
       else
@@ -831,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
       {
         using V = typename StoreVec<FD, 1>::type;
         V v; v.x = y[0].re; v.y = y[0].im;
-        store_vec(reinterpret_cast<V*>(p), v, nt);
+        store_vec(reinterpret_cast<V*>(p), v);
       }
     }
     dst += a.nbins;
@@ -895,9 +888,9 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 // One workgroup = all bins of one (channel, time chunk): wave w owns bins [64*BPL*w, 64*BPL*(w+1)),
 // every lane owns BPL adjacent bins; there are no halo lanes and no redundant recurrences (lanes
 // past bin N-1 in a partial last wave run the mirrored bins, as in forward_kernel, so that the
-// in-wave shifts see the right neighbours).  The waves advance in lockstep, kGroup samples at a
+// in-wave shifts see the right neighbours).  The waves advance in lockstep, kRowGroup samples at a
 // time:
-//   phase A  recurrence for kGroup samples; the demodulated bins stay in registers; the bins a
+//   phase A  recurrence for kRowGroup samples; the demodulated bins stay in registers; the bins a
 //            neighbouring wave needs -- or, at the two ends of the spectrum, their conjugate
 //            mirror images (sdft.h:589-595) -- are published to LDS edge slots by the few lanes
 //            that own them (exec-masked ds_write, scalar bookkeeping only);
@@ -1005,7 +998,6 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
-  const bool nt = a.nt_store != 0;
   cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins;     // wave-uniform row base
   const unsigned lane_off = (unsigned)((wave * kWave + lane) * BPL);
   const unsigned slot_stride = (unsigned)(nwaves * kWave * BPL);
@@ -1085,7 +1077,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           {
             using V = typename StoreVec<FD, 2>::type;
             V vv; vv.x = y[0].re; vv.y = y[0].im; vv.z = y[1].re; vv.w = y[1].im;
-            store_vec(reinterpret_cast<V*>(p), vv, nt);
+            store_vec(reinterpret_cast<V*>(p), vv);
           }
         }
         else
@@ -1100,7 +1092,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         {
           using V = typename StoreVec<FD, 1>::type;
           V vv; vv.x = y[0].re; vv.y = y[0].im;
-          store_vec(reinterpret_cast<V*>(p), vv, nt);
+          store_vec(reinterpret_cast<V*>(p), vv);
         }
       }
     }

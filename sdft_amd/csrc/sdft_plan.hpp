@@ -34,9 +34,6 @@ bool lane_selftest();                                   // sdft_common.hip
 template <typename FD> static inline FD host_cos(FD a);
 template <> inline float  host_cos<float>(float a)   { return cosf(a); }
 template <> inline double host_cos<double>(double a) { return cos(a); }
-template <typename FD> static inline FD host_sin(FD a);
-template <> inline float  host_sin<float>(float a)   { return sinf(a); }
-template <> inline double host_sin<double>(double a) { return sin(a); }
 template <typename FD> static inline FD host_acos(FD a);
 template <> inline float  host_acos<float>(float a)   { return acosf(a); }
 template <> inline double host_acos<double>(double a) { return acos(a); }
@@ -88,7 +85,6 @@ enum CarryMode : int { CARRY_FAST = 0, CARRY_EXACT = 1 };
 
 enum ProfileStage : int { ST_DELTA = 0, ST_CARRY = 1, ST_FORWARD = 2, ST_INVERSE = 3, ST_COUNT = 4 };
 
-struct PtrKind { bool device; };
 static inline bool is_device_pointer(const void* p)
 {
   if (!p) return false;
@@ -136,7 +132,6 @@ class Plan
   long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
   size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
   bool profile = false;
-  long opt_nt = 0;               // non-temporal matrix stores
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
   long opt_pointers = 0;         // 0 = detect per call (hipPointerGetAttributes), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
@@ -477,7 +472,6 @@ class Plan
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
     fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor;
     fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
-    fa.nt_store = (int)opt_nt;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     last_segments = segments;
     for (long sg = 0; sg < segments; ++sg)
