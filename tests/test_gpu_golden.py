@@ -22,10 +22,15 @@ def rel_err(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max()) / (scale if scale else 1.0)
 
 
-def digest_of(d):
+def digest_of(d, block=4096):
+    """per-row checksums (sum re, sum im, sum |.|^2, sum (k+1) re), computed in row blocks to keep the
+    temporaries small"""
     k = np.arange(1, d.shape[1] + 1, dtype=np.float64)
-    re = d.real.astype(np.float64); im = d.imag.astype(np.float64)
-    return np.stack([re.sum(1), im.sum(1), (re * re + im * im).sum(1), (re * k).sum(1)], axis=1)
+    out = np.empty((d.shape[0], 4), dtype=np.float64)
+    for i in range(0, d.shape[0], block):
+        re = d[i:i + block].real.astype(np.float64); im = d[i:i + block].imag.astype(np.float64)
+        out[i:i + block] = np.stack([re.sum(1), im.sum(1), (re * re + im * im).sum(1), (re * k).sum(1)], axis=1)
+    return out
 
 
 def test_tiny_golden_cases_bit_exact():
