@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q --timeout=600 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q --timeout=600 2>&1 | tail -12 | cut -c1-600

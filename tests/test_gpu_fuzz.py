@@ -1,0 +1,100 @@
+"""Seeded randomized parity sweep: random sizes, windows, latencies, type pairs, chunk geometry,
+kernel choices and call patterns against the oracle.  Exact-carry mode and single-chunk calls must
+be bit-identical, the chunk-parallel FD-double path within 1e-11; synthesis always bit-identical."""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdft_amd.signals import noise
+
+pytestmark = pytest.mark.gpu
+WINDOWS = ("boxcar", "hann", "hamming", "blackman")
+
+
+def rel_err(a, b):
+    scale = float(np.abs(b).max())
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max()) / (scale if scale else 1.0)
+
+
+def _batched_case(rng, m, window, latency, combo, opts, tag):
+    """a batched plan == independent reference plans, channel by channel"""
+    from sdft_amd.sdft import SDFT
+    td = O.combo_types(combo)[0]
+    ch = int(rng.integers(2, 5))
+    n = int(rng.integers(1, 1500))
+    xb = np.stack([noise(n, seed=int(rng.integers(0, 1 << 30)), dtype=td) for _ in range(ch)])
+    refs = [O.best(m, window, latency, combo) for _ in range(ch)]
+    want = np.stack([r.sdft(xb[c]) for c, r in enumerate(refs)])
+    with SDFT(m, window, latency, combo, channels=ch) as p:
+        for k, v in opts.items():
+            p.set_option(k, v)
+        got = p.sdft(xb)
+        exact = bool(p.get_option("carry")) or p.get_option("last_chunks") == 1
+        y = p.isdft(got)
+    if exact:
+        assert np.array_equal(got, want), ("batch", tag)
+    else:
+        assert rel_err(got, want) <= 1e-11, ("batch", tag)
+    for c, r in enumerate(refs):
+        assert np.array_equal(y[c], r.isdft(got[c])), ("batch", tag)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_geometry_parity(seed):
+    from sdft_amd.sdft import SDFT
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(6):
+        combo = O.COMBOS[int(rng.integers(0, 4))]
+        td, fd, fdx = O.combo_types(combo)
+        # sizes around the structural boundaries: wave (64), workgroup row (1024/2048), slots, tiny
+        m = int(rng.choice([1, 2, 3, 5, 8, 9, 31, 63, 64, 65, 127, 128, 129, 500, 1000, 1023, 1024, 1025, 1100,
+                            2047, 2048, 2049, 2500, 4096, 4100]))
+        if m > 2048 and rng.random() < 0.5:
+            m = int(rng.integers(8, 300))
+        window = WINDOWS[int(rng.integers(0, 4))]
+        latency = float(rng.choice([1.0, 0.5, 0.3]))
+        n1 = int(rng.integers(1, max(2, min(6000, 3_000_000 // max(m, 1)))))
+        n2 = int(rng.integers(1, 700))
+        opts = {
+            "chunk": int(rng.choice([0, 8, 64, 96, 200, 512, 1 << 30])),
+            "carry": int(rng.integers(0, 2)),
+            "rows_kernel": int(rng.integers(0, 2)),
+            "row_slots_max": int(rng.integers(1, 3)),
+            "segments": int(rng.choice([0, 1, 2, 5])),
+            "fft_carry": int(rng.integers(0, 2)),
+            "fused": int(rng.integers(0, 2)),
+        }
+        x1 = noise(n1, seed=seed * 100 + case, dtype=td)
+        x2 = noise(n2, seed=seed * 100 + case + 50, dtype=td)
+        ref = O.best(m, window, latency, combo)
+        w1, w2 = ref.sdft(x1), ref.sdft(x2)
+        tag = (seed, case, combo, m, window, latency, n1, n2, opts)
+        if case == 5 and m <= 600:
+            _batched_case(rng, m, window, latency, combo, opts, tag)
+        with SDFT(m, window, latency, combo) as p:
+            for k, v in opts.items():
+                p.set_option(k, v)
+            if case % 2:                                  # device pointers, no staging
+                import torch
+                g1 = p.sdft(torch.from_numpy(x1).cuda()).cpu().numpy()
+            else:
+                g1 = p.sdft(x1)
+            chunks1 = p.get_option("last_chunks")
+            exact = bool(p.get_option("carry")) or chunks1 == 1
+            g2 = p.sdft(x2)                              # continues from the state the first call left
+            exact2 = exact and (bool(p.get_option("carry")) or p.get_option("last_chunks") == 1)
+            y = p.isdft(g2)
+            st = p.state()
+        if exact:
+            assert np.array_equal(g1, w1), tag
+        else:
+            assert rel_err(g1, w1) <= 1e-11, (tag, rel_err(g1, w1))
+        if exact2:
+            assert np.array_equal(g2, w2), tag
+            racc, rfid, rhist, rcur = ref.state()
+            assert st[3] == rcur and np.array_equal(st[2], rhist), tag
+            assert np.array_equal(st[0], racc) and np.array_equal(st[1], rfid), tag
+        else:
+            assert rel_err(g2, w2) <= 1e-11, (tag, rel_err(g2, w2))
+        assert np.array_equal(y, ref.isdft(g2)), tag       # synthesis of the same matrix: bit-identical
