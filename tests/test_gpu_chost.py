@@ -85,3 +85,43 @@ def test_cpp_facade_host(tmp_path, hip_library, t, f, combo):
     got_y = np.fromfile(tmp_path / "y.raw", dtype=td)
     tol = 1e-6 if combo.endswith("f64") else 1e-4
     assert np.abs(got_y - want_y).max() <= tol * np.abs(want_y).max()
+
+
+def test_wav_tool_end_to_end(tmp_path, hip_library):
+    """examples/sdft_wav.c = the reference's test driver (test/test.c) as a tool: PCM24 WAV in (the
+    reference's test.wav excerpt kept in the golden fixture), hop loop on the GPU, float WAV + DFT
+    dump out; compared with the oracle fed the same decoded samples."""
+    import struct
+    import wave
+    libdir = os.path.dirname(hip_library)
+    rt = hip_runtime_dir()
+    exe = tmp_path / "sdft_wav"
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "sdft_wav.c"),
+           "-o", str(exe), "-L", libdir, "-lsdft_hip", "-L", rt, "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "testwav_m1000_hop100_hann_f32f64.npz"))
+    pcm = np.round(g["x"].astype(np.float64) * ((1 << 23) - 0.5) - 0.5).astype(np.int64)     # inverse of wav.py:24-26
+    pcm = pcm[:5000]
+    with wave.open(str(tmp_path / "in.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(3); w.setframerate(44100)
+        w.writeframes(b"".join(struct.pack("<i", int(v))[:3] for v in pcm))
+    r = subprocess.run([str(exe), "1000", "100", "hann", "1", str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "out.dft")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "5000 44100Hz" in r.stdout, (r.stdout, r.stderr)
+
+    x = (pcm / 8388608.0).astype(np.float32)                # the tool's (dr_wav-style) scaling
+    ref = O.best(1000, "hann", 1.0, "f32f64")
+    firsts, ys = [], []
+    for i in range(0, x.size, 100):
+        d = ref.sdft(x[i:i + 100])
+        firsts.append(d[0]); ys.append(ref.isdft(d))
+    got_d = np.fromfile(tmp_path / "out.dft", dtype=np.complex128).reshape(-1, 1000)
+    assert np.array_equal(got_d, np.stack(firsts))
+    raw = open(tmp_path / "out.wav", "rb").read()            # IEEE-float WAV (python's wave module reads PCM only)
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data"
+    fmt, nch, rate, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
+    assert (fmt, nch, rate, bits) == (3, 1, 44100, 32)
+    got_y = np.frombuffer(raw[44:], dtype=np.float32)
+    assert np.array_equal(got_y, np.concatenate(ys))
