@@ -132,6 +132,7 @@ if __name__ == "__main__":
             for where in ("device", "host"):
                 p = SDFT(m)
                 if len(sys.argv) > 2: p.set_option("pointers", 1 if where == "device" else 2)
+                if len(sys.argv) > 3 and where == "device": p.set_option("async", 1); p.set_option("profile", 1)
                 n = hop * 400
                 xh = sine_sweep(n)
                 if where == "device":
@@ -143,6 +144,8 @@ if __name__ == "__main__":
                 for i in range(20 * hop, n, hop): p.sdft(x[i:i + hop], out); p.isdft(out, y)
                 torch.cuda.synchronize(); dt = (_t.perf_counter() - t0) / (n // hop - 20)
                 print(f"hop streaming m={m} hop={hop} {where} pointers: {dt * 1e6:.1f} us per hop (sdft_n + isdft_n) -> {hop / dt / 1e6:.3f} Msamples/s", flush=True)
+                if len(sys.argv) > 3 and where == "device":
+                    pr = p.profile(); print("   per-call device ms:", {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items()}, flush=True)
                 p.close()
     if which == "inv2":
         for rep in range(2):

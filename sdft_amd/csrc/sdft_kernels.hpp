@@ -1233,10 +1233,11 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 // 256 bytes are fetched with 16-byte loads (one instruction = four 256-byte row segments), the
 // scalar each bin contributes -- re(X)*(+-1) for latency 1, re(X * twiddle) otherwise -- goes to a
 // padded LDS tile, and the next tile's loads are in flight while the current one is summed.
-// Result: bit-identical to the reference for every type.  RW = 64 for long calls, 16 when there
-// are too few rows to fill the chip with 64-row groups.
+// Result: bit-identical to the reference for every type.  RW = 32 (one tile ahead) for long FD
+// double calls, 16 for FD float and medium calls, 4 with an 8-deep ring for short calls (a hop of
+// 100 rows has too few rows to hide latency with row-parallelism alone).
 // ------------------------------------------------------------------------------------------
-template <typename TD, typename FD, bool LAT1, int RW>
+template <typename TD, typename FD, bool LAT1, int RW, int DEPTH>
 __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, FD> a)
 {
   constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load (1 for f64, 2 for f32)
@@ -1303,27 +1304,37 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
     };
 
     FD sum = (FD)0;
-    cx<FD> cur[NI][BPL];
-    fetch(0, cur);
-    for (unsigned k0 = 0; k0 < a.nbins; k0 += C)
-    {
-      stage(k0, cur);
-      if (k0 + C < a.nbins) fetch(k0 + C, cur);          // in flight during the summation below
-      __builtin_amdgcn_wave_barrier();
-      const unsigned cnt = (a.nbins - k0 < (unsigned)C) ? a.nbins - k0 : (unsigned)C;
-      if (lane < RW)
-      {
-        if (cnt == (unsigned)C)
-        {
+    // ring of DEPTH tiles in registers: tile t is consumed while tiles t+1 .. t+DEPTH are in flight
+    cx<FD> ring[DEPTH][NI][BPL];
 #pragma unroll
-          for (int c = 0; c < C; ++c) sum += tile[wib][lane][c];
-        }
-        else
+    for (int dd = 0; dd < DEPTH; ++dd) fetch((unsigned)dd * C, ring[dd]);
+    for (unsigned kb = 0; kb < a.nbins; kb += DEPTH * C)
+    {
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd)
+      {
+        const unsigned k0 = kb + (unsigned)dd * C;
+        if (k0 < a.nbins)                                // wave-uniform
         {
-          for (unsigned c = 0; c < cnt; ++c) sum += tile[wib][lane][c];
+          stage(k0, ring[dd]);
+          fetch(k0 + DEPTH * C, ring[dd]);               // past the row end: predicated off, zeros
+          __builtin_amdgcn_wave_barrier();
+          const unsigned cnt = (a.nbins - k0 < (unsigned)C) ? a.nbins - k0 : (unsigned)C;
+          if (lane < RW)
+          {
+            if (cnt == (unsigned)C)
+            {
+#pragma unroll
+              for (int c = 0; c < C; ++c) sum += tile[wib][lane][c];
+            }
+            else
+            {
+              for (unsigned c = 0; c < cnt; ++c) sum += tile[wib][lane][c];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
       }
-      __builtin_amdgcn_wave_barrier();
     }
     const size_t r = r0 + lane;
     if (lane < RW && r < a.n) a.y[ch * a.y_stride + r] = (TD)(sum * a.sweight);     // sdft.h:654-656

@@ -558,19 +558,24 @@ class Plan
       // measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16: 2.82, 64: 3.6 (130 VGPRs);
       // float bins and short calls do best with 16
       const long rw = opt_inverse_rows > 0 ? opt_inverse_rows
-                                           : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16);
+                                           : (total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
       size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
       eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
       const dim3 g((unsigned)eb), b(kBlock);
       if (rw >= 32)
       {
-        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 32>), g, b, 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 32>), g, b, 0, stream, ia);
+        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 32, 1>), g, b, 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 32, 1>), g, b, 0, stream, ia);
+      }
+      else if (rw >= 16)
+      {
+        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 16, 1>), g, b, 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 16, 1>), g, b, 0, stream, ia);
       }
       else
       {
-        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 16>), g, b, 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 16>), g, b, 0, stream, ia);
+        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 4, 8>), g, b, 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 4, 8>), g, b, 0, stream, ia);
       }
     }
     else if (latency == 1)                                                      // :639 exact compare
