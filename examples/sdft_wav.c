@@ -1,11 +1,11 @@
 /*
- * sdft_wav.c -- the reference's end-to-end test driver (test/test.c:34-96) as a tool on top of
- * libsdft_hip.so: read a WAV file, analyse and resynthesise it hop by hop with persistent state,
- * write the synthesised WAV and a dump of the first DFT row of every hop (raw interleaved complex
- * doubles, like test/dump.h:12-28).
+ * sdft_wav.c -- WAV in, WAV + DFT dump out: hop-wise analysis and resynthesis with persistent plan
+ * state on the GPU.  Same command line and same outputs as the reference's end-to-end test driver
+ * (positional arguments of test/test.c:41-47; first DFT row of every hop dumped as raw interleaved
+ * complex doubles like test/dump.h), so its comparison script can be pointed at these files:
  *
- * usage: sdft_wav <dftsize> <hopsize> <window> <latency> <src.wav> <out.wav> <out.dft>
- *        (the reference's run: 1000 100 hann 1 test.wav test.c.wav test.c.dft -- test/main.sh:3-6,20)
+ *   sdft_wav <dftsize> <hopsize> <boxcar|hann|hamming|blackman> <latency> <in.wav> <out.wav> <out.dft>
+ *   e.g.     1000 100 hann 1 test.wav test.hip.wav test.hip.dft        (reference test/main.sh:3-6)
  */
 
 #include <stdio.h>
@@ -16,40 +16,77 @@
 
 #include "wav.h"
 
-static sdft_window_t getwindow(const char* w)
+struct job
 {
-  if (!strcmp(w, "hann")) return sdft_window_hann;
-  if (!strcmp(w, "hamming")) return sdft_window_hamming;
-  if (!strcmp(w, "blackman")) return sdft_window_blackman;
-  return sdft_window_boxcar;
+  size_t bins, hop;
+  sdft_window_t window;
+  double latency;
+  const char *wav_in, *wav_out, *dft_out;
+};
+
+static int parse(int argc, char** argv, struct job* j)
+{
+  static const struct { const char* name; sdft_window_t id; } windows[] = {
+    { "boxcar", sdft_window_boxcar }, { "hann", sdft_window_hann },
+    { "hamming", sdft_window_hamming }, { "blackman", sdft_window_blackman } };
+  if (argc != 8) return 0;
+  j->bins = strtoul(argv[1], NULL, 10);
+  j->hop = strtoul(argv[2], NULL, 10);
+  j->window = sdft_window_boxcar;                      /* unknown names fall back to boxcar */
+  for (size_t w = 0; w < sizeof(windows) / sizeof(windows[0]); ++w)
+    if (strcmp(argv[3], windows[w].name) == 0) j->window = windows[w].id;
+  j->latency = strtod(argv[4], NULL);
+  j->wav_in = argv[5]; j->wav_out = argv[6]; j->dft_out = argv[7];
+  return j->bins > 0 && j->hop > 0;
 }
 
-int main(int argc, char* argv[])
+/* analyse + resynthesise `hops` hops; spectra of one hop live in `scratch` (hop x bins) */
+static void stream(sdft_t* plan, const struct job* j, const float* in, float* out, size_t hops,
+                   sdft_fdx_t* scratch, FILE* dump)
 {
-  if (argc < 8) { fprintf(stderr, "usage: %s dftsize hopsize window latency src.wav out.wav out.dft\n", argv[0]); return 1; }
-  const size_t dftsize = (size_t)atol(argv[1]), hopsize = (size_t)atol(argv[2]);
-  float* input; size_t size, sr;
-  if (!wav_read_mono(argv[5], &input, &size, &sr)) { fprintf(stderr, "cannot read %s\n", argv[5]); return 1; }
-  printf("C\t%s %zu %zuHz\n", argv[5], size, sr);
-  size = (size / hopsize) * hopsize;
-
-  sdft_t* sdft = sdft_alloc_custom(dftsize, getwindow(argv[3]), atof(argv[4]));
-  if (!sdft) { fprintf(stderr, "no plan: %s\n", sdft_hip_last_error()); return 1; }
-
-  float* output = (float*)malloc((size ? size : 1) * sizeof(float));
-  sdft_fdx_t* buffer = (sdft_fdx_t*)malloc(hopsize * dftsize * sizeof(sdft_fdx_t));
-  sdft_fdx_t* dfts = (sdft_fdx_t*)malloc((size / hopsize + 1) * dftsize * sizeof(sdft_fdx_t));
-  for (size_t i = 0, j = 0; i < size; i += hopsize, ++j)
+  for (size_t h = 0; h < hops; ++h)
   {
-    sdft_sdft_n(sdft, hopsize, input + i, buffer);
-    sdft_isdft_n(sdft, hopsize, buffer, output + i);
-    memcpy(dfts + j * dftsize, buffer, dftsize * sizeof(sdft_fdx_t));
+    const size_t at = h * j->hop;
+    sdft_sdft_n(plan, j->hop, in + at, scratch);
+    sdft_isdft_n(plan, j->hop, scratch, out + at);
+    if (dump) fwrite(scratch, sizeof(sdft_fdx_t), j->bins, dump);      /* row 0 of the hop */
   }
-  wav_write_mono_f32(argv[6], output, size, sr);
-  FILE* f = fopen(argv[7], "wb");
-  if (f) { fwrite(dfts, sizeof(sdft_fdx_t), (size / hopsize) * dftsize, f); fclose(f); }
+}
 
-  free(dfts); free(buffer); free(output); free(input);
-  sdft_free(sdft);
-  return 0;
+int main(int argc, char** argv)
+{
+  struct job j;
+  if (!parse(argc, argv, &j))
+  {
+    fprintf(stderr, "usage: %s dftsize hopsize window latency in.wav out.wav out.dft\n", argv[0]);
+    return 2;
+  }
+  float* samples = NULL;
+  size_t frames = 0, rate = 0;
+  if (!wav_read_mono(j.wav_in, &samples, &frames, &rate))
+  {
+    fprintf(stderr, "%s: not a PCM/float WAV file\n", j.wav_in);
+    return 1;
+  }
+  const size_t hops = frames / j.hop;                  /* whole hops only */
+  printf("C\t%s %zu %zuHz\n", j.wav_in, frames, rate);
+
+  sdft_t* plan = sdft_alloc_custom(j.bins, j.window, j.latency);
+  if (plan == NULL)
+  {
+    fprintf(stderr, "sdft_alloc_custom: %s\n", sdft_hip_last_error());
+    free(samples);
+    return 1;
+  }
+  float* resynth = (float*)calloc(hops * j.hop + 1, sizeof(float));
+  sdft_fdx_t* scratch = (sdft_fdx_t*)malloc(j.hop * j.bins * sizeof(sdft_fdx_t));
+  FILE* dump = fopen(j.dft_out, "wb");
+
+  stream(plan, &j, samples, resynth, hops, scratch, dump);
+
+  if (dump) fclose(dump);
+  const int ok = wav_write_mono_f32(j.wav_out, resynth, hops * j.hop, rate) && sdft_hip_last_error() == NULL;
+  sdft_free(plan);
+  free(scratch); free(resynth); free(samples);
+  return ok ? 0 : 1;
 }
