@@ -273,6 +273,32 @@ def main():
         extras["synthesis_read_gbs"] = round(count * n * (m * esz + np.dtype(td).itemsize) / (i_avg * 1e-3) / 1e9, 1)
         step_ms = secs / args.steps * 1e3
         extras["analysis_plus_synthesis_msamples_s"] = round(count * n / ((step_ms + i_avg) * 1e-3) / 1e6, 2)
+        if not distributed and workload == "single":
+            # the north star quotes its >= 50 % target at n = 48000 (same m, window, types): one call is
+            # only ~0.17 ms of device work, so both the kernel-only and the per-call wall rate are given
+            n48 = 48000
+            x48 = torch.from_numpy(sine_sweep(n48, dtype=td)).cuda()
+            o48 = out.view(-1)[: n48 * m].view(n48, m)
+            p48 = SDFT(m, window, 1.0, combo, device=local_rank)
+            p48.set_stream(stream.cuda_stream); p48.set_option("async", 1); p48.set_option("profile", 1)
+            for _ in range(5):
+                p48.sdft(x48, o48)
+            p48.synchronize(); torch.cuda.synchronize(); p48.profile()
+            t48 = time.perf_counter()
+            for _ in range(50):
+                p48.sdft(x48, o48)
+            p48.synchronize(); torch.cuda.synchronize()
+            w48 = (time.perf_counter() - t48) / 50
+            pr48 = p48.profile()
+            k48 = pr48["forward"][0] / max(pr48["forward"][1], 1) * 1e-3
+            b48 = n48 * (m * esz + np.dtype(td).itemsize)
+            extras["north_star_n48000"] = {
+                "msamples_s_wall": round(n48 / w48 / 1e6, 1), "gbs_wall": round(b48 / w48 / 1e9, 1),
+                "frac_of_peak_wall": round(b48 / w48 / 1e9 / HBM_PEAK_GBS, 4),
+                "forward_kernel_gbs": round(b48 / k48 / 1e9, 1), "ms_per_call_wall": round(w48 * 1e3, 4),
+                "note": "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache",
+            }
+            p48.close()
         if not distributed:
             npci = min(n, 65536)
             hx = xh[..., :npci].copy() if count == 1 else np.ascontiguousarray(xh[:, :npci])
