@@ -255,3 +255,31 @@ def test_inverse_is_bit_identical(combo, latency):
         yb = p.isdft(db)
     for c in range(ch):
         assert np.array_equal(yb[c], refs[c].isdft(db[c]))
+
+
+@pytest.mark.parametrize("combo,m,opts", [("f32f64", 2500, {"carry": 0, "chunk": 256}), ("f32f64", 2500, {"carry": 1, "chunk": 96, "segments": 3}),
+                                          ("f32f32", 4100, {"chunk": 160, "segments": 4}), ("f64f64", 2049, {"carry": 0}),
+                                          ("f32f32", 4096, {"rows_kernel": 0, "chunk": 128, "segments": 2})])
+def test_batched_plans_beyond_the_row_group_limit(combo, m, opts):
+    """Batched plans whose rows do not fit the row-group kernel (independent-tile kernel), both carry
+    modes, segmented exact pass; channel by channel against independent reference plans."""
+    td, fd, fdx = O.combo_types(combo)
+    ch, n = 3, 1500
+    xb = np.stack([noise(n, seed=40 + c, dtype=td) for c in range(ch)])
+    refs = [O.best(m, "blackman", 1.0, combo) for _ in range(ch)]
+    want = [r.sdft(xb[c]) for c, r in enumerate(refs)]
+    with make(m, "blackman", 1.0, combo, channels=ch, **opts) as p:
+        got = p.sdft(xb)
+        exact = bool(p.get_option("carry"))
+        assert p.get_option("last_chunks") > 1
+        y = p.isdft(got)
+        x2 = np.stack([noise(300, seed=70 + c, dtype=td) for c in range(ch)])
+        got2 = p.sdft(x2)
+    for c in range(ch):
+        if exact:
+            assert np.array_equal(got[c], want[c]), (combo, m, c)
+            assert np.array_equal(got2[c], refs[c].sdft(x2[c])), (combo, m, c)
+        else:
+            assert rel_err(got[c], want[c]) <= 1e-11
+            assert rel_err(got2[c], refs[c].sdft(x2[c])) <= 1e-11
+        assert np.array_equal(y[c], refs[c].isdft(got[c]))
