@@ -69,7 +69,8 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "target_waves"  waves the time chunking aims for
    "pointers"      0 = classify every pointer (hipPointerGetAttributes), 1 = all device, 2 = all host
    "stage_bytes"   segment size of the host-pointer staging path
-   "profile"       0|1  record per-stage HIP events (read with sdft_hip_get_profile)
+   "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
+                       (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel", "last_segments", "last_fused", "cursor", "device". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);

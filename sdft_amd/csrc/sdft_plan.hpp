@@ -131,7 +131,7 @@ class Plan
   long opt_interior = 0;         // forced interior lanes per wave (0 = maximum)
   long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
   size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
-  bool profile = false;
+  int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
   long opt_pointers = 0;         // 0 = detect per call (hipPointerGetAttributes), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
@@ -251,9 +251,10 @@ class Plan
   bool synchronize() { SDFT_TRY(hipStreamSynchronize(stream)); return collect_profile(); }
 
   // ---- profiling ---------------------------------------------------------------------------
+  bool prof_on(int st) const { return profile == 1 || (profile == 2 && (st == ST_FORWARD || st == ST_INVERSE)); }
   bool prof_begin(int st)
   {
-    if (!profile) return true;
+    if (!prof_on(st)) return true;
     if (ev_used[st] + 2 > ev_pool[st].size())
     {
       hipEvent_t a, b;
@@ -265,7 +266,7 @@ class Plan
   }
   bool prof_end(int st)
   {
-    if (!profile) return true;
+    if (!prof_on(st)) return true;
     SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st] + 1], stream));
     ev_used[st] += 2;
     return true;
