@@ -147,6 +147,11 @@ if __name__ == "__main__":
                 if len(sys.argv) > 3 and where == "device":
                     pr = p.profile(); print("   per-call device ms:", {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items()}, flush=True)
                 p.close()
+    if which == "blocks":
+        for rep in range(2):
+            for blocks in (256, 512, 768, 1024, 1280, 2048):
+                ln = -(-1000000 // blocks); ln = -(-ln // 8) * 8
+                run(1000000, 1024, chunk=ln)
     if which == "inv2":
         for rep in range(2):
             for rw in (16, 32, 64):

@@ -1,20 +1,28 @@
 // sdft_kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4) implementing the modulated
 // Sliding DFT hot path.  Citations are into /root/reference/c/src/sdft/sdft.h.
 //
-// Work decomposition:
-//   lanes      <-> frequency bins (one complex bin per lane for 16-byte bins, two adjacent
-//                  bins per lane for 8-byte bins, so a wave always stores 16 B per lane),
-//   wave loop  <-> time: the sample loop is carried inside the kernel,
-//   grid       <-> bin tiles x time chunks x channels.
-// A wave owns 64 lanes of which the outer ones are *halo* lanes: they run the recurrence of the
-// neighbouring (or mirrored) bins redundantly so that the 3/5-tap spectral window needs no LDS
-// and no barrier -- neighbours are fetched with DPP wave shifts (v_mov_b32_dpp wave_shr/shl).
-// The per-sample input difference is wave-uniform and arrives through the scalar cache
-// (s_load), twiddles/state live in VGPRs for the whole chunk.
+// Kernels:
+//   delta_kernel          K0   differences x[t] - x[t-2N] in TD precision + delay line update
+//   chunk_fft_kernel      K1a  per-chunk partial sums of the accumulator as an in-LDS 2N-point FFT
+//   chunk_sum_kernel      K1a  the same sums directly (N not a power of two)
+//   carry_scan_kernel     K1b  exclusive scan over chunks -> carry-in of every time chunk
+//   carry_exact_kernel    K1a' serial pass with the reference's rounding sequence (FD float)
+//   forward_rows_kernel   K1   one workgroup per (chunk, row): LDS edge exchange, lockstep row stores
+//   forward_kernel        K1   independent waves with halo lanes (any N, row-pointer outputs)
+//   inverse_exact_kernel  K2   synthesis, bins summed in the reference's order (LDS transpose)
+//   inverse_kernel        K2   synthesis, wave-parallel tree sum (measurement alternative)
+//
+// Common decomposition: lanes <-> frequency bins (one complex bin per lane for 16-byte bins, two
+// adjacent bins per lane for 8-byte bins, so a lane always stores 16 B), the sample loop is carried
+// inside the kernel, the grid is bins x time chunks x channels.  The per-sample input difference
+// is wave-uniform and arrives over the scalar unit (s_load through the constant address space);
+// twiddles and state live in VGPRs for a whole chunk; window neighbours come from DPP whole-wave
+// shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1).
 //
 // Arithmetic follows the reference's struct-complex formulas operation by operation and the
 // translation units are compiled with -ffp-contract=off: given the same carry-in a wave
-// reproduces the reference bit for bit.
+// reproduces the reference bit for bit (the FUSED instantiation of forward_rows_kernel is the
+// one deliberate exception, used only where the carry-in already differs in summation order).
 
 #pragma once
 
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 (row-group form)  forward for rows that fit one workgroup: 8 <= N <= 1024*BPL bins.
+// K1 (row-group form)  forward for rows that fit one workgroup: 8 <= N <= 1024*BPL*S bins.
 //
 // One workgroup = all bins of one (channel, time chunk): wave w owns bins [64*BPL*w, 64*BPL*(w+1)),
 // every lane owns BPL adjacent bins; there are no halo lanes and no redundant recurrences (lanes
@@ -1173,7 +1181,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 // ------------------------------------------------------------------------------------------
 // K2  inverse (sdft.h:635-657): one wave per row, 16-byte coalesced loads, per-lane strided
 // partial sums, wave reduction by cross-lane shuffles, lane 0 scales and stores one TD sample.
-// Summation order differs from the reference's serial bin loop.
+// Summation order differs from the reference's serial bin loop: kept as the measurement
+// alternative to inverse_exact_kernel (option exact_inverse = 0).
 // ------------------------------------------------------------------------------------------
 template <typename FD> SDFT_D FD wave_sum(FD v)
 {
