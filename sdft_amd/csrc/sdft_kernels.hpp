@@ -119,6 +119,10 @@ template <typename T> SDFT_D cx<T> from_above_fill(cx<T> o, cx<T> z) { return cm
 template <typename T> SDFT_D cx<T> from_below(cx<T> z) { return cmake<T>(from_below(z.re), from_below(z.im)); }
 template <typename T> SDFT_D cx<T> from_above(cx<T> z) { return cmake<T>(from_above(z.re), from_above(z.im)); }
 
+// conjugation by a lane-constant mask (0 or the sign bit): one v_xor_b32, no select
+SDFT_D float flip_sign(float v, unsigned mask) { return __int_as_float(__float_as_int(v) ^ (int)mask); }
+SDFT_D double flip_sign(double v, unsigned mask) { return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v)); }
+
 // ------------------------------------------------------------------------------------------
 // index reflection for the halo (sdft.h:589-595): X[-i] = conj X[i], X[N-1+i] = conj X[N-1-i],
 // iterated for tiny N.  Returns the source bin, sets `flip` when an odd number of conjugations
@@ -952,6 +956,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // publishing role of each owned bin: LDS destination and whether the published value is conjugated
   cx<FD>* pub[S][BPL];
   bool pubflip[S][BPL], has_role[S][BPL];
+  unsigned flipmask[S][BPL], pubmask[S][BPL];            // sign-bit masks: conjugate on use / on publish
   const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
 #pragma unroll
   for (int q = 0; q < S; ++q)
@@ -1001,14 +1006,29 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       }
     }
   }
+#pragma unroll
+  for (int q = 0; q < S; ++q)
+#pragma unroll
+    for (int b = 0; b < BPL; ++b)
+    {
+      flipmask[q][b] = flip[q][b] ? 0x80000000u : 0u;
+      pubmask[q][b] = (flip[q][b] != pubflip[q][b]) ? 0x80000000u : 0u;
+    }
   constexpr size_t kSlabU = (size_t)VW * HS;              // elements between consecutive u
   constexpr size_t kSlabBuf = (size_t)G * kSlabU;         // elements between the two buffers
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   const FD w = a.wscale;
   cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins;     // wave-uniform row base
-  const unsigned lane_off = (unsigned)((wave * kWave + lane) * BPL);
-  const unsigned slot_stride = (unsigned)(nwaves * kWave * BPL);
+  // lane-constant 32-bit element offsets into a row: the stores then use the scalar-base form
+  // (global_store_dwordx4 v_off, v_data, s[row]) with no per-sample address arithmetic
+  unsigned off_elems[S];
+#pragma unroll
+  for (int q = 0; q < S; ++q)
+  {
+    off_elems[q] = (unsigned)(((q * nwaves + wave) * kWave + lane) * BPL);
+    __builtin_assume(off_elems[q] < (1u << 20));          // < 2048*BPL bins: the byte offset fits 32 bits
+  }
 
   auto publish = [&](const cx<FD> (&x)[S][BPL], int buf, int u)
   {
@@ -1022,7 +1042,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           if (has_role[q][b])                             // a handful of lanes per wave (exec mask)
           {
             cx<FD> v = x[q][b];
-            if (flip[q][b] != pubflip[q][b]) v.im = -v.im;
+            v.im = flip_sign(v.im, pubmask[q][b]);
             pub[q][b][(size_t)buf * kSlabBuf + (size_t)u * kSlabU] = v;
           }
         }
@@ -1037,7 +1057,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       const int v = q * nwaves + wave;
       cx<FD> x[BPL];
 #pragma unroll
-      for (int b = 0; b < BPL; ++b) { x[b] = xin[q][b]; if (flip[q][b]) x[b].im = -x[b].im; }
+      for (int b = 0; b < BPL; ++b) { x[b] = xin[q][b]; x[b].im = flip_sign(x[b].im, flipmask[q][b]); }
       cx<FD> e[BPL + 4] = {};
 #pragma unroll
       for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
@@ -1076,7 +1096,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       }
       // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit offset: the
       // row advance is scalar arithmetic, no per-lane 64-bit pointer bump
-      cx<FD>* p = row + (lane_off + (unsigned)q * slot_stride);
+      cx<FD>* p = row + off_elems[q];
       if constexpr (BPL == 2)
       {
         if (a.vec_store)
@@ -1156,9 +1176,17 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     }
     __syncthreads();
     // phase B
+    if (m == G)
+    {
 #pragma unroll
-    for (int u = 0; u < G; ++u)
-      if (u < m) finish(xs[u], buf, u);
+      for (int u = 0; u < G; ++u) finish(xs[u], buf, u);
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (u < m) finish(xs[u], buf, u);
+    }
     t += m;
     buf ^= 1;
   }
