@@ -328,9 +328,11 @@ class Plan
   {
     if (rows_kernel && opt_chunk <= 0 && n >= 512)
     {
-      // row-group kernel: one workgroup per (channel, chunk); aim at a few workgroups per CU
+      // row-group kernel: one workgroup per (channel, chunk).  The forward kernel does not care
+      // (256 ... 2048 workgroups: 2.91-2.95 ms at n = 1e6), the carry pre-pass gets cheaper with
+      // fewer chunks (1017 chunks 0.044 ms, 511 chunks 0.029 ms): two rounds of the 256 CUs
       const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves())
-                                                      : 1024;
+                                                      : (carry_mode == CARRY_EXACT ? 1024 : 512);   // exact: 4 overlap segments
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
       want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
       len = (long)((n + want - 1) / want);
