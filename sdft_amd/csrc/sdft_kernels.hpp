@@ -4,7 +4,8 @@
 // Kernels:
 //   delta_kernel          K0   differences x[t] - x[t-2N] in TD precision + delay line update
 //   chunk_fft_kernel      K1a  per-chunk partial sums of the accumulator as an in-LDS 2N-point FFT
-//   chunk_sum_kernel      K1a  the same sums directly (N not a power of two)
+//   chunk_fft_mixed_kernel K1a the same for 2N = product of 2, 3, 4, 5 (Stockham, two LDS buffers)
+//   chunk_sum_kernel      K1a  the same sums directly (any other N)
 //   carry_scan_kernel     K1b  exclusive scan over chunks -> carry-in of every time chunk
 //   carry_exact_kernel    K1a' serial pass with the reference's rounding sequence (FD float)
 //   forward_rows_kernel   K1   one workgroup per (chunk, row): LDS edge exchange, lockstep row stores
@@ -350,6 +351,72 @@ __global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsi
     const unsigned r = __brev(k) >> (32 - log2m);
     const cx<FD> rot = a.wtab[(size_t)(((unsigned long long)k * c0) % m)];
     a.carry[(ch * a.chunks + j) * a.nbins + k] = cmul(x[r], rot);
+  }
+}
+
+// K1a (mixed-radix FFT form): the same 2N-point DFT for sizes that are not powers of two but
+// factor into 2, 3, 4, 5 (the reference's own test size N = 1000: 2N = 4*4*5*5*5).  Stockham
+// autosort between two LDS buffers, natural-order output, generic r-point butterflies with all
+// roots taken from the plan's table W[j] = exp(-2*pi*i*j/(2N)).
+struct RadixList { unsigned char count; unsigned char r[15]; };
+
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_fft_mixed_kernel(CarryArgs<FD> a, unsigned m, RadixList rl)
+{
+  extern __shared__ __align__(16) unsigned char fft_lds_raw2[];
+  cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw2);
+  cx<FD>* y = x + m;
+  const unsigned j = blockIdx.x;                         // chunk 0 .. chunks-2 (full length)
+  const size_t ch = blockIdx.y;
+  const size_t t0 = (size_t)j * a.chunk_len;
+  const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
+  const FD* d = a.delta + ch * a.n + t0;
+
+  for (unsigned v = threadIdx.x; v < m; v += kBlock)
+  {
+    FD acc = (FD)0;
+    for (size_t u = v; u < a.chunk_len; u += m) acc += d[u];
+    x[v] = cmake<FD>(acc, (FD)0);
+  }
+  __syncthreads();
+  unsigned ns = 1;                                       // product of the radices already applied
+  for (unsigned st = 0; st < rl.count; ++st)
+  {
+    const unsigned r = rl.r[st];
+    const unsigned nr = m / r;
+    const unsigned tstep = m / (ns * r);                 // table stride of the stage twiddle
+    const unsigned rstep = nr;                           // table stride of the r-th roots of unity
+    for (unsigned i = threadIdx.x; i < nr; i += kBlock)
+    {
+      const unsigned k = i % ns;
+      cx<FD> v[5];
+#pragma unroll
+      for (unsigned t = 0; t < 5; ++t)
+        if (t < r)
+        {
+          const cx<FD> in = x[i + t * nr];
+          v[t] = t == 0 ? in : cmul(in, a.wtab[(size_t)(((unsigned long long)t * k * tstep) % m)]);
+        }
+      const unsigned base = (i / ns) * ns * r + k;
+#pragma unroll
+      for (unsigned q = 0; q < 5; ++q)
+        if (q < r)
+        {
+          cx<FD> o = v[0];
+#pragma unroll
+          for (unsigned t = 1; t < 5; ++t)
+            if (t < r) o = cadd(o, cmul(v[t], a.wtab[(size_t)(((unsigned long long)q * t * rstep) % m)]));
+          y[base + q * ns] = o;
+        }
+    }
+    __syncthreads();
+    cx<FD>* tmp = x; x = y; y = tmp;
+    ns *= r;
+  }
+  for (unsigned k = threadIdx.x; k < a.nbins; k += kBlock)
+  {
+    const cx<FD> rot = a.wtab[(size_t)(((unsigned long long)k * c0) % m)];
+    a.carry[(ch * a.chunks + j) * a.nbins + k] = cmul(x[k], rot);
   }
 }
 

@@ -449,11 +449,22 @@ class Plan
       // partial sums per chunk: FFT form when 2N is a power of two (and fits LDS), direct sums otherwise
       const size_t span_bytes = span * sizeof(fdx);
       const bool pow2 = (span & (span - 1)) == 0 && span >= 2;
+      RadixList rl; rl.count = 0;
+      if (!pow2)
+      {
+        size_t rem = span;
+        for (unsigned f : {4u, 2u, 3u, 5u})
+          while (rem % f == 0 && rl.count < 15) { rl.r[rl.count++] = (unsigned char)f; rem /= f; }
+        if (rem != 1) rl.count = 0;                                   // other prime factors: direct sums
+      }
       if (opt_fft_carry && pow2 && span_bytes <= (size_t)64 * 1024)
       {
         unsigned lg = 0; while (((size_t)1 << lg) < span) ++lg;
         hipLaunchKernelGGL((chunk_fft_kernel<FD>), dim3((unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), span_bytes, stream, ca, lg);
       }
+      else if (opt_fft_carry && rl.count > 0 && 2 * span_bytes <= (size_t)64 * 1024)
+        hipLaunchKernelGGL((chunk_fft_mixed_kernel<FD>), dim3((unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 2 * span_bytes,
+                           stream, ca, (unsigned)span, rl);
       else
         hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());

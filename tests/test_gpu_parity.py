@@ -208,7 +208,9 @@ def test_row_group_kernel_equals_tile_kernel_and_oracle(combo, m, window):
     assert np.array_equal(got[(1, "next")], got[(0, "next")])
 
 
-@pytest.mark.parametrize("m,chunk", [(1024, 512), (1024, 3000), (256, 600), (64, 128), (512, 5000)])
+@pytest.mark.parametrize("m,chunk", [(1024, 512), (1024, 3000), (256, 600), (64, 128), (512, 5000),
+                                     # mixed radix (2N = 2000, 1500, 192, 250, 1800) and a size that falls back (1001)
+                                     (1000, 352), (1000, 2600), (750, 400), (96, 64), (125, 1000), (900, 512), (1001, 256)])
 def test_fft_carry_equals_direct_sums(m, chunk):
     """Chunk partial sums by the in-LDS FFT (power-of-two N) vs the direct sums vs the oracle, incl.
     chunks longer than 2N (folding) and a second call that continues from a non-zero cursor."""
