@@ -338,6 +338,7 @@ def main():
         print(json.dumps(result), flush=True)
     plan.close()
     if distributed:
+        shard.barrier(local_rank)        # rank 0 may still have been busy with its side measurements
         dist.destroy_process_group()
 
 
