@@ -285,3 +285,23 @@ def test_batched_plans_beyond_the_row_group_limit(combo, m, opts):
             assert rel_err(got[c], want[c]) <= 1e-11
             assert rel_err(got2[c], refs[c].sdft(x2[c])) <= 1e-11
         assert np.array_equal(y[c], refs[c].isdft(got[c]))
+
+
+@pytest.mark.parametrize("combo,m,n", [("f32f64", 20000, 2500), ("f32f32", 30001, 1200), ("f64f64", 65536, 700)])
+def test_very_large_dftsize(combo, m, n):
+    """Bin counts far beyond the row-group limit (independent-tile kernel, direct-sum carries):
+    index arithmetic and chunk geometry at N up to 65536."""
+    td, fd, fdx = O.combo_types(combo)
+    x = noise(n, seed=3, dtype=td)
+    ref = O.best(m, "hamming", 0.5, combo)
+    want = ref.sdft(x)
+    with make(m, "hamming", 0.5, combo, chunk=128) as p:
+        got = p.sdft(x)
+        assert p.get_option("last_chunks") > 1 and p.get_option("last_kernel") == 1
+        exact = bool(p.get_option("carry"))
+        y = p.isdft(got)
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        assert rel_err(got, want) <= 1e-11
+    assert np.array_equal(y, ref.isdft(got))
