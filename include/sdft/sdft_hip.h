@@ -85,6 +85,11 @@ int  sdft_hip_get_profile(sdft_t* sdft, double ms[4], long calls[4]) SDFT_HIP_SY
    in time order (oldest first); any pointer may be NULL */
 int  sdft_hip_get_state(sdft_t* sdft, sdft_fdx_t* acc, sdft_fdx_t* fid, sdft_td_t* hist, size_t* cursor) SDFT_HIP_SYMBOL(get_state);
 
+/* checkpoint / resume: installs a state read with sdft_hip_get_state into a plan of the same dftsize,
+   window, latency, types and channel count (also one living on another GPU); NULL pointers leave
+   that part untouched */
+int  sdft_hip_set_state(sdft_t* sdft, const sdft_fdx_t* acc, const sdft_fdx_t* fid, const sdft_td_t* hist, size_t cursor) SDFT_HIP_SYMBOL(set_state);
+
 /* host-only (no GPU needed): the plan tables exactly as uploaded; tw, syn [dftsize], wtab
    [2*dftsize], weights [2] = {analysis, synthesis}; any pointer may be NULL */
 int  sdft_hip_plan_tables(const sdft_size_t dftsize, const sdft_double_t latency, sdft_fdx_t* tw,

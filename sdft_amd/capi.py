@@ -48,6 +48,7 @@ def typed_signatures(combo: str):
         "get_option": (C.c_long, [vp, C.c_char_p]),
         "get_profile": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
         "get_state": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
+        "set_state": (C.c_int, [vp, vp, vp, vp, sz]),
         "plan_tables": (C.c_int, [sz, C.c_double, vp, vp, vp, vp]),
     }
 

@@ -778,6 +778,23 @@ class Plan
     return true;
   }
 
+  // checkpoint / resume: install a state previously read with get_state (any plan of the same
+  // dftsize, window, latency, types and channel count -- also on another GPU)
+  bool set_state(const fdx* acc, const fdx* fid, const TD* hist, size_t cur)
+  {
+    if (!bind()) return false;
+    SDFT_TRY(hipStreamSynchronize(stream));
+    if (nbins)
+    {
+      if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }
+      if (acc) SDFT_TRY(hipMemcpy(d_acc.p, acc, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
+      if (fid) SDFT_TRY(hipMemcpy(d_fid.p, fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
+      if (hist) SDFT_TRY(hipMemcpy(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD), hipMemcpyHostToDevice));
+    }
+    cursor = cur;
+    return true;
+  }
+
   // state read-back for tests: acc, fid [channels][N]; hist [channels][2N] in time order
   bool get_state(fdx* acc, fdx* fid, TD* hist, size_t* cur)
   {

@@ -121,6 +121,16 @@ class SDFT:
             acc, fid, hist = acc[0], fid[0], hist[0]
         return acc, fid, hist, int(cur.value)
 
+    def set_state(self, acc, fid, hist, cursor: int):
+        """Checkpoint / resume: install a state obtained from :meth:`state` (of a plan with the same
+        parameters, possibly on another GPU)."""
+        acc = np.ascontiguousarray(acc, dtype=self.fdx); fid = np.ascontiguousarray(fid, dtype=self.fdx)
+        hist = np.ascontiguousarray(hist, dtype=self.td)
+        assert acc.size == self.channels * self.dftsize and hist.size == 2 * self.channels * self.dftsize
+        if self.api.set_state(self._p, acc.ctypes.data, fid.ctypes.data, hist.ctypes.data, int(cursor)) != 0:
+            self.api.check()
+            raise SdftHipError("sdft_hip_set_state failed")
+
     # ---- analysis / synthesis ---------------------------------------------------------------
     def _shape_x(self, shape):
         if self.channels == 1 and len(shape) == 1:

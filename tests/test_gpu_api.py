@@ -158,3 +158,32 @@ def test_reset_mid_stream_and_profile_counters():
         prof = p.profile()
         assert prof["forward"][1] == 2 and prof["delta"][1] == 2 and prof["forward"][0] > 0
         assert p.profile()["forward"][1] == 0              # counters reset after reading
+
+
+@pytest.mark.parametrize("combo", ["f32f64", "f32f32"])
+def test_checkpoint_and_resume_on_a_fresh_plan(combo):
+    """get_state -> set_state on a new plan continues the stream exactly where the first plan stopped
+    (the plan *is* the stream state, reference sdft.h:145-160)."""
+    td, fd, fdx = O.combo_types(combo)
+    m = 300
+    x = noise(2500, seed=5, dtype=td)
+    ref = O.best(m, "hann", 1.0, combo)
+    ref.sdft(x[:1300])
+    want = ref.sdft(x[1300:])
+    with make(m, "hann", 1.0, combo, carry=1, chunk=128) as a:
+        a.sdft(x[:1300])
+        snap = a.state()
+    with make(m, "hann", 1.0, combo, carry=1, chunk=128) as b:
+        b.set_state(*snap)
+        got = b.sdft(x[1300:])
+        assert b.state()[3] == (2500 % (2 * m))
+    assert np.array_equal(got, want)
+    # batched plan
+    ch = 2
+    xb = np.stack([noise(900, seed=c, dtype=td) for c in range(ch)])
+    with make(m, "hann", 1.0, combo, ch, chunk=1 << 30) as a:
+        a.sdft(xb[:, :400]); snap = a.state()
+        cont = a.sdft(xb[:, 400:])
+    with make(m, "hann", 1.0, combo, ch, chunk=1 << 30) as b:
+        b.set_state(*snap)
+        assert np.array_equal(b.sdft(xb[:, 400:]), cont)
