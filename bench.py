@@ -162,6 +162,7 @@ def main():
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
     plan.set_stream(stream.cuda_stream)
     plan.set_option("async", 1)
+    plan.set_option("pointers", 1)       # every buffer is device memory: skip the per-call pointer queries
     plan.set_option("profile", 1)
 
     def sync():
@@ -284,7 +285,7 @@ def main():
             x48 = torch.from_numpy(sine_sweep(n48, dtype=td)).cuda()
             o48 = out.view(-1)[: n48 * m].view(n48, m)
             p48 = SDFT(m, window, 1.0, combo, device=local_rank)
-            p48.set_stream(stream.cuda_stream); p48.set_option("async", 1)
+            p48.set_stream(stream.cuda_stream); p48.set_option("async", 1); p48.set_option("pointers", 1)
             for _ in range(5):
                 p48.sdft(x48, o48)
             p48.synchronize(); torch.cuda.synchronize()
