@@ -147,6 +147,19 @@ if __name__ == "__main__":
                 if len(sys.argv) > 3 and where == "device":
                     pr = p.profile(); print("   per-call device ms:", {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items()}, flush=True)
                 p.close()
+    if which == "host":
+        import time as _t, ctypes as C
+        for n, hint in ((1024, 0), (1024, 1), (48000, 1), (64, 1)):
+            p = SDFT(1024); p.set_option("async", 1); p.set_option("pointers", hint)
+            x = torch.from_numpy(sine_sweep(n)).cuda(); out = torch.empty((n, 1024), dtype=torch.complex128, device="cuda")
+            for _ in range(20): p.sdft(x, out)
+            p.synchronize()
+            xp, op = C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())
+            t0 = _t.perf_counter()
+            for _ in range(300): p.api.sdft_n(p._p, n, xp, op)          # raw C-ABI call, returns after enqueueing
+            t1 = _t.perf_counter(); p.synchronize(); t2 = _t.perf_counter()
+            print(f"n={n} pointers-hint={hint}: host {1e6 * (t1 - t0) / 300:.1f} us per call to return, {1e6 * (t2 - t0) / 300:.1f} us per call incl. drain; chunks={p.get_option('last_chunks')}", flush=True)
+            p.close()
     if which == "blocks":
         for rep in range(2):
             for blocks in (256, 512, 768, 1024, 1280, 2048):
