@@ -13,17 +13,29 @@ in HBM: `sdft_sdft_n` through the C-ABI of libsdft_hip.so on device pointers.
             each, m = 1024, Hann, FD double; channels are sharded over ranks, no data-path
             collective (RCCL is used for the barrier and the max/sum of scalars only).
 
-Rank 0 prints ONE JSON line.  `value` = samples analysed by all ranks / max-over-ranks wall time
-of the K timed steps.  `roofline` prices the dominant kernel (forward_kernel) by its algorithmic
-bytes (m*sizeof(fdx) + sizeof(td) per sample) over the kernel's own duration, measured with HIP
-events recorded by the library on the stream the kernel runs on.  `cpu_baseline` is the oracle
-(the genuine reference build when oracle/_ref is present, else our bit-identical port) timed on
-one host core on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+
+* `value` = samples ANALYSED (sdft_sdft_n) by all ranks / max-over-ranks wall time of the K timed
+  steps -- what configs[1] ("forward sdft only") asks for.  The metric string also names
+  synthesis: a second bracketed region times K analysis+synthesis pairs on every rank and reports
+  `analysis_plus_synthesis_msamples_s` (whole job, max over ranks) next to `synthesis_msamples_s`.
+* `roofline` prices the dominant kernel by its algorithmic bytes (m*sizeof(fdx) + sizeof(td) per
+  sample) over the kernel's own duration, measured with HIP events recorded by the library on the
+  stream the kernel runs on.
+* `cpu_baseline` is the oracle (the genuine reference build when oracle/_ref is present, else our
+  bit-identical port) timed on one host core on a bounded sample of the same workload.
+* At N = 1 rank 0 also reports, outside the timed regions: the north star's own shape (n = 48000)
+  on the DEFAULT drop-in path (no pointer hints; synchronous and asynchronous calls), the
+  reference's streaming test shape (hop = 100, m = 1000), one GPU's share of configs[4]
+  (64 channels x 48000, so the 1 -> 8 GPU curve has a like-for-like N = 1 point) with the
+  many-core CPU baseline beside it, the fused analysis->synthesis path, and the PCIe-inclusive
+  host-pointer rate.
 """
 
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -42,16 +54,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "single", "batch"])
-    ap.add_argument("--n", type=int, default=0, help="samples per channel (0 = workload default)")
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="samples per channel (0 = workload default)")
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--channels-per-gpu", type=int, default=64)
     ap.add_argument("--window", default="hann")
     ap.add_argument("--combo", default="f32f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=200000)
-    ap.add_argument("--no-extras", action="store_true", help="skip synthesis / PCIe side measurements")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the oracle with one channel per host core (many-core CPU baseline)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements outside the timed regions")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the many-core CPU baseline of the batch share")
     return ap.parse_args()
 
 
@@ -97,6 +108,75 @@ def cpu_baseline(m, window, combo, n_cpu):
         "sample": f"sdft_sdft_n forward, n={n_cpu} of the sine sweep, m={m}, {window}, {combo}, 1 thread"
                   f"{' pinned' if pinned else ''}, output pre-touched, best of 5; host has {os.cpu_count()} cores",
     }
+
+
+def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz, td, device):
+    """n = 48000 (the shape the north star quotes its >= 50 % target on) on the default drop-in path:
+    device pointers, NO pointer hints, synchronous calls (what a C host that just calls sdft_sdft_n
+    gets) and asynchronous ones; wall clock per call."""
+    n48 = 48000
+    x48 = torch.from_numpy(sine_sweep(n48, dtype=td)).cuda()
+    o48 = scratch.view(-1)[: n48 * m].view(n48, m)
+    b48 = n48 * (m * esz + np.dtype(td).itemsize)
+    res = {}
+    for mode in ("sync", "async"):
+        p = SDFT(m, window, 1.0, combo, device=device)
+        if mode == "async":
+            p.set_option("async", 1)
+        for _ in range(5):
+            p.sdft(x48, o48)
+        p.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            p.sdft(x48, o48)
+        p.synchronize(); torch.cuda.synchronize()
+        w = (time.perf_counter() - t0) / 50
+        res[mode] = {"ms_per_call_wall": round(w * 1e3, 4), "msamples_s_wall": round(n48 / w / 1e6, 1),
+                     "gbs_wall": round(b48 / w / 1e9, 1), "frac_of_peak_wall": round(b48 / w / 1e9 / HBM_PEAK_GBS, 4)}
+        if mode == "async":
+            p.set_option("profile", 1)                   # kernel time in a separate pass
+            for _ in range(20):
+                p.sdft(x48, o48)
+            pr = p.profile()
+            k48 = pr["forward"][0] / max(pr["forward"][1], 1) * 1e-3
+            res["forward_kernel_gbs"] = round(b48 / k48 / 1e9, 1)
+            res["prepass_us"] = round((pr["delta"][0] + pr["carry"][0]) / max(pr["forward"][1], 1) * 1e3, 1)
+        p.close()
+    res["path"] = "default: pointers classified by the library (cached per buffer), no options set"
+    res["note"] = "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache"
+    return res
+
+
+def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, hop=100, total=20000):
+    """/root/reference/test/test.c:69-83 with test/main.sh:3-6: hops of 100 samples, dftsize 1000,
+    Hann: sdft_sdft_n + sdft_isdft_n per hop on device pointers through the raw C-ABI."""
+    x = torch.from_numpy(sine_sweep(total, dtype=td)).cuda()
+    y = torch.empty(total, dtype=x.dtype, device="cuda")
+    d = torch.empty((hop, m), dtype=cdt, device="cuda")
+    p = SDFT(m, "hann", 1.0, combo, device=device)
+    xs, ys, ds, isz = x.data_ptr(), y.data_ptr(), d.data_ptr(), x.element_size()
+    res = {"dftsize": m, "hop": hop, "calls": "sdft_sdft_n + sdft_isdft_n per hop, device pointers, default options"}
+    for mode in ("sync", "async"):
+        p.set_option("async", 1 if mode == "async" else 0)
+        w = 0.0
+        for rep in range(2):
+            p.synchronize()
+            t0 = time.perf_counter()
+            for i in range(0, total, hop):
+                p.api.sdft_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ds))
+                p.api.isdft_n(p._p, hop, C.c_void_p(ds), C.c_void_p(ys + i * isz))
+            p.synchronize()
+            w = (time.perf_counter() - t0) / (total // hop)
+        res[f"us_per_hop_{mode}"] = round(w * 1e6, 1)
+    p.set_option("async", 1); p.set_option("profile", 1)
+    for i in range(0, total, hop):
+        p.api.sdft_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ds))
+        p.api.isdft_n(p._p, hop, C.c_void_p(ds), C.c_void_p(ys + i * isz))
+    pr = p.profile()
+    res["forward_kernel_us"] = round(pr["forward"][0] / max(pr["forward"][1], 1) * 1e3, 1)
+    res["inverse_kernel_us"] = round(pr["inverse"][0] / max(pr["inverse"][1], 1) * 1e3, 1)
+    p.close()
+    return res
 
 
 def main():
@@ -162,7 +242,6 @@ def main():
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
     plan.set_stream(stream.cuda_stream)
     plan.set_option("async", 1)
-    plan.set_option("pointers", 1)       # every buffer is device memory: skip the per-call pointer queries
     plan.set_option("profile", 1)
 
     def sync():
@@ -175,7 +254,7 @@ def main():
             sync(); plan.profile()       # the first call allocates the workspace: not representative
     sync()
     warm = plan.profile()                # warm-up pass: per-stage events (delta, carries, forward)
-    prepass_ms = (warm["delta"][0] + warm["carry"][0]) / max(warm["delta"][1], 1)
+    prepass_ms = (warm["delta"][0] + warm["carry"][0]) / max(warm["forward"][1], 1)
     plan.set_option("profile", 2)        # timed region: only the event pair around the dominant kernel
     shard.barrier(local_rank)
     sync()
@@ -191,6 +270,25 @@ def main():
     units = float(count * n * args.steps)
     rate, secs = shard.job_throughput(units, elapsed, local_rank)
 
+    # second bracketed region, every rank: analysis + synthesis pairs (the metric string names both)
+    y = plan.isdft(out)
+    sync(); plan.profile()
+    shard.barrier(local_rank)
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.sdft(x, out)
+        plan.isdft(out, y)
+    sync()
+    shard.barrier(local_rank)
+    sync()
+    elapsed_rt = time.perf_counter() - t1
+    prof_rt = plan.profile()
+    rate_rt, secs_rt = shard.job_throughput(units, elapsed_rt, local_rank)
+    i_ms, i_calls = prof_rt["inverse"]
+    i_avg = i_ms / max(i_calls, 1)
+    syn_rate = shard.sum_over_ranks(count * n / (i_avg * 1e-3) if i_avg > 0 else 0.0, local_rank)
+
     # roofline of the dominant kernel (this rank's launches; every rank runs the same shape)
     f_ms, f_calls = prof["forward"]
     bytes_per_launch = count * n * (m * esz + np.dtype(td).itemsize)
@@ -205,14 +303,19 @@ def main():
     except Exception:
         pass
 
+    kernel_names = {1: "forward_kernel", 2: "forward_rows_kernel", 3: "forward_hop_kernel"}
     result = {
         "metric": "Msamples/s analysis+synthesis, m=1024 Hann fp64; achieved HBM GB/s vs peak",
         "value": round(rate / 1e6, 3),
         "unit": "Msamples/s",
+        "value_is": "analysis only (sdft_sdft_n), as configs[1] states; the analysis+synthesis pair rate is the next field",
+        "analysis_plus_synthesis_msamples_s": round(rate_rt / 1e6, 3),
+        "synthesis_msamples_s": round(syn_rate / 1e6, 3),
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(secs / args.steps * 1e3, 4),
+        "ms_per_step_analysis_plus_synthesis": round(secs_rt / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -225,14 +328,14 @@ def main():
             "dftsize": m,
             "window": window,
             "types": combo,
-            "step": "analysis (sdft_sdft_n) only, as configs[1] states; synthesis rate reported under 'extras'",
+            "step": "analysis (sdft_sdft_n) on device-resident buffers",
             "time_chunks": plan.get_option("last_chunks"),
             "chunk_len": plan.get_option("last_chunk_len"),
             "carry_mode": "exact" if plan.get_option("carry") else "fast",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "forward_rows_kernel" if plan.get_option("last_kernel") == 2 else "forward_kernel",
+            "kernel": kernel_names.get(plan.get_option("last_kernel"), "?"),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -242,102 +345,106 @@ def main():
             "avg_launch_ms": round(f_avg_ms, 4),
             "launches": f_calls,
             "prepass_ms_per_step": round(prepass_ms, 4),
+            "synthesis_read_gbs": round(bytes_per_launch / (i_avg * 1e-3) / 1e9, 1) if i_avg > 0 else None,
         },
     }
 
-    # side measurements outside the timed region (rank 0, single GPU): store-only ceiling,
-    # synthesis, PCIe-inclusive path
-    if rank == 0 and not args.no_extras:
+    # side measurements outside the timed regions (rank 0, single GPU)
+    if rank == 0 and not distributed and not args.no_extras:
         extras = {}
+        from sdft_amd import capi
+        lib = capi.load()
         # achievable-write ceiling: kernels that do nothing but the store stream,
         # (a) plain linear fill, (b) the forward kernel's own shape (one workgroup per time chunk
         # writing whole rows in lockstep, barrier every 8 rows), over the same output buffer
-        from sdft_amd import capi
-        lib = capi.load()
         if esz == 16 and m % 64 == 0 and m <= 1024:
             nbytes = count * n * m * esz
             sync()
             lin = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 0, m, 64, 1, 5)
             grp = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 2, m, 8, max(int(plan.get_option("last_chunk_len")), 1), 5)
             torch.cuda.synchronize()
-            best_ms = min(x for x in (lin, grp) if x > 0)
+            best_ms = min(v for v in (lin, grp) if v > 0)
             result["roofline"]["store_only_ceiling"] = {
                 "linear_fill_gbs": round(nbytes / (lin * 1e-3) / 1e9, 1),
                 "row_lockstep_gbs": round(nbytes / (grp * 1e-3) / 1e9, 1),
                 "frac_of_best_store_only": round(achieved / (nbytes / (best_ms * 1e-3) / 1e9), 4),
             }
-        y = plan.isdft(out)
-        sync(); plan.profile()
-        reps = max(3, min(args.steps, 10))
-        for _ in range(reps):
-            plan.isdft(out, y)
-        sync()
-        i_ms, i_calls = plan.profile()["inverse"]
-        i_avg = i_ms / max(i_calls, 1)
-        extras["synthesis_msamples_s"] = round(count * n / (i_avg * 1e-3) / 1e6, 2)
-        extras["synthesis_read_gbs"] = round(count * n * (m * esz + np.dtype(td).itemsize) / (i_avg * 1e-3) / 1e9, 1)
-        step_ms = secs / args.steps * 1e3
-        extras["analysis_plus_synthesis_msamples_s"] = round(count * n / ((step_ms + i_avg) * 1e-3) / 1e6, 2)
-        if not distributed and workload == "single":
-            # the north star quotes its >= 50 % target at n = 48000 (same m, window, types): one call is
-            # only ~0.17 ms of device work, so both the kernel-only and the per-call wall rate are given
-            n48 = 48000
-            x48 = torch.from_numpy(sine_sweep(n48, dtype=td)).cuda()
-            o48 = out.view(-1)[: n48 * m].view(n48, m)
-            p48 = SDFT(m, window, 1.0, combo, device=local_rank)
-            p48.set_stream(stream.cuda_stream); p48.set_option("async", 1); p48.set_option("pointers", 1)
-            for _ in range(5):
-                p48.sdft(x48, o48)
-            p48.synchronize(); torch.cuda.synchronize()
-            t48 = time.perf_counter()                    # wall per call, no profiling events in the way
-            for _ in range(50):
-                p48.sdft(x48, o48)
-            p48.synchronize(); torch.cuda.synchronize()
-            w48 = (time.perf_counter() - t48) / 50
-            p48.set_option("profile", 1)                 # kernel time in a separate pass
-            for _ in range(20):
-                p48.sdft(x48, o48)
-            pr48 = p48.profile()
-            k48 = pr48["forward"][0] / max(pr48["forward"][1], 1) * 1e-3
-            b48 = n48 * (m * esz + np.dtype(td).itemsize)
-            extras["north_star_n48000"] = {
-                "msamples_s_wall": round(n48 / w48 / 1e6, 1), "gbs_wall": round(b48 / w48 / 1e9, 1),
-                "frac_of_peak_wall": round(b48 / w48 / 1e9 / HBM_PEAK_GBS, 4),
-                "forward_kernel_gbs": round(b48 / k48 / 1e9, 1), "ms_per_call_wall": round(w48 * 1e3, 4),
-                "note": "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache",
-            }
-            p48.close()
-        if not distributed:
-            npci = min(n, 65536)
-            hx = xh[..., :npci].copy() if count == 1 else np.ascontiguousarray(xh[:, :npci])
-            hp = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
-            hout = np.empty((npci, m) if count == 1 else (count, npci, m), dtype=np.complex128 if esz == 16 else np.complex64)
-            hp.sdft(hx, hout)
-            hp.reset()
-            t1 = time.perf_counter()
-            hp.sdft(hx, hout)
-            extras["host_pointer_pcie_inclusive_msamples_s"] = round(count * npci / (time.perf_counter() - t1) / 1e6, 3)
-            hp.close()
+        if workload == "single" and out.numel() >= 48000 * m:
+            result["north_star_n48000"] = north_star_shape(torch, np, SDFT, sine_sweep, out, m, window, combo, esz, td, local_rank)
+        result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)
+
+        # PCIe-inclusive host-pointer path (never `value`)
+        npci = min(n, 65536)
+        hx = xh[..., :npci].copy() if count == 1 else np.ascontiguousarray(xh[:, :npci])
+        hp = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
+        hout = np.empty((npci, m) if count == 1 else (count, npci, m), dtype=np.complex128 if esz == 16 else np.complex64)
+        hp.sdft(hx, hout)
+        hp.reset()
+        tp = time.perf_counter()
+        hp.sdft(hx, hout)
+        extras["host_pointer_pcie_inclusive_msamples_s"] = round(count * npci / (time.perf_counter() - tp) / 1e6, 3)
+        hp.close()
+
+        if workload == "single":
+            # one GPU's share of configs[4] (64 channels x 48000): the like-for-like N = 1 point of the
+            # 1 -> 8 GPU curve the driver builds from the N > 1 runs of this script
+            plan.close(); del out, y
+            torch.cuda.empty_cache()
+            chs, nb_ = args.channels_per_gpu, 48000
+            free, _ = torch.cuda.mem_get_info()
+            if free > chs * nb_ * m * esz * 1.05:
+                xb = torch.from_numpy(np.stack([sine_sweep(nb_, channel=c, channels=chs, dtype=td) for c in range(chs)])).cuda()
+                ob = torch.empty((chs, nb_, m), dtype=cdt, device="cuda")
+                pb = SDFT(m, window, 1.0, combo, channels=chs, device=local_rank)
+                pb.set_option("async", 1)
+                yb = None
+                for _ in range(2):
+                    pb.sdft(xb, ob); yb = pb.isdft(ob, yb)
+                pb.synchronize(); torch.cuda.synchronize()
+                reps = 5
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    pb.sdft(xb, ob)
+                pb.synchronize(); torch.cuda.synchronize()
+                wa = (time.perf_counter() - tb) / reps
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    pb.isdft(ob, yb)
+                pb.synchronize(); torch.cuda.synchronize()
+                ws = (time.perf_counter() - tb) / reps
+                bb = chs * nb_ * (m * esz + np.dtype(td).itemsize)
+                share = {
+                    "workload": f"one GPU's share of BASELINE configs[4]: {chs} channels x n={nb_}, m={m}, {window}, {combo}",
+                    "analysis_msamples_s": round(chs * nb_ / wa / 1e6, 2), "analysis_gbs": round(bb / wa / 1e9, 1),
+                    "analysis_frac_of_peak": round(bb / wa / 1e9 / HBM_PEAK_GBS, 4),
+                    "synthesis_msamples_s": round(chs * nb_ / ws / 1e6, 2), "synthesis_gbs": round(bb / ws / 1e9, 1),
+                    "analysis_plus_synthesis_msamples_s": round(chs * nb_ / (wa + ws) / 1e6, 2),
+                    "ms_per_call_analysis": round(wa * 1e3, 3),
+                }
+                pb.close(); del ob, xb, yb
+                torch.cuda.empty_cache()
+                if not args.no_cpu_all_cores:
+                    import subprocess
+                    procs = min(os.cpu_count() or 1, 64)
+                    r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--procs", str(procs), "--n", "16384", "--m", str(m),
+                                        "--window", window, "--combo", combo], capture_output=True, text=True, cwd=ROOT, timeout=600)
+                    try:
+                        share["cpu_baseline_all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
+                    except Exception:
+                        share["cpu_baseline_all_cores"] = {"error": r.stderr[-300:]}
+                result["batch_share"] = share
+            plan = None
         result["extras"] = extras
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        del out
         result["cpu_baseline"] = cpu_baseline(m, window, combo, args.cpu_samples)
     elif rank == 0:
         result["cpu_baseline"] = None
-    if rank == 0 and args.cpu_all_cores:
-        import subprocess
-        procs = min(os.cpu_count() or 1, 64)
-        r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--procs", str(procs), "--n", "16384", "--m", str(m),
-                            "--window", window, "--combo", combo], capture_output=True, text=True, cwd=ROOT, timeout=600)
-        try:
-            result.setdefault("extras", {})["cpu_baseline_all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
-        except Exception:
-            result.setdefault("extras", {})["cpu_baseline_all_cores"] = {"error": r.stderr[-300:]}
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    plan.close()
+    if plan is not None:
+        plan.close()
     if distributed:
         shard.barrier(local_rank)        # rank 0 may still have been busy with its side measurements
         dist.destroy_process_group()

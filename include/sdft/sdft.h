@@ -118,6 +118,10 @@ typedef struct sdft_plan sdft_t;
 
 /* ---- the drop-in surface ----------------------------------------------------------------- */
 
+/* Halo cells on either side of a spectrum for the window convolution (replaces the constant
+   defined at sdft.h:184; here it lives in the library, untyped). */
+extern const sdft_size_t sdft_convolution_kernel_size;
+
 /* Allocates a plan with `dftsize` bins, Hann window, latency 1.   (replaces sdft.h:457)
    Returns NULL if the GPU cannot be set up (sdft_hip_last_error() tells why). */
 sdft_t* sdft_alloc(const sdft_size_t dftsize) SDFT_HIP_SYMBOL(alloc);

@@ -49,6 +49,18 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
     if not force and not _stale():
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
+    # one builder at a time (every rank of a torchrun job may arrive here at once): the others wait
+    # on the lock and then find a fresh library; the link goes to a temporary name and is renamed
+    # into place, so no process can ever map a half-written libsdft_hip.so
+    import fcntl
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build_locked(save_temps, verbose, extra_flags)
+
+
+def _build_locked(save_temps, verbose, extra_flags) -> str:
     obj_dir = os.path.join(OUT_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
@@ -71,10 +83,12 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
     # runtime (two cannot both open the GPU); PyTorch wheels bundle their own under a different
     # soname than /opt/rocm's.  The host decides: a C program links -lamdhip64 itself
     # (INTEGRATION.md), capi.load() binds to the runtime already loaded in the interpreter.
-    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lm"],
+    tmp = LIB + f".tmp{os.getpid()}"
+    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lm"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(tmp, LIB)
     return LIB
 
 

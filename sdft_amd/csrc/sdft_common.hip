@@ -99,6 +99,10 @@ __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t
 
 extern "C" {
 
+// sdft.h:184
+extern const size_t sdft_convolution_kernel_size;
+const size_t sdft_convolution_kernel_size = 2;
+
 // Times `reps` launches of the store-only kernel over `bytes` of device memory at `dst`;
 // returns the average milliseconds per launch (negative on error).
 double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,

@@ -103,6 +103,23 @@ SDFT_D double from_above_fill(double old, double v)
   return __hiloint2double(hi, lo);
 }
 
+// bound_ctrl forms: the lane without a source lane receives 0 and no `old` value has to be set up
+// (saves one v_mov per shifted dword); for callers that never use what lane 0 / lane 63 receive
+SDFT_D int lane_from_below_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+SDFT_D int lane_from_above_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+SDFT_D float from_below_z(float v) { return __int_as_float(lane_from_below_z(__float_as_int(v))); }
+SDFT_D float from_above_z(float v) { return __int_as_float(lane_from_above_z(__float_as_int(v))); }
+SDFT_D double from_below_z(double v)
+{
+  const int lo = lane_from_below_z(__double2loint(v)), hi = lane_from_below_z(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+SDFT_D double from_above_z(double v)
+{
+  const int lo = lane_from_above_z(__double2loint(v)), hi = lane_from_above_z(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 SDFT_D float from_below(float v) { return __int_as_float(lane_from_below(__float_as_int(v))); }
 SDFT_D float from_above(float v) { return __int_as_float(lane_from_above(__float_as_int(v))); }
 SDFT_D double from_below(double v)
@@ -117,6 +134,8 @@ SDFT_D double from_above(double v)
 }
 template <typename T> SDFT_D cx<T> from_below_fill(cx<T> o, cx<T> z) { return cmake<T>(from_below_fill(o.re, z.re), from_below_fill(o.im, z.im)); }
 template <typename T> SDFT_D cx<T> from_above_fill(cx<T> o, cx<T> z) { return cmake<T>(from_above_fill(o.re, z.re), from_above_fill(o.im, z.im)); }
+template <typename T> SDFT_D cx<T> from_below_z(cx<T> z) { return cmake<T>(from_below_z(z.re), from_below_z(z.im)); }
+template <typename T> SDFT_D cx<T> from_above_z(cx<T> z) { return cmake<T>(from_above_z(z.re), from_above_z(z.im)); }
 template <typename T> SDFT_D cx<T> from_below(cx<T> z) { return cmake<T>(from_below(z.re), from_below(z.im)); }
 template <typename T> SDFT_D cx<T> from_above(cx<T> z) { return cmake<T>(from_above(z.re), from_above(z.im)); }
 
@@ -152,10 +171,12 @@ __global__ __launch_bounds__(kBlock) void delta_kernel(const TD* __restrict__ x,
                                                        const TD* __restrict__ hist_in, TD* __restrict__ hist_out,
                                                        FD* __restrict__ delta, size_t n, size_t span /*2N*/,
                                                        const cx<FD>* __restrict__ acc_state, const cx<FD>* __restrict__ fid_state,
-                                                       cx<FD>* __restrict__ carry0, cx<FD>* __restrict__ seed0)
+                                                       cx<FD>* __restrict__ carry0, cx<FD>* __restrict__ seed0,
+                                                       unsigned blocks_per_channel)
 {
-  const size_t ch = blockIdx.y;
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  // channels ride on grid.x (grid.y/z stop at 65535)
+  const size_t ch = blockIdx.x / blocks_per_channel;
+  const size_t i = (size_t)(blockIdx.x % blocks_per_channel) * kBlock + threadIdx.x;
   const TD* xs = x + ch * x_stride;
   const TD* hi = hist_in + ch * span;
   if (i < n)
@@ -267,9 +288,11 @@ template <typename FD>
 __global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
 {
   constexpr int B = kSumBlock;
-  const unsigned k = blockIdx.x * kBlock + threadIdx.x;
-  const unsigned j = blockIdx.y;            // chunk 0 .. chunks-2 (all of full length, a multiple of B)
-  const size_t ch = blockIdx.z;
+  // 1-D grid = bin blocks x (chunks - 1) x channels (grid.y/z stop at 65535)
+  const unsigned bin_blocks = (a.nbins + kBlock - 1) / kBlock;
+  const unsigned k = (blockIdx.x % bin_blocks) * kBlock + threadIdx.x;
+  const unsigned j = (blockIdx.x / bin_blocks) % (a.chunks - 1);   // chunk 0 .. chunks-2 (all of full length, a multiple of B)
+  const size_t ch = (blockIdx.x / bin_blocks) / (a.chunks - 1);
   const unsigned kk = k < a.nbins ? k : a.nbins - 1;
   const unsigned span = 2u * a.nbins;
   const size_t t0 = (size_t)j * a.chunk_len;
@@ -319,8 +342,8 @@ __global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsi
   extern __shared__ __align__(16) unsigned char fft_lds_raw[];
   cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw);
   const unsigned m = 1u << log2m;                        // 2N
-  const unsigned j = blockIdx.x;                         // chunk 0 .. chunks-2 (full length)
-  const size_t ch = blockIdx.y;
+  const unsigned j = blockIdx.x % (a.chunks - 1);        // chunk 0 .. chunks-2 (full length)
+  const size_t ch = blockIdx.x / (a.chunks - 1);
   const size_t t0 = (size_t)j * a.chunk_len;
   const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
   const FD* d = a.delta + ch * a.n + t0;
@@ -366,8 +389,8 @@ __global__ __launch_bounds__(kBlock) void chunk_fft_mixed_kernel(CarryArgs<FD> a
   extern __shared__ __align__(16) unsigned char fft_lds_raw2[];
   cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw2);
   cx<FD>* y = x + m;
-  const unsigned j = blockIdx.x;                         // chunk 0 .. chunks-2 (full length)
-  const size_t ch = blockIdx.y;
+  const unsigned j = blockIdx.x % (a.chunks - 1);        // chunk 0 .. chunks-2 (full length)
+  const size_t ch = blockIdx.x / (a.chunks - 1);
   const size_t t0 = (size_t)j * a.chunk_len;
   const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
   const FD* d = a.delta + ch * a.n + t0;
@@ -434,8 +457,9 @@ __global__ __launch_bounds__(kScanBins * kScanSlices) void carry_scan_kernel(Car
   __shared__ cx<FD> totals[kScanSlices][kScanBins];
   const int bin = threadIdx.x % kScanBins;
   const int slice = threadIdx.x / kScanBins;
-  const unsigned k = blockIdx.x * kScanBins + bin;
-  const size_t ch = blockIdx.y;
+  const unsigned bin_blocks = (a.nbins + kScanBins - 1) / kScanBins;
+  const unsigned k = (blockIdx.x % bin_blocks) * kScanBins + bin;
+  const size_t ch = blockIdx.x / bin_blocks;
   const unsigned kk = k < a.nbins ? k : a.nbins - 1;
   const unsigned per = (a.chunks + kScanSlices - 1) / kScanSlices;
   const unsigned j0 = slice * per;
@@ -496,8 +520,9 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
 
   const int lane = threadIdx.x;
   const int comp = lane & 1;
-  const unsigned bin = blockIdx.x * (kWave / 2) + (lane >> 1);
-  const size_t ch = blockIdx.y;
+  const unsigned bin_blocks = (a.nbins + kWave / 2 - 1) / (kWave / 2);
+  const unsigned bin = (blockIdx.x % bin_blocks) * (kWave / 2) + (lane >> 1);
+  const size_t ch = blockIdx.x / bin_blocks;
   const bool valid = bin < a.nbins;
   const unsigned kk = valid ? bin : a.nbins - 1;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
@@ -959,6 +984,231 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
         a.fid_state[ch * a.nbins + kfirst + b] = s[b].fid;
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 (hop form)  forward for calls that are one time chunk (hop-wise streaming, SURVEY.md 8 f1:
+// /root/reference/test/test.c:69-83 calls sdft_sdft_n with 100 samples per hop).  ONE launch does
+// what delta_kernel + forward kernel do for long calls:
+//   * the differences x[t] - x[t-2N] (sdft.h:564, TD precision) are formed in the kernel from the
+//     samples and the delay line, both read over the scalar unit (wave-uniform, read-only here);
+//   * a wave owns a tile of bins plus redundant halo lanes (like forward_kernel), and every wave is
+//     its own workgroup, so the tiles of a row spread over as many CUs: one CU alone stores only
+//     ~40 GB/s, which is what bounded the single-workgroup form (36 us per 100-sample hop);
+//   * the stream state is double-buffered (read acc/fid/delay line from the current set, write the
+//     other one), so no wave can observe a neighbour's new state and no copy launch is needed.
+// Arithmetic is the unfused reference sequence: bit-identical to the reference for every type.
+// (N == 1, where the reference's halo cells stay zero, keeps the three-launch path.)
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD> struct HopArgs
+{
+  const TD* x;                // [channels][n]
+  size_t x_stride;
+  const TD* hist_in;          // [channels][2N] delay line in time order
+  TD* hist_out;
+  const cx<FD>* tw;           // [N]
+  const cx<FD>* acc_in;       // [channels][N]
+  const cx<FD>* fid_in;
+  cx<FD>* acc_out;
+  cx<FD>* fid_out;
+  cx<FD>* out;                // rows: out + ch*out_stride + t*N
+  size_t out_stride;
+  cx<FD>* const* out_rows;    // optional row-pointer table [channels*n]
+  size_t n;
+  unsigned long long total_waves;
+  unsigned nbins, tiles, interior_lanes, cursor0;
+  int vec_store;
+  FD wscale;
+};
+
+template <typename TD, typename FD, int BPL, int WIN, bool ROWS, int WPB>
+__global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD> a)
+{
+  constexpr int H = win_halo<WIN>::value;
+  constexpr int HL = (H + BPL - 1) / BPL;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long wave = (unsigned long long)blockIdx.x * WPB + wib;
+  if (wave >= a.total_waves) return;
+  const unsigned tile = (unsigned)(wave % a.tiles);
+  const size_t ch = (size_t)(wave / a.tiles);
+
+  const long nbins = (long)a.nbins;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  unsigned c = a.cursor0;
+
+  const long kfirst = (long)tile * a.interior_lanes * BPL + (long)(lane - HL) * BPL;
+  const bool owner = (lane >= HL) && (lane < HL + (int)a.interior_lanes);
+
+  BinState<FD> s[BPL];
+  bool flip[BPL], keep[BPL];
+  unsigned flipmask[BPL];
+  const size_t sbase = ch * a.nbins;
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+  {
+    const long k = kfirst + b;
+    const long kk = reflect_bin(k, nbins, flip[b]);
+    flipmask[b] = flip[b] ? 0x80000000u : 0u;
+    keep[b] = owner && k >= 0 && k < nbins;
+    s[b].tw = a.tw[kk];
+    s[b].acc = a.acc_in[sbase + kk];
+    s[b].fid = a.fid_in[sbase + kk];
+  }
+
+  // delay line for the next call: element i of the last 2N samples of (hist ++ x)
+  {
+    const TD* xv = a.x + ch * a.x_stride;
+    const TD* hv = a.hist_in + ch * span;
+    TD* ho = a.hist_out + ch * span;
+    for (size_t i = (size_t)tile * kWave + lane; i < span; i += (size_t)a.tiles * kWave)
+    {
+      const size_t j = a.n + i;
+      ho[i] = (j >= span) ? xv[j - span] : hv[j];
+    }
+  }
+
+  const SDFT_CONSTANT TD* xs = as_uniform(a.x + ch * a.x_stride);
+  const SDFT_CONSTANT TD* hs = as_uniform(a.hist_in + ch * span);
+  const FD w = a.wscale;
+  // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit element offset
+  cx<FD>* row = a.out + ch * a.out_stride;
+  const unsigned off_bytes = (keep[0] || (BPL == 2 && keep[BPL - 1])) ? (unsigned)(kfirst < 0 ? 0 : kfirst) * (unsigned)sizeof(cx<FD>) : 0u;
+  cx<FD>* const* rows = ROWS ? a.out_rows + ch * a.n : nullptr;
+
+  auto emit = [&](cx<FD> (&x)[BPL], size_t t)
+  {
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) x[b].im = flip_sign(x[b].im, flipmask[b]);     // mirror lanes conjugate
+    cx<FD> e[BPL + 4] = {};
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) e[b + 2] = x[b];
+    if constexpr (H >= 1)
+    {
+      e[1] = from_below_z(x[BPL - 1]);
+      e[BPL + 2] = from_above_z(x[0]);
+    }
+    if constexpr (H >= 2)
+    {
+      if constexpr (BPL >= 2)
+      {
+        e[0] = from_below_z(x[BPL - 2]);
+        e[BPL + 3] = from_above_z(x[1]);
+      }
+      else
+      {
+        e[0] = from_below_z(e[1]);
+        e[BPL + 3] = from_above_z(e[BPL + 2]);
+      }
+    }
+    cx<FD> y[BPL];
+#pragma unroll
+    for (int b = 0; b < BPL; ++b)
+      y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
+
+    cx<FD>* p = reinterpret_cast<cx<FD>*>(reinterpret_cast<char*>(row) + off_bytes);
+    if constexpr (ROWS) p = rows[t] + kfirst;
+    if constexpr (BPL == 2)
+    {
+      if (a.vec_store && !ROWS)
+      {
+        if (keep[0])
+        {
+          using V = typename StoreVec<FD, 2>::type;
+          V v; v.x = y[0].re; v.y = y[0].im; v.z = y[1].re; v.w = y[1].im;
+          store_vec(reinterpret_cast<V*>(p), v);
+        }
+      }
+      else
+      {
+        if (keep[0]) p[0] = y[0];
+        if (keep[1]) p[1] = y[1];
+      }
+    }
+    else
+    {
+      if (keep[0])
+      {
+        using V = typename StoreVec<FD, 1>::type;
+        V v; v.x = y[0].re; v.y = y[0].im;
+        store_vec(reinterpret_cast<V*>(p), v);
+      }
+    }
+    row += a.nbins;
+  };
+
+  size_t t = 0;
+  while (t < a.n)
+  {
+    size_t run = maxc - c;
+    if (run > a.n - t) run = a.n - t;
+    size_t i = 0;
+    for (; i + kGroup <= run; i += kGroup)
+    {
+      // differences of kGroup samples (sdft.h:564): the old sample comes from the delay line while
+      // t < 2N, from the call's own input afterwards
+      const size_t tt = t + i;
+      TD cur[kGroup], old[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) cur[u] = xs[tt + u];
+      if (tt + kGroup <= span)
+      {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) old[u] = hs[tt + u];
+      }
+      else if (tt >= span)
+      {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) old[u] = xs[tt - span + u];
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) old[u] = (tt + u < span) ? hs[tt + u] : xs[tt + u - span];
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u)
+      {
+        const TD dd = cur[u] - old[u];                    // TD precision
+        const FD dl = (FD)dd;
+        cx<FD> x[BPL];
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) x[b] = step_normal(s[b], dl);
+        emit(x, tt + u);
+      }
+    }
+    for (; i <= run && t + i < a.n; ++i)                  // tail of the run, then the roll-over step
+    {
+      const size_t tt = t + i;
+      const TD cur = xs[tt];
+      const TD old = (tt < span) ? hs[tt] : xs[tt - span];
+      const TD dd = cur - old;
+      const FD dl = (FD)dd;
+      cx<FD> x[BPL];
+      if (i < run)
+      {
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) x[b] = step_normal(s[b], dl);
+      }
+      else
+      {
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) x[b] = step_wrap(s[b], dl);
+      }
+      emit(x, tt);
+    }
+    if (t + run < a.n) { t += run + 1; c = 0; }            // the roll-over step was taken
+    else { t += run; c += (unsigned)run; }
+  }
+
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+    if (keep[b])
+    {
+      a.acc_out[sbase + kfirst + b] = s[b].acc;
+      a.fid_out[sbase + kfirst + b] = s[b].fid;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1443,6 +1693,93 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
     const size_t r = r0 + lane;
     if (lane < RW && r < a.n) a.y[ch * a.y_stride + r] = (TD)(sum * a.sweight);     // sdft.h:654-656
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 (row form, short calls)  exact-order synthesis for calls with few rows (a 100-row hop): one
+// wave per row.  The lanes fetch the whole row with every load in flight at once, turn bins into
+// the scalars the reference adds (sdft.h:643 / :650) and park them in LDS in bin order; then all
+// lanes walk the LDS block with broadcast reads and add the terms strictly in ascending bin
+// order (every lane holds the same sum: no exec masking, same cost as one lane).  What remains is
+// the chain of N dependent additions the reference's summation order dictates.
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD, bool LAT1>
+__global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> a)
+{
+  constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load
+  constexpr int NL = 16;                                 // loads in flight per lane
+  constexpr int TB = kWave * NL * BPL;                   // bins per LDS block (1024 f64 / 2048 f32: 8 KiB)
+  using V = typename StoreVec<FD, (sizeof(cx<FD>) == 16 ? 1 : 2)>::type;
+  __shared__ __align__(16) FD terms[TB];
+
+  const int lane = threadIdx.x;
+  const size_t r = blockIdx.x;
+  const size_t ch = r / a.n, t = r - ch * a.n;
+  const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
+  const bool vec_ok = (BPL == 1) || ((a.nbins % 2 == 0) && (((uintptr_t)row & 15) == 0));
+
+  FD sum = (FD)0;
+  for (unsigned k0 = 0; k0 < a.nbins; k0 += TB)
+  {
+    cx<FD> v[NL][BPL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+    {
+      const unsigned k = k0 + (unsigned)(i * kWave + lane) * BPL;
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) v[i][b] = cmake<FD>((FD)0, (FD)0);
+      if (k < a.nbins)
+      {
+        if (BPL == 2 && vec_ok && k + 1 < a.nbins)
+        {
+          const V q = *reinterpret_cast<const V*>(row + k);
+          v[i][0] = cmake<FD>((FD)q[0], (FD)q[1]);
+          if constexpr (BPL == 2) v[i][1] = cmake<FD>((FD)q[2], (FD)q[3]);
+        }
+        else
+        {
+#pragma unroll
+          for (int b = 0; b < BPL; ++b)
+            if (k + b < a.nbins) v[i][b] = row[k + b];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int b = 0; b < BPL; ++b)
+      {
+        const unsigned kl = (unsigned)(i * kWave + lane) * BPL + b;
+        const unsigned k = k0 + kl;
+        FD term;
+        if constexpr (LAT1) term = v[i][b].re * ((k & 1u) ? (FD)(-1) : (FD)(+1));              // sdft.h:643
+        else { const cx<FD> sy = a.syn[k < a.nbins ? k : 0]; term = v[i][b].re * sy.re - v[i][b].im * sy.im; }   // re of :650
+        terms[kl] = term;
+      }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const unsigned cnt = (a.nbins - k0 < (unsigned)TB) ? a.nbins - k0 : (unsigned)TB;
+    if (cnt == (unsigned)TB)
+    {
+#pragma unroll 32
+      for (int cix = 0; cix < TB; ++cix) sum += terms[cix];
+    }
+    else
+    {
+      unsigned cix = 0;
+      for (; cix + 16 <= cnt; cix += 16)
+      {
+        FD tt[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tt[q] = terms[cix + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += tt[q];
+      }
+      for (; cix < cnt; ++cix) sum += terms[cix];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);                   // sdft.h:654-656
 }
 
 }  // namespace sdfthip

@@ -102,9 +102,11 @@ template <typename T> struct DevBuf
   bool reserve(size_t count)
   {
     if (count <= cap) return true;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    SDFT_TRY(hipMalloc((void**)&p, count * sizeof(T)));
-    cap = count;
+    // allocate first, free afterwards: a failed growth leaves the old buffer usable
+    T* q = nullptr;
+    SDFT_TRY(hipMalloc((void**)&q, count * sizeof(T)));
+    if (p) (void)hipFree(p);
+    p = q; cap = count;
     return true;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -140,11 +142,18 @@ class Plan
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
   long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
+  long opt_hop_kernel = 1;       // single-chunk calls: fused delta + forward launch (forward_hop_kernel)
+  long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
 
   // device-resident stream state
-  DevBuf<fdx> d_tw, d_syn, d_wtab, d_acc, d_fid;
+  DevBuf<fdx> d_tw, d_syn, d_wtab;
+  // acc / fid / delay line are double-buffered: single-chunk calls read one set and write the other
+  DevBuf<fdx> d_accs[2], d_fids[2];
+  int st_cur = 0;
+  fdx* acc_p() { return d_accs[st_cur].p; }
+  fdx* fid_p() { return d_fids[st_cur].p; }
   DevBuf<TD> d_hist[2];
   int hist_cur = 0;
   size_t cursor = 0;             // reference cursor (:153)
@@ -193,7 +202,8 @@ class Plan
     if (nbins == 0) return true;
     const size_t nb = nbins, span = 2 * nbins;
     if (!d_tw.reserve(nb) || !d_syn.reserve(nb) || !d_wtab.reserve(span)) return false;
-    if (!d_acc.reserve(channels * nb) || !d_fid.reserve(channels * nb)) return false;
+    for (int q = 0; q < 2; ++q)
+      if (!d_accs[q].reserve(channels * nb) || !d_fids[q].reserve(channels * nb)) return false;
     if (!d_hist[0].reserve(channels * span) || !d_hist[1].reserve(channels * span)) return false;
     SDFT_TRY(hipMemcpyAsync(d_tw.p, tab.tw.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
     SDFT_TRY(hipMemcpyAsync(d_syn.p, tab.syn.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
@@ -205,9 +215,10 @@ class Plan
   {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    d_tw.release(); d_syn.release(); d_wtab.release(); d_acc.release(); d_fid.release();
+    d_tw.release(); d_syn.release(); d_wtab.release();
+    for (int q = 0; q < 2; ++q) { d_accs[q].release(); d_fids[q].release(); }
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
-    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release();
+    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -228,14 +239,14 @@ class Plan
   // sdft.h:517-529
   bool reset()
   {
-    cursor = 0; hist_cur = 0;
+    cursor = 0; hist_cur = 0; st_cur = 0;
     if (nbins == 0) return true;
     if (!bind()) return false;
     const size_t nb = nbins, span = 2 * nbins;
     SDFT_TRY(hipMemsetAsync(d_hist[0].p, 0, channels * span * sizeof(TD), stream));
-    SDFT_TRY(hipMemsetAsync(d_acc.p, 0, channels * nb * sizeof(fdx), stream));
+    SDFT_TRY(hipMemsetAsync(acc_p(), 0, channels * nb * sizeof(fdx), stream));
     std::vector<fdx> ones(channels * nb, cmake<FD>((FD)1, (FD)0));
-    SDFT_TRY(hipMemcpyAsync(d_fid.p, ones.data(), ones.size() * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    SDFT_TRY(hipMemcpyAsync(fid_p(), ones.data(), ones.size() * sizeof(fdx), hipMemcpyHostToDevice, stream));
     SDFT_TRY(hipStreamSynchronize(stream));
     return true;
   }
@@ -252,7 +263,7 @@ class Plan
 
   // ---- profiling ---------------------------------------------------------------------------
   bool prof_on(int st) const { return profile == 1 || (profile == 2 && (st == ST_FORWARD || st == ST_INVERSE)); }
-  bool prof_begin(int st)
+  bool prof_begin(int st, hipStream_t on = nullptr)
   {
     if (!prof_on(st)) return true;
     if (ev_used[st] + 2 > ev_pool[st].size())
@@ -261,13 +272,13 @@ class Plan
       SDFT_TRY(hipEventCreate(&a)); SDFT_TRY(hipEventCreate(&b));
       ev_pool[st].push_back(a); ev_pool[st].push_back(b);
     }
-    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st]], stream));
+    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st]], on ? on : stream));
     return true;
   }
-  bool prof_end(int st)
+  bool prof_end(int st, hipStream_t on = nullptr)
   {
     if (!prof_on(st)) return true;
-    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st] + 1], stream));
+    SDFT_TRY(hipEventRecord(ev_pool[st][ev_used[st] + 1], on ? on : stream));
     ev_used[st] += 2;
     return true;
   }
@@ -358,6 +369,14 @@ class Plan
     chunks = (long)((n + len - 1) / len);
   }
 
+  // every launch is a 1-D grid (channels ride on grid.x); refuse what would not fit it
+  static bool grid_fits(size_t blocks)
+  {
+    if (blocks <= 0x7fffffffull) return true;
+    set_error("launch", "grid too large: channels x chunks x bins exceed 2^31 workgroups");
+    return false;
+  }
+
   // ---- forward on device-resident buffers ------------------------------------------------
   // x: [channels] x n with stride x_stride; out: rows at out + ch*out_stride + t*N, or the row
   // pointer table `rows` (device array of channels*n device pointers)
@@ -373,6 +392,8 @@ class Plan
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
+    last_segments = 1; last_fused = 0;
+    if (chunks == 1 && opt_hop_kernel && nbins >= 2) return forward_hop(n, x, x_stride, out, out_stride, rows);
 
     if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
@@ -383,11 +404,13 @@ class Plan
     if (!prof_begin(ST_DELTA)) return false;
     {
       const size_t work = std::max(n, span);
-      dim3 grid((unsigned)((work + kBlock - 1) / kBlock), (unsigned)channels);
+      const size_t per_ch = (work + kBlock - 1) / kBlock;
+      if (!grid_fits(per_ch * channels)) return false;
       const bool single = (chunks == 1);
-      hipLaunchKernelGGL((delta_kernel<TD, FD>), grid, dim3(kBlock), 0, stream, x, x_stride,
+      hipLaunchKernelGGL((delta_kernel<TD, FD>), dim3((unsigned)(per_ch * channels)), dim3(kBlock), 0, stream, x, x_stride,
                          d_hist[hist_cur].p, d_hist[hist_cur ^ 1].p, d_delta.p, n, span,
-                         (const fdx*)d_acc.p, (const fdx*)d_fid.p, single ? d_carry.p : (fdx*)nullptr, single ? d_seed.p : (fdx*)nullptr);
+                         (const fdx*)acc_p(), (const fdx*)fid_p(), single ? d_carry.p : (fdx*)nullptr, single ? d_seed.p : (fdx*)nullptr,
+                         (unsigned)per_ch);
       SDFT_TRY(hipGetLastError());
       hist_cur ^= 1;
     }
@@ -395,22 +418,10 @@ class Plan
 
     // carries
     long segments = 1;
-    if (!prof_begin(ST_CARRY)) return false;
-    CarryArgs<FD> ca;
-    ca.acc_next = nullptr; ca.fid_next = nullptr; ca.chunk0 = 0; ca.launch_chunks = (unsigned)chunks;
-    ca.delta = d_delta.p; ca.tw = d_tw.p; ca.wtab = d_wtab.p; ca.carry = d_carry.p; ca.seed = d_seed.p;
-    ca.acc_state = d_acc.p; ca.fid_state = d_fid.p; ca.n = n;
-    ca.nbins = (unsigned)nb; ca.chunks = (unsigned)chunks; ca.chunk_len = (unsigned)len; ca.cursor0 = (unsigned)cursor;
-    const unsigned bin_blocks = (unsigned)((nb + kBlock - 1) / kBlock);
-    bool use_seed = true;
-    if (chunks == 1)
-    {
-      // single chunk: the stream state is the carry; delta_kernel has already copied it
-    }
-    else if (exact)
+    if (exact && chunks > 1)
     {
       // time segments: the serial pass of segment s+1 (few waves, latency-bound) runs on `aux`
-      // while the forward kernel of segment s streams the matrix on `stream`
+      // while the forward kernel of segment s streams the matrix on `stream`;
       // up to 8 segments, each forward launch still filling the chip (>= 256 workgroups)
       const long launch_blocks = use_rows ? (long)channels * chunks : (long)channels * chunks * ntiles / kWavesPerBlock;
       segments = opt_segments > 0 ? opt_segments : std::max(1L, std::min(8L, launch_blocks / 256));
@@ -429,16 +440,35 @@ class Plan
         SDFT_TRY(hipEventRecord(ev_delta, stream));                 // delta (and everything before) done
         SDFT_TRY(hipStreamWaitEvent(aux, ev_delta, 0));
       }
+    }
+    // the stage's events go where its kernels go (the overlapped exact pass runs on `aux`)
+    hipStream_t carry_stream = segments > 1 ? aux : stream;
+    if (!prof_begin(ST_CARRY, carry_stream)) return false;
+    CarryArgs<FD> ca;
+    ca.acc_next = nullptr; ca.fid_next = nullptr; ca.chunk0 = 0; ca.launch_chunks = (unsigned)chunks;
+    ca.delta = d_delta.p; ca.tw = d_tw.p; ca.wtab = d_wtab.p; ca.carry = d_carry.p; ca.seed = d_seed.p;
+    ca.acc_state = acc_p(); ca.fid_state = fid_p(); ca.n = n;
+    ca.nbins = (unsigned)nb; ca.chunks = (unsigned)chunks; ca.chunk_len = (unsigned)len; ca.cursor0 = (unsigned)cursor;
+    const unsigned bin_blocks = (unsigned)((nb + kBlock - 1) / kBlock);
+    if (!grid_fits((size_t)bin_blocks * (size_t)chunks * channels) || !grid_fits(((nb + kScanBins - 1) / kScanBins) * channels) ||
+        !grid_fits(((nb + kWave / 2 - 1) / (kWave / 2)) * channels)) return false;
+    bool use_seed = true;
+    if (chunks == 1)
+    {
+      // single chunk: the stream state is the carry; delta_kernel has already copied it
+    }
+    else if (exact)
+    {
       const unsigned eblocks = (unsigned)((nb + kWave / 2 - 1) / (kWave / 2));
       for (long sg = 0; sg < segments; ++sg)
       {
         const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
         CarryArgs<FD> cs = ca;
         cs.chunk0 = (unsigned)j0; cs.launch_chunks = (unsigned)(j1 - j0);
-        cs.acc_state = sg == 0 ? d_acc.p : d_run_acc[(sg - 1) & 1].p;
-        cs.fid_state = sg == 0 ? d_fid.p : d_run_fid[(sg - 1) & 1].p;
+        cs.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
+        cs.fid_state = sg == 0 ? fid_p() : d_run_fid[(sg - 1) & 1].p;
         cs.acc_next = d_run_acc[sg & 1].p; cs.fid_next = d_run_fid[sg & 1].p;
-        hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3(eblocks, (unsigned)channels), dim3(kWave), 0,
+        hipLaunchKernelGGL((carry_exact_kernel<FD>), dim3(eblocks * (unsigned)channels), dim3(kWave), 0,
                            segments > 1 ? aux : stream, cs);
         SDFT_TRY(hipGetLastError());
         if (segments > 1) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
@@ -460,20 +490,20 @@ class Plan
       if (opt_fft_carry && pow2 && span_bytes <= (size_t)64 * 1024)
       {
         unsigned lg = 0; while (((size_t)1 << lg) < span) ++lg;
-        hipLaunchKernelGGL((chunk_fft_kernel<FD>), dim3((unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), span_bytes, stream, ca, lg);
+        hipLaunchKernelGGL((chunk_fft_kernel<FD>), dim3((unsigned)((chunks - 1) * channels)), dim3(kBlock), span_bytes, stream, ca, lg);
       }
       else if (opt_fft_carry && rl.count > 0 && 2 * span_bytes <= (size_t)64 * 1024)
-        hipLaunchKernelGGL((chunk_fft_mixed_kernel<FD>), dim3((unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 2 * span_bytes,
+        hipLaunchKernelGGL((chunk_fft_mixed_kernel<FD>), dim3((unsigned)((chunks - 1) * channels)), dim3(kBlock), 2 * span_bytes,
                            stream, ca, (unsigned)span, rl);
       else
-        hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3(bin_blocks, (unsigned)(chunks - 1), (unsigned)channels), dim3(kBlock), 0, stream, ca);
+        hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3((unsigned)((size_t)bin_blocks * (chunks - 1) * channels)), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
-      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)((nb + kScanBins - 1) / kScanBins), (unsigned)channels),
+      hipLaunchKernelGGL((carry_scan_kernel<FD>), dim3((unsigned)(((nb + kScanBins - 1) / kScanBins) * channels)),
                          dim3(kScanBins * kScanSlices), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
       use_seed = false;
     }
-    if (!prof_end(ST_CARRY)) return false;
+    if (!prof_end(ST_CARRY, carry_stream)) return false;
 
     // K1
     if (!prof_begin(ST_FORWARD)) return false;
@@ -481,7 +511,7 @@ class Plan
     fa.delta = d_delta.p; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = d_carry.p;
     fa.seed = use_seed ? d_seed.p : nullptr;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = rows;
-    fa.acc_state = d_acc.p; fa.fid_state = d_fid.p; fa.n = n;
+    fa.acc_state = acc_p(); fa.fid_state = fid_p(); fa.n = n;
     fa.total_waves = (unsigned long long)channels * (unsigned long long)chunks * (unsigned long long)ntiles;
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
     fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor;
@@ -506,6 +536,51 @@ class Plan
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
 
+    cursor = (cursor + n) % span;
+    return true;
+  }
+
+  // ---- single-chunk calls (hop-wise streaming): one fused launch, tiles spread over the CUs ----
+  template <bool ROWS, int WPB> void launch_hop_t(const HopArgs<TD, FD>& ha, unsigned blocks)
+  {
+    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
+    const dim3 g(blocks), b(kWave * WPB);
+    switch (window)
+    {
+      case WIN_HANN:     hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_HANN, ROWS, WPB>), g, b, 0, stream, ha); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_HAMMING, ROWS, WPB>), g, b, 0, stream, ha); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_BLACKMAN, ROWS, WPB>), g, b, 0, stream, ha); break;
+      default:           hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_BOXCAR, ROWS, WPB>), g, b, 0, stream, ha); break;
+    }
+  }
+
+  bool forward_hop(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows)
+  {
+    const size_t nb = nbins, span = 2 * nbins;
+    const long ntiles = tiles(), inter = interior_lanes();
+    HopArgs<TD, FD> ha;
+    ha.x = x; ha.x_stride = x_stride;
+    ha.hist_in = d_hist[hist_cur].p; ha.hist_out = d_hist[hist_cur ^ 1].p;
+    ha.tw = d_tw.p;
+    ha.acc_in = d_accs[st_cur].p; ha.fid_in = d_fids[st_cur].p;
+    ha.acc_out = d_accs[st_cur ^ 1].p; ha.fid_out = d_fids[st_cur ^ 1].p;
+    ha.out = out; ha.out_stride = out_stride; ha.out_rows = rows; ha.n = n;
+    ha.total_waves = (unsigned long long)channels * (unsigned long long)ntiles;
+    ha.nbins = (unsigned)nb; ha.tiles = (unsigned)ntiles; ha.interior_lanes = (unsigned)inter; ha.cursor0 = (unsigned)cursor;
+    ha.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
+    ha.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
+    // one wave per workgroup while the launch is small (the tiles of a row land on different CUs);
+    // four per workgroup once there are more waves than SIMDs anyway
+    const bool wide = ha.total_waves > 2048;
+    const unsigned long long blocks = wide ? (ha.total_waves + 3) / 4 : ha.total_waves;
+    if (!grid_fits(blocks)) return false;
+    if (!prof_begin(ST_FORWARD)) return false;
+    if (rows) { if (wide) launch_hop_t<true, 4>(ha, (unsigned)blocks); else launch_hop_t<true, 1>(ha, (unsigned)blocks); }
+    else      { if (wide) launch_hop_t<false, 4>(ha, (unsigned)blocks); else launch_hop_t<false, 1>(ha, (unsigned)blocks); }
+    SDFT_TRY(hipGetLastError());
+    if (!prof_end(ST_FORWARD)) return false;
+    hist_cur ^= 1; st_cur ^= 1;
+    last_kernel = 3;
     cursor = (cursor + n) % span;
     return true;
   }
@@ -571,12 +646,18 @@ class Plan
       const bool lat1 = (latency == 1);                                         // :639 exact compare
       // measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16: 2.82, 64: 3.6 (130 VGPRs);
       // float bins and short calls do best with 16
+      // short calls (a hop of 100 rows): one wave per row, the rows spread over the CUs
       const long rw = opt_inverse_rows > 0 ? opt_inverse_rows
-                                           : (total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
+                                           : (total_rows <= 1024 ? 1 : total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
       size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
       eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
       const dim3 g((unsigned)eb), b(kBlock);
-      if (rw >= 32)
+      if (rw == 1 && grid_fits(total_rows))
+      {
+        if (lat1) hipLaunchKernelGGL((inverse_row_kernel<TD, FD, true>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
+        else hipLaunchKernelGGL((inverse_row_kernel<TD, FD, false>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
+      }
+      else if (rw >= 32)
       {
         if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 32, 1>), g, b, 0, stream, ia);
         else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 32, 1>), g, b, 0, stream, ia);
@@ -601,7 +682,41 @@ class Plan
     return true;
   }
 
-  bool finish() { if (!async) return synchronize(); return true; }
+  // synchronous calls: short ones poll the stream (a sleeping hipStreamSynchronize wakes up late --
+  // tens of microseconds, more than a whole 100-sample hop takes on the device)
+  bool finish(size_t work = 0)
+  {
+    if (async) return true;
+    if (opt_spin && work && work <= ((size_t)1 << 24))
+    {
+      for (int spins = 0; spins < 20000; ++spins)
+      {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return collect_profile();
+        if (e != hipErrorNotReady) { set_error("hipStreamQuery", hipGetErrorString(e)); return false; }
+      }
+      (void)hipGetLastError();
+    }
+    return synchronize();
+  }
+
+  // Pointer classification, cached per distinct pointer value: hosts that stream through the same
+  // buffers call after call pay hipPointerGetAttributes once per buffer.  (A cached answer would
+  // be stale only if a device allocation were freed and the very same address handed out again as
+  // host memory; option "pointers" = 3 queries on every call, 1 / 2 declare all device / all host.)
+  struct PtrClass { const void* p; bool dev; };
+  PtrClass ptr_cache[8] = {};
+  unsigned ptr_cache_next = 0;
+  bool on_device(const void* p)
+  {
+    if (opt_pointers == 1) return true;
+    if (opt_pointers == 2) return false;
+    if (opt_pointers == 3 || !p) return is_device_pointer(p);
+    for (const PtrClass& e : ptr_cache) if (e.p == p) return e.dev;
+    const bool dev = is_device_pointer(p);
+    ptr_cache[ptr_cache_next++ % 8] = PtrClass{p, dev};
+    return dev;
+  }
 
   // one strip per channel; per-channel async copies (no pitch limits, works for any size)
   bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, hipMemcpyKind kind)
@@ -613,14 +728,15 @@ class Plan
 
   // ---- public entry points: dense matrices, host or device pointers ---------------------------
   // x: [channels][n], dfts: [channels][n][N]
-  bool sdft_n(size_t n, const TD* x, fdx* dfts)
+  // x_class: -1 = classify x, 0 = x is host memory whatever option "pointers" says (by-value sample)
+  bool sdft_n(size_t n, const TD* x, fdx* dfts, int x_class = -1)
   {
     if (n == 0 || nbins == 0) return true;
     if (!bind()) return false;
-    const bool xd = opt_pointers ? opt_pointers == 1 : is_device_pointer(x);
-    const bool od = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
+    const bool xd = x_class < 0 ? on_device(x) : x_class != 0;
+    const bool od = on_device(dfts);
     if (xd && od)
-      return forward_device(n, x, n, dfts, n * nbins, nullptr) && finish();
+      return forward_device(n, x, n, dfts, n * nbins, nullptr) && finish(channels * n * nbins);
 
     // staged path (host pointers): time segments so that the staging matrix stays bounded;
     // the stream state carries over from segment to segment exactly like hop-wise calls do
@@ -654,10 +770,18 @@ class Plan
     return synchronize();
   }
 
-  // array-of-row-pointers variant (sdft.h:622-628); single channel
+  // array-of-row-pointers variant (sdft.h:622-628).  Single-channel plans only: the reference's
+  // table has one pointer per sample, a batched layout for it is not defined.
+  bool single_channel(const char* fn)
+  {
+    if (channels == 1) return true;
+    set_error(fn, "row-pointer variants take single-channel plans only (use sdft_sdft_n / sdft_isdft_n with a batched plan)");
+    return false;
+  }
   bool sdft_nd(size_t n, const TD* x, fdx** dfts)
   {
     if (n == 0 || nbins == 0) return true;
+    if (!single_channel("sdft_sdft_nd")) return false;
     if (!bind()) return false;
     const bool table_on_device = is_device_pointer(dfts);
     bool rows_on_device = false;
@@ -701,8 +825,8 @@ class Plan
   {
     if (n == 0) return true;
     if (!bind()) return false;
-    const bool id = opt_pointers ? opt_pointers == 1 : is_device_pointer(dfts);
-    const bool yd = opt_pointers ? opt_pointers == 1 : is_device_pointer(y);
+    const bool id = on_device(dfts);
+    const bool yd = on_device(y);
     if (nbins == 0)
     {
       // empty spectrum: the reference returns (td)(0 * 2)
@@ -710,7 +834,7 @@ class Plan
       return finish();
     }
     if (id && yd)
-      return inverse_device(n, dfts, n * nbins, nullptr, y, n) && finish();
+      return inverse_device(n, dfts, n * nbins, nullptr, y, n) && finish(channels * n * nbins);
     const size_t row_bytes = channels * nbins * sizeof(fdx);
     size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
     seg = std::min(seg, n);
@@ -744,6 +868,7 @@ class Plan
   bool isdft_nd(size_t n, const fdx** dfts, TD* y)
   {
     if (n == 0) return true;
+    if (!single_channel("sdft_isdft_nd")) return false;
     if (!bind()) return false;
     if (nbins == 0) return isdft_n(n, nullptr, y);
     const bool table_on_device = is_device_pointer(dfts);
@@ -778,6 +903,29 @@ class Plan
     return true;
   }
 
+  // single-sample synthesis (sdft.h:635): the result comes back by value, so a device-resident
+  // row needs a one-element device buffer (owned by the plan, allocated on the plan's device)
+  DevBuf<TD> d_one;
+  bool isdft_one(const fdx* dft, TD* y)
+  {
+    if (nbins == 0) { *y = (TD)0; return true; }           // the reference returns (td)(0 * 2)
+    if (!bind()) return false;
+    const bool saved = async; async = false;
+    bool ok;
+    if (on_device(dft))
+    {
+      ok = d_one.reserve(1) && inverse_device(1, dft, nbins, nullptr, d_one.p, 1);
+      if (ok) { const hipError_t e = hipMemcpyAsync(y, d_one.p, sizeof(TD), hipMemcpyDeviceToHost, stream); ok = (e == hipSuccess); if (!ok) set_error("hipMemcpyAsync", hipGetErrorString(e)); }
+      ok = ok && synchronize();
+    }
+    else
+    {
+      ok = isdft_n(1, dft, y);
+    }
+    async = saved;
+    return ok;
+  }
+
   // checkpoint / resume: install a state previously read with get_state (any plan of the same
   // dftsize, window, latency, types and channel count -- also on another GPU)
   bool set_state(const fdx* acc, const fdx* fid, const TD* hist, size_t cur)
@@ -787,8 +935,8 @@ class Plan
     if (nbins)
     {
       if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }
-      if (acc) SDFT_TRY(hipMemcpy(d_acc.p, acc, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
-      if (fid) SDFT_TRY(hipMemcpy(d_fid.p, fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
+      if (acc) SDFT_TRY(hipMemcpy(acc_p(), acc, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
+      if (fid) SDFT_TRY(hipMemcpy(fid_p(), fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
       if (hist) SDFT_TRY(hipMemcpy(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD), hipMemcpyHostToDevice));
     }
     cursor = cur;
@@ -802,8 +950,8 @@ class Plan
     SDFT_TRY(hipStreamSynchronize(stream));
     if (nbins)
     {
-      if (acc) SDFT_TRY(hipMemcpy(acc, d_acc.p, channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
-      if (fid) SDFT_TRY(hipMemcpy(fid, d_fid.p, channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
+      if (acc) SDFT_TRY(hipMemcpy(acc, acc_p(), channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
+      if (fid) SDFT_TRY(hipMemcpy(fid, fid_p(), channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
       if (hist) SDFT_TRY(hipMemcpy(hist, d_hist[hist_cur].p, channels * 2 * nbins * sizeof(TD), hipMemcpyDeviceToHost));
     }
     if (cur) *cur = cursor;

@@ -53,6 +53,7 @@ class SDFT:
             if self.api.lib.sdft_hip_set_device(int(device)) != 0:
                 self.api.check()
         self._p = self.api.alloc_batch(self.dftsize, self.window, self.latency, self.channels)
+        self.device = int(self.api.get_option(self._p, b"device")) if self._p else -1
         if not self._p:
             err = self.api.last_error()
             self.api.lib.sdft_hip_clear_error()
@@ -132,6 +133,19 @@ class SDFT:
             raise SdftHipError("sdft_hip_set_state failed")
 
     # ---- analysis / synthesis ---------------------------------------------------------------
+    def _check_tensor(self, t, what, dtype, shape=None):
+        """Device tensors are handed to the library as raw pointers: they must live on the plan's GPU,
+        be dense, and have exactly the element type and shape the C-ABI expects."""
+        torch = _torch()
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError(f"{what} must be a CUDA tensor on the plan's device cuda:{self.device}, got {t.device}")
+        if not t.is_contiguous():
+            raise ValueError(f"{what} must be contiguous")
+        if t.dtype != getattr(torch, np.dtype(dtype).name):
+            raise ValueError(f"{what} must have dtype {np.dtype(dtype).name}, got {t.dtype}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+
     def _shape_x(self, shape):
         if self.channels == 1 and len(shape) == 1:
             return shape[0]
@@ -147,11 +161,11 @@ class SDFT:
         if _is_tensor(x):
             torch = _torch()
             n = self._shape_x(x.shape)
-            assert x.is_cuda and x.is_contiguous() and x.dtype == getattr(torch, np.dtype(self.td).name)
+            self._check_tensor(x, "samples", self.td)
             shape = (n, self.dftsize) if x.dim() == 1 else (self.channels, n, self.dftsize)
             if out is None:
                 out = torch.empty(shape, dtype=getattr(torch, np.dtype(self.fdx).name), device=x.device)
-            assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == shape
+            self._check_tensor(out, "out", self.fdx, shape)
             self.api.sdft_n(self._p, n, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()))
         else:
             x = np.ascontiguousarray(x, dtype=self.td)
@@ -172,14 +186,16 @@ class SDFT:
         yshape = (self.channels, n) if batched else (n,)
         if _is_tensor(dfts):
             torch = _torch()
-            assert dfts.is_cuda and dfts.is_contiguous() and dfts.dtype == getattr(torch, np.dtype(self.fdx).name)
+            self._check_tensor(dfts, "dfts", self.fdx)
             if out is None:
                 out = torch.empty(yshape, dtype=getattr(torch, np.dtype(self.td).name), device=dfts.device)
+            self._check_tensor(out, "out", self.td, yshape)
             self.api.isdft_n(self._p, n, C.c_void_p(dfts.data_ptr()), C.c_void_p(out.data_ptr()))
         else:
             dfts = np.ascontiguousarray(dfts, dtype=self.fdx)
             if out is None:
                 out = np.empty(yshape, dtype=self.td)
+            assert out.flags.c_contiguous and out.shape == yshape and out.dtype == self.td
             self.api.isdft_n(self._p, n, C.c_void_p(dfts.ctypes.data), C.c_void_p(out.ctypes.data))
         self.api.check()
         return out

@@ -156,8 +156,14 @@ def test_reset_mid_stream_and_profile_counters():
         p.reset(); ref.reset()
         assert np.array_equal(p.sdft(x[:777]), ref.sdft(x[:777]))
         prof = p.profile()
-        assert prof["forward"][1] == 2 and prof["delta"][1] == 2 and prof["forward"][0] > 0
+        assert p.get_option("last_kernel") == 3            # single-chunk calls: the fused hop kernel, no delta launch
+        assert prof["forward"][1] == 2 and prof["delta"][1] == 0 and prof["forward"][0] > 0
         assert p.profile()["forward"][1] == 0              # counters reset after reading
+    with make(m, "hann", 1.0, "f32f64", profile=1, chunk=1 << 30, hop_kernel=0) as p:
+        ref.reset()
+        assert np.array_equal(p.sdft(x[:777]), ref.sdft(x[:777]))
+        prof = p.profile()
+        assert prof["forward"][1] == 1 and prof["delta"][1] == 1
 
 
 @pytest.mark.parametrize("combo", ["f32f64", "f32f32"])
@@ -187,3 +193,111 @@ def test_checkpoint_and_resume_on_a_fresh_plan(combo):
     with make(m, "hann", 1.0, combo, ch, chunk=1 << 30) as b:
         b.set_state(*snap)
         assert np.array_equal(b.sdft(xb[:, 400:]), cont)
+
+
+@pytest.mark.parametrize("combo", O.COMBOS)
+@pytest.mark.parametrize("window", ["hann", "blackman", "boxcar"])
+def test_hop_kernel_matches_reference_and_legacy_single_chunk_path(combo, window):
+    """Single-chunk calls run one fused launch (differences formed in the kernel, double-buffered
+    state, tiles spread over the CUs).  Hop sizes below and above 2N, across the roll-over, batched
+    channels; the three-launch path it replaces (option hop_kernel = 0) must agree bit for bit."""
+    td, fd, fdx = O.combo_types(combo)
+    for m, hops in ((1000, (100, 100, 100, 1, 7, 1999, 2000, 2001, 100)), (70, (100, 300, 139, 140, 141, 5)), (3, (1, 2, 3, 11))):
+        total = sum(hops)
+        ch = 2
+        xb = np.stack([noise(total, seed=11 + c, dtype=td) for c in range(ch)])
+        refs = [O.best(m, window, 0.5, combo) for _ in range(ch)]
+        with make(m, window, 0.5, combo, ch, chunk=1 << 30) as p, make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_kernel=0) as q:
+            i = 0
+            for h in hops:
+                seg = np.ascontiguousarray(xb[:, i:i + h])
+                got = p.sdft(seg)
+                old = q.sdft(seg)
+                assert p.get_option("last_kernel") == 3 and q.get_option("last_kernel") != 3
+                for c in range(ch):
+                    want = refs[c].sdft(seg[c])
+                    assert np.array_equal(got[c], want), (combo, window, m, h, c)
+                assert np.array_equal(got, old)
+                i += h
+            for a, b in zip(p.state(), q.state()):
+                assert np.array_equal(a, b)
+            acc, fid, hist, cur = p.state()
+            for c in range(ch):
+                racc, rfid, rhist, rcur = refs[c].state()
+                assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid) and np.array_equal(hist[c], rhist)
+
+
+def test_short_inverse_row_kernel_is_bit_identical():
+    """Calls with few rows use one wave per row (inverse_row_kernel); same summation order as the reference."""
+    for combo in O.COMBOS:
+        td, fd, fdx = O.combo_types(combo)
+        for m, n, lat in ((1000, 100, 1.0), (1000, 100, 0.5), (1024, 7, 1.0), (2500, 33, 0.25), (5, 9, 1.0), (4097, 3, 1.0)):
+            x = noise(n + 2 * m, seed=m, dtype=td)
+            ref = O.best(m, "hann", lat, combo)
+            d = ref.sdft(x)[-n:]
+            want = ref.isdft(d)
+            with make(m, "hann", lat, combo) as p:
+                assert np.array_equal(p.isdft(np.ascontiguousarray(d)), want), (combo, m, n, lat)
+                p.set_option("inverse_rows", 4)
+                assert np.array_equal(p.isdft(np.ascontiguousarray(d)), want)
+
+
+def test_row_pointer_variants_reject_batched_plans():
+    """sdft_sdft_nd / sdft_isdft_nd are defined for one stream (one pointer per sample, reference
+    sdft.h:622-628); a batched plan must fail loudly instead of reading past the table."""
+    from sdft_amd.capi import Api
+    api = Api("f32f64")
+    plan = api.alloc_batch(16, 1, 1.0, 3)
+    x = noise(3 * 8, seed=2)
+    rows = np.zeros((8, 16), dtype=np.complex128)
+    table = np.array([rows[i].ctypes.data for i in range(8)], dtype=np.uint64)
+    api.sdft_nd(plan, 8, C.c_void_p(x.ctypes.data), C.c_void_p(table.ctypes.data))
+    err = api.last_error()
+    assert err and "single-channel" in err
+    api.lib.sdft_hip_clear_error()
+    assert not rows.any()                                   # outputs untouched
+    y = np.full(8, 3.0, dtype=np.float32)
+    api.isdft_nd(plan, 8, C.c_void_p(table.ctypes.data), C.c_void_p(y.ctypes.data))
+    assert api.last_error() and (y == 3.0).all()
+    api.lib.sdft_hip_clear_error()
+    api.free(plan)
+
+
+def test_single_sample_entry_points_under_pointers_option():
+    """sdft_sdft takes its sample by value: it is host data even when option pointers = 1 declares
+    every buffer device memory; sdft_isdft returns by value from a device-resident row."""
+    import torch
+    from sdft_amd.capi import Api
+    api = Api("f32f64")
+    m = 48
+    x = noise(40, seed=9)
+    ref = O.best(m, "hamming", 1.0, "f32f64")
+    want = ref.sdft(x)
+    wy = ref.isdft(want)
+    plan = api.alloc_custom(m, 2, 1.0)
+    api.set_option(plan, b"pointers", 1)
+    row = torch.zeros(m, dtype=torch.complex128, device="cuda")
+    for i in range(40):
+        api.sdft(plan, float(x[i]), C.c_void_p(row.data_ptr()))
+        api.check()
+        assert np.array_equal(row.cpu().numpy(), want[i])
+        assert api.isdft(plan, C.c_void_p(row.data_ptr())) == wy[i]
+    api.free(plan)
+
+
+def test_more_channels_than_a_grid_dimension():
+    """70000 independent channels in one plan (grid.y / grid.z stop at 65535: channels ride on grid.x)."""
+    import torch
+    ch, m, n = 70000, 8, 24
+    rng = np.random.default_rng(3)
+    xb = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+    for opts in ({}, {"chunk": 8}, {"chunk": 8, "carry": 1}, {"hop_kernel": 0}):
+        with make(m, "hann", 1.0, "f32f64", ch, **opts) as p:
+            d = p.sdft(torch.from_numpy(xb).cuda())
+            y = p.isdft(d).cpu().numpy()
+            dh = d[[0, 1, 65535, 65536, ch - 1]].cpu().numpy()
+        for i, c in enumerate((0, 1, 65535, 65536, ch - 1)):
+            r = O.best(m, "hann", 1.0, "f32f64")
+            w = r.sdft(xb[c])
+            assert np.abs(dh[i] - w).max() <= 1e-12 * np.abs(w).max(), (opts, c)
+            assert np.abs(y[c] - r.isdft(w)).max() <= 1e-6

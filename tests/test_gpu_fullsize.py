@@ -105,3 +105,30 @@ def test_config3_float_roundtrip_n262144():
         got_firsts = d[::hop].cpu().numpy()
     assert np.array_equal(got_firsts, np.stack(firsts))
     assert np.abs(y - yref).max() <= 1e-4 * np.abs(yref).max()
+
+
+def test_config5_one_gpu_share_64ch_m1024():
+    """configs[4], one GPU's share: 64 channels x n=48000 x m=1024, Hann, FD double (50.3 GB) through
+    one batched plan.  Channels 0, 31, 63 row by row against the oracle's digests, synthesis and the
+    round trip on every channel."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    ch, n, m = 64, 48000, 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < ch * n * m * 16 * 1.05:
+        pytest.skip("not enough free HBM for the 50.3 GB matrix")
+    xb = sweep_batch(ch, n)
+    with SDFT(m, "hann", 1.0, "f32f64", channels=ch) as p:
+        d = p.sdft(torch.from_numpy(xb).cuda())
+        assert p.get_option("last_chunks") > 1
+        y = p.isdft(d).cpu().numpy()
+        for c in (0, 31, 63):
+            dig, yref = O.Port(m, "hann", 1.0, "f32f64").digest(xb[c])
+            got = row_digest(d[c])
+            scale = np.abs(dig).max(axis=0)
+            assert (np.abs(got - dig).max(axis=0) <= 1e-9 * scale).all(), c
+            assert np.abs(y[c] - yref).max() <= 1e-6 * np.abs(yref).max()
+    lag = m - 1
+    for c in range(ch):
+        err = y[c, 2 * m + lag:].astype(np.float64) - xb[c, 2 * m:-lag]
+        assert np.sqrt(np.mean(err ** 2)) < 0.05, c
