@@ -33,6 +33,35 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "chainlen":
+        for ch in (192, 256, 384, 768):
+            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chunk=ch)
+        for ch in (192, 384):
+            for sg in (4, 8):
+                run(262144, 4096, "blackman", "f32f32", chain=2, segments=sg, chunk=ch)
+        run(262144, 4096, "blackman", "f32f32", chain=2, chunk=384, chain_producers=4)
+        run(262144, 4096, "blackman", "f32f32", chain=2, chunk=384, chain_producers=3)
+    if which == "chaindbg":
+        for dbg in (0, 1, 2, 3, 5, 9, 13):
+            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_debug=dbg)
+        for P in (2, 4, 6):
+            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_producers=P)
+        for L in (8, 16):
+            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_block=L)
+        run(262144, 1024, "hann", "f32f32", chain=0, segments=1)
+        run(262144, 4096, "blackman", "f32f32", chain=2, segments=1)
+        run(262144, 4096, "blackman", "f32f32", chain=0, segments=1)
+    if which == "exact":
+        for chain in (0, 2):
+            run(262144, 4096, "blackman", "f32f32", chain=chain)
+            run(262144, 4096, "blackman", "f32f32", chain=chain, segments=8)
+        run(262144, 4096, "blackman", "f32f32", chain=2, segments=16)
+        for chain in (0, 2):
+            run(48000, 2048, "hann", "f32f32", channels=64, chain=chain)
+            run(1000000, 1024, carry=1, chain=chain)
+        run(1000000, 1024)
+        run(262144, 1024, "hann", "f32f32", chain=0)
+        run(262144, 1024, "hann", "f32f32", chain=2)
     if which == "v2":
         for rep in range(2):
             run(1000000, 1024)

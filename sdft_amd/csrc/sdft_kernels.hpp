@@ -722,6 +722,331 @@ __global__ __launch_bounds__(kWave) void carry_exact_kernel(CarryArgs<FD> a)
 }
 
 // ------------------------------------------------------------------------------------------
+// K1a'' (exact carry, chain form)  the same job as carry_exact_kernel -- the reference's rounding
+// sequence of acc at every chunk start -- with the serial part cut down to what the reference's
+// summation order really dictates: one dependent addition per sample,
+//     acc(t+1) = fl( acc(t) + fl( fid(c_t) * delta_t ) )                       (sdft.h:583 / :572).
+// Everything else is off the chain, because fid does not depend on the data: it is re-seeded to 1
+// at every roll-over (sdft.h:573) and multiplied by a constant otherwise (:584), so fid_k(c) is a
+// pure function of (bin, cursor) with period 2N.  fid_seed_kernel tabulates it once per plan at
+// every L-th cursor; any block of L consecutive steps can then be regenerated from its seed, and
+// blocks of different time are independent.
+//
+// One workgroup = 32 bins (re / im in a lane pair, as in carry_exact_kernel) = 1 consumer wave +
+// P producer waves.  Time runs in rounds of R = P*L steps: in period i producer p regenerates the
+// rotations of block p of round i from the seed table (3 VALU per step: f*T1, partner(f)*T2 by
+// DPP, add), forms the products fid*delta (1 VALU) and parks them in LDS; the consumer adds the
+// products of round i-1 to acc in time order (1 dependent VALU per step + LDS reads) and writes
+// acc to `carry` whenever a chunk starts.  One barrier per period; two product buffers.
+// The forward kernels seed their own fid from the same table (ForwardArgs::fseed).
+// Bit-identical to the serial pass: same operands, same operations, same order on the chain.
+// ------------------------------------------------------------------------------------------
+template <typename FD> struct ChainArgs
+{
+  const FD* delta;            // [channels][n]
+  const cx<FD>* tw;           // [N]
+  const cx<FD>* fseed;        // [2N/L][N]  fid at cursor b*L
+  cx<FD>* carry;              // [channels][chunks][N]
+  const cx<FD>* acc_state;    // [channels][N]  acc at the first step of this launch
+  cx<FD>* acc_next;           // [channels][N]  acc after the last step (nullptr when the launch ends the call)
+  size_t n;
+  unsigned nbins, chunks, chunk_len, cursor0;
+  unsigned chunk0, launch_chunks;
+  unsigned L, P;              // block length (divides 2N, multiple of 8), producer waves
+  unsigned debug;             // measurement aid: bit 0 = consumer idles, bit 1 = producers idle (results are garbage)
+  unsigned long long* stats;  // measurement aid: per wave of workgroup 0, cycles in {work, tail waits, barrier} (or nullptr)
+};
+
+template <typename FD>
+__global__ __launch_bounds__(kWave) void fid_seed_kernel(const cx<FD>* __restrict__ tw, cx<FD>* __restrict__ fseed,
+                                                         unsigned nbins, unsigned L)
+{
+  const unsigned k = blockIdx.x * kWave + threadIdx.x;
+  if (k >= nbins) return;
+  const cx<FD> t = tw[k];
+  cx<FD> f = cmake<FD>((FD)1, (FD)0);                      // fid at cursor 0 (sdft.h:446, :573)
+  const unsigned span = 2u * nbins;
+  for (unsigned c = 0; c < span; ++c)
+  {
+    if (c % L == 0) fseed[(size_t)(c / L) * nbins + k] = f;
+    f = cmul(f, t);                                        // sdft.h:584
+  }
+}
+
+constexpr int kChainSlack = 32;                            // steps of a lane's row the consumer's read-ahead may touch past a round
+
+// LDS image of one product buffer: [lane][S], S = R + slack + one 16-byte vector, so that a lane's
+// products of consecutive steps are contiguous (16-byte reads and writes move 4 (FD float) or 2
+// (FD double) steps each) and S/(16 bytes) is odd: both the 8-lane groups of ds_write_b128 and the
+// 16-lane groups of ds_read_b128 then fall on distinct banks.
+template <typename FD> SDFT_HD constexpr int chain_row(int R) { return R + kChainSlack + 16 / (int)sizeof(FD); }
+
+// one producer step on a lane pair: p = fid*delta (fid before its rotation), then fid *= tw.
+// FD float is spelled out in ISA: left to itself the compiler packs the two multiplies of the
+// rotation into v_pk_mul_f32 / v_pk_add_f32 plus moves (2.5x the issue slots of four plain VALU
+// ops on a lone wave).  The DPP read of f needs two wait states after the v_add that wrote it:
+// the two plain multiplies at the head of the next step are those.
+SDFT_D float chain_step(float& f, float dl, float T1, float T2)
+{
+  float p, m1, m2;
+  asm volatile(
+      "v_mul_f32_e32 %[p], %[dl], %[f]\n\t"
+      "v_mul_f32_e32 %[m1], %[f], %[t1]\n\t"
+      "v_mul_f32_dpp %[m2], %[f], %[t2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_e32 %[f], %[m1], %[m2]"
+      : [p] "=&v"(p), [m1] "=&v"(m1), [m2] "=&v"(m2), [f] "+v"(f)
+      : [dl] "s"(dl), [t1] "v"(T1), [t2] "v"(T2));
+  return p;
+}
+SDFT_D double chain_step(double& f, double dl, double T1, double T2)
+{
+  const double p = f * dl;
+  const double g = partner(f);
+  const double m1 = f * T1;
+  const double m2 = g * T2;
+  f = m1 + m2;                                             // sdft.h:584
+  return p;
+}
+
+template <typename FD, int L>
+__global__ __launch_bounds__(kWave * 8) void carry_chain_kernel(ChainArgs<FD> a)
+{
+  constexpr int NV = 16 / (int)sizeof(FD);                 // steps per 16-byte LDS access
+  typedef FD vec_t __attribute__((ext_vector_type(NV)));
+  extern __shared__ __align__(16) unsigned char chain_lds_raw[];
+  FD* prod = reinterpret_cast<FD*>(chain_lds_raw);         // [2][64][S]
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int comp = lane & 1;
+  const unsigned bin_blocks = (a.nbins + kWave / 2 - 1) / (kWave / 2);
+  const unsigned bin = (blockIdx.x % bin_blocks) * (kWave / 2) + (lane >> 1);
+  const size_t ch = blockIdx.x / bin_blocks;
+  const bool valid = bin < a.nbins;
+  const unsigned kk = valid ? bin : a.nbins - 1;
+  const unsigned span = 2u * a.nbins;
+  const int P = (int)a.P, R = L * P, S = chain_row<FD>(R);
+
+  // this launch: steps [tb, te) of the call; chunk starts inside it are dumped, the call's very last
+  // chunk is run by the forward kernel itself (its start is the final dump)
+  const unsigned jend = a.chunk0 + a.launch_chunks;
+  const bool ends_call = (jend == a.chunks);
+  const long long tb = (long long)a.chunk0 * a.chunk_len;
+  const long long total = (long long)(a.launch_chunks - (ends_call ? 1 : 0)) * a.chunk_len;
+  // absolute step index u = cursor0 + t; blocks are aligned to multiples of L in u
+  const long long u0 = (long long)a.cursor0 + tb, u1 = u0 + total;
+  const long long q0 = u0 / L;
+  const long long nblocks = (u1 + L - 1) / L - q0;
+  const long long rounds = (nblocks + P - 1) / P;
+
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);            // the chain: wins every issue arbitration
+  else __builtin_amdgcn_s_setprio(2);
+
+  // consumer state
+  FD acc = (FD)0;
+  long long done = 0, next_dump = 0;
+  unsigned j = a.chunk0;
+  FD* carry = reinterpret_cast<FD*>(a.carry);
+  if (wave == 0)
+  {
+    const cx<FD> acc0 = a.acc_state[ch * a.nbins + kk];
+    acc = comp ? acc0.im : acc0.re;
+  }
+  // producer constants
+  const cx<FD> tw = a.tw[kk];
+  const FD T1 = tw.re;
+  const FD T2 = comp ? tw.im : -tw.im;
+  const SDFT_CONSTANT FD* dch = as_uniform(a.delta + ch * a.n);
+
+  auto dump = [&]()
+  {
+    if (valid) carry[(((ch * a.chunks + j) * a.nbins) + bin) * 2 + comp] = acc;
+    ++j; next_dump += a.chunk_len;
+  };
+
+  // producers: seed and differences of the wave's first block
+  cx<FD> sd_next = cmake<FD>((FD)1, (FD)0);
+  FD dl_next[L];
+#pragma unroll
+  for (int s = 0; s < L; ++s) dl_next[s] = (FD)0;
+  // cursor of the block whose seed is in sd_next, kept in 32 bits and advanced by R per period (a
+  // 64-bit modulo per block costs a lone wave more than the block's arithmetic)
+  unsigned cb_next = 0;
+  if (wave > 0 && (long long)(wave - 1) < nblocks)
+  {
+    const long long ub = (q0 + (wave - 1)) * L;
+    cb_next = (unsigned)(ub % span);
+    sd_next = a.fseed[(size_t)(cb_next / L) * a.nbins + kk];
+    if (ub >= u0 && ub + L <= u1)
+    {
+#pragma unroll
+      for (int s = 0; s < L; ++s) dl_next[s] = dch[ub - (long long)a.cursor0 + s];
+    }
+  }
+
+  unsigned long long st_work = 0, st_tail = 0, st_bar = 0;
+  for (long long period = 0; period <= rounds; ++period)
+  {
+    const unsigned long long stamp0 = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long stamp1 = stamp0;
+    if (wave == 0)
+    {
+      if (period > 0 && !(a.debug & 1u))
+      {
+        const long long r = period - 1;
+        const FD* pb = prod + ((size_t)(r & 1) * kWave + lane) * S;      // this lane's row of the round
+        const long long ub = (q0 + r * P) * L;             // first step of the round
+        int s0 = (int)((u0 > ub ? u0 : ub) - ub);
+        const int s1 = (int)((u1 < ub + R ? u1 : ub + R) - ub);
+        while (s0 < s1)
+        {
+          if (done == next_dump) dump();
+          int run = s1 - s0;
+          if ((long long)run > next_dump - done) run = (int)(next_dump - done);
+          const FD* ps = pb + s0;
+          int i = 0;
+          for (; i < run && ((s0 + i) % NV) != 0; ++i) acc = acc + ps[i];     // up to the next 16-byte boundary
+          if (run - i >= 32)
+          {
+            // Four register sets in rotation: the LDS reads of a group of eight products are issued
+            // three groups (24 dependent additions) before the chain consumes them, so the chain never
+            // waits for LDS.  The scheduling fences keep the compiler from re-sorting reads behind
+            // additions.  (The read-ahead at the end of a run touches steps past it: inside the lane's
+            // row, never used.)
+            vec_t v0[8 / NV], v1[8 / NV], v2[8 / NV], v3[8 / NV];
+            auto fetch = [&](vec_t (&v)[8 / NV], int at)
+            {
+#pragma unroll
+              for (int q = 0; q < 8 / NV; ++q) v[q] = *reinterpret_cast<const vec_t*>(ps + at + q * NV);
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            auto chain8 = [&](const vec_t (&v)[8 / NV])
+            {
+#pragma unroll
+              for (int q = 0; q < 8 / NV; ++q)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) acc = acc + v[q][e];               // the chain (sdft.h:583)
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            fetch(v0, i); fetch(v1, i + 8); fetch(v2, i + 16);
+            for (; i + 32 <= run; i += 32)
+            {
+              fetch(v3, i + 24); chain8(v0);
+              fetch(v0, i + 32); chain8(v1);
+              fetch(v1, i + 40); chain8(v2);
+              fetch(v2, i + 48); chain8(v3);
+            }
+          }
+          if (run - i >= 8)
+          {
+            // what is left of the run (< 32 steps): every read first, then the additions
+            vec_t v[3][8 / NV];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int q = 0; q < 8 / NV; ++q) v[g][q] = *reinterpret_cast<const vec_t*>(ps + i + g * 8 + q * NV);
+            const int groups = (run - i) / 8;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+              if (g < groups)
+              {
+#pragma unroll
+                for (int q = 0; q < 8 / NV; ++q)
+#pragma unroll
+                  for (int e = 0; e < NV; ++e) acc = acc + v[g][q][e];
+              }
+            i += groups * 8;
+          }
+          if (run - i > 0)
+          {
+            const int rem = run - i;                         // < 8
+            vec_t v[8 / NV];
+#pragma unroll
+            for (int q = 0; q < 8 / NV; ++q) v[q] = *reinterpret_cast<const vec_t*>(ps + i + q * NV);
+#pragma unroll
+            for (int q = 0; q < 8 / NV; ++q)
+#pragma unroll
+              for (int e = 0; e < NV; ++e)
+                if (q * NV + e < rem) acc = acc + v[q][e];
+          }
+          s0 += run; done += run;
+        }
+      }
+    }
+    else if (period < rounds && !(a.debug & 2u))
+    {
+      const long long q = q0 + period * P + (wave - 1);      // this wave's block
+      if (q - q0 < nblocks)
+      {
+        const long long ub = q * L;
+        FD* pw = prod + ((size_t)(period & 1) * kWave + lane) * S + (size_t)(wave - 1) * L;
+        const long long t_first = ub - (long long)a.cursor0;   // sample index of the block's first step
+        const long long qn = q + P, ubn = qn * L;              // the block after this one (next period)
+        const bool more = (qn - q0 < nblocks);
+        const bool full_n = more && ubn >= u0 && ubn + L <= u1;
+
+        FD f = comp ? sd_next.im : sd_next.re;
+        // all products of the block first, then the LDS stores: a store issued in the middle would make
+        // the next multiplies wait until it has read its source registers (measured: 35 cycles per
+        // ds_write_b32, 140 per ds_write_b128 between dependent VALU work)
+        vec_t pv[L / NV];
+        if (ub >= u0 && ub + L <= u1)
+        {
+#pragma unroll
+          for (int s = 0; s < L; ++s) pv[s / NV][s % NV] = chain_step(f, dl_next[s], T1, T2);
+        }
+        else
+        {
+#pragma unroll
+          for (int s = 0; s < L; ++s)                        // ragged first / last block of the launch
+          {
+            const long long u = ub + s;
+            const FD dl = (u >= u0 && u < u1) ? dch[t_first + s] : (FD)0;
+            pv[s / NV][s % NV] = chain_step(f, dl, T1, T2);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
+        if (a.stats) stamp1 = __builtin_amdgcn_s_memtime();
+        // seed and differences of the next block: requested now, they arrive while this wave waits at the
+        // barrier for the consumer -- a producer never waits for memory at the top of a round
+        unsigned cbn = cb_next + (unsigned)R;
+        while (cbn >= span) cbn -= span;
+        cb_next = cbn;
+        if (more) sd_next = a.fseed[(size_t)(cbn / L) * a.nbins + kk];
+        if (full_n)
+        {
+#pragma unroll
+          for (int s = 0; s < L; ++s) dl_next[s] = dch[ubn - (long long)a.cursor0 + s];
+        }
+      }
+    }
+    if (a.stats)
+    {
+      if (wave == 0) stamp1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+      st_work += stamp1 - stamp0; st_tail += stamp2 - stamp1; st_bar += stamp3 - stamp2;
+    }
+    else
+    __syncthreads();
+  }
+  if (a.stats && blockIdx.x == 0 && lane == 0)
+  {
+    a.stats[wave * 4 + 0] = st_work; a.stats[wave * 4 + 1] = st_tail; a.stats[wave * 4 + 2] = st_bar; a.stats[wave * 4 + 3] = (unsigned long long)rounds;
+  }
+  if (wave == 0)
+  {
+    if (done == next_dump && j < jend) dump();              // the chunk that starts where this launch ends
+    if (!ends_call && valid)
+      reinterpret_cast<FD*>(a.acc_next)[((ch * a.nbins) + bin) * 2 + comp] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // spectral window (sdft.h:350-402); e[] holds X[k-2] .. X[k+2] at index 0..4
 // ------------------------------------------------------------------------------------------
 template <typename FD, int WIN> SDFT_D cx<FD> window_tap(cx<FD> m2, cx<FD> m1, cx<FD> c0, cx<FD> p1, cx<FD> p2, FD w)
@@ -783,6 +1108,15 @@ template <typename FD, int WIN> SDFT_D cx<FD> window_tap_fused(cx<FD> m2, cx<FD>
 // ------------------------------------------------------------------------------------------
 // K1  forward: recurrence + mirror + window + coalesced store of the (n, N) matrix
 // ------------------------------------------------------------------------------------------
+// fid of bin kk at cursor c, rebuilt from the plan's seed table exactly as the reference would have
+// rotated it since the last roll-over (sdft.h:584, unfused)
+template <typename FD> SDFT_D cx<FD> fid_from_table(const cx<FD>* fseed, unsigned L, unsigned nbins, long kk, unsigned c, cx<FD> tw)
+{
+  cx<FD> f = fseed[(size_t)(c / L) * nbins + kk];
+  for (unsigned i = c % L; i > 0; --i) f = cmul(f, tw);
+  return f;
+}
+
 template <typename FD> struct ForwardArgs
 {
   const FD* delta;            // [channels][n]
@@ -790,6 +1124,8 @@ template <typename FD> struct ForwardArgs
   const cx<FD>* wtab;         // [2N]   (used when seed == nullptr)
   const cx<FD>* carry;        // [channels][chunks][N]
   const cx<FD>* seed;         // [channels][chunks][N] or nullptr
+  const cx<FD>* fseed;        // [2N/fseed_L][N] fid at every fseed_L-th cursor (exact mode, chain form) or nullptr
+  unsigned fseed_L;
   cx<FD>* out;                // rows: out + ch*out_stride + t*N
   size_t out_stride;
   cx<FD>* const* out_rows;    // optional row-pointer table [channels*n] (sdft_sdft_nd); nullptr = dense
@@ -854,7 +1190,8 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
     keep[b] = owner && k >= 0 && k < nbins;
     s[b].tw = a.tw[kk];
     s[b].acc = a.carry[cbase + kk];
-    s[b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+    s[b].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, kk, c, s[b].tw)
+             : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
   }
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
@@ -1289,7 +1626,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       keep[q][b] = k < nbins;
       s[q][b].tw = a.tw[kk];
       s[q][b].acc = a.carry[cbase + kk];
-      s[q][b].fid = a.seed ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+      s[q][b].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, kk, c, s[q][b].tw)
+                  : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
 
       pub[q][b] = &edgeL[0][0][0][0];
       pubflip[q][b] = false; has_role[q][b] = false;

@@ -167,6 +167,19 @@ class Plan
   long opt_segments = 0;         // 0 = heuristic
   long last_segments = 1;
 
+  // exact carries, chain form: fid at every fseed_L-th cursor of the canonical rotation sequence
+  // (built on first use); fid_canonical = the stream's fid state is on that sequence (false after
+  // a chunk-parallel call seeded fid from the closed-form table, or after set_state, until the
+  // next roll-over puts it back to exactly 1)
+  DevBuf<fdx> d_fseed;
+  unsigned fseed_L = 0, chain_P = 0;
+  bool fid_canonical = true;
+  bool chain_attr[3] = {false, false, false};
+  long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
+  long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  DevBuf<unsigned long long> d_chain_stats;
+  long last_chain = 0;
+
   // workspace
   DevBuf<FD> d_delta;
   DevBuf<fdx> d_carry, d_seed;
@@ -218,7 +231,7 @@ class Plan
     d_tw.release(); d_syn.release(); d_wtab.release();
     for (int q = 0; q < 2; ++q) { d_accs[q].release(); d_fids[q].release(); }
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
-    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release();
+    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release(); d_fseed.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -239,7 +252,7 @@ class Plan
   // sdft.h:517-529
   bool reset()
   {
-    cursor = 0; hist_cur = 0; st_cur = 0;
+    cursor = 0; hist_cur = 0; st_cur = 0; fid_canonical = true;
     if (nbins == 0) return true;
     if (!bind()) return false;
     const size_t nb = nbins, span = 2 * nbins;
@@ -377,6 +390,54 @@ class Plan
     return false;
   }
 
+  // ---- exact carries, chain form: block length / producer count / seed table -----------------
+  // L divides 2N (so the roll-over ends a block and every block starts on a tabulated cursor) and is
+  // a multiple of 8; a round of P*L steps keeps two product buffers of 64 lanes within 64 KiB of LDS.
+  static constexpr size_t kChainLdsBytes = (size_t)128 * 1024;      // of the CU's 160 KiB
+  static size_t chain_lds(unsigned L, unsigned P) { return (size_t)2 * kWave * chain_row<FD>((int)(L * P)) * sizeof(FD); }
+  bool chain_geometry(unsigned& L, unsigned& P) const
+  {
+    const size_t span = 2 * nbins;
+    L = 0;
+    if (opt_chain_L > 0)
+    {
+      const bool built = opt_chain_L == 8 || opt_chain_L == 16 || (opt_chain_L == 32 && sizeof(FD) == 4);
+      if (built && span % (size_t)opt_chain_L == 0) L = (unsigned)opt_chain_L;
+    }
+    else
+      for (unsigned cand : {32u, 16u, 8u})                 // 32-step blocks are built for 4-byte products only
+        if ((cand < 32 || sizeof(FD) == 4) && span % cand == 0) { L = cand; break; }
+    if (!L) return false;
+    unsigned pmax = 7;
+    while (pmax > 1 && chain_lds(L, pmax) > kChainLdsBytes) --pmax;
+    P = opt_chain_P > 0 ? std::min((unsigned)opt_chain_P, pmax) : std::min(6u, pmax);
+    P = std::max(1u, P);
+    return ((span / L) * nbins * sizeof(fdx)) <= ((size_t)256 << 20);      // seed table budget
+  }
+  template <int L> bool launch_chain(const ChainArgs<FD>& cc, unsigned blocks, hipStream_t on)
+  {
+    bool& raised = chain_attr[L == 8 ? 0 : (L == 16 ? 1 : 2)];   // dynamic LDS beyond 64 KiB has to be asked for once (per device)
+    if (!raised)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&carry_chain_kernel<FD, L>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes));
+      raised = true;
+    }
+    hipLaunchKernelGGL((carry_chain_kernel<FD, L>), dim3(blocks), dim3(kWave * (cc.P + 1)), chain_lds(cc.L, cc.P), on, cc);
+    SDFT_TRY(hipGetLastError());
+    return true;
+  }
+  bool ensure_fseed(unsigned L)
+  {
+    if (fseed_L == L && d_fseed.p) return true;
+    if (!d_fseed.reserve((2 * nbins / L) * nbins)) return false;
+    hipLaunchKernelGGL((fid_seed_kernel<FD>), dim3((unsigned)((nbins + kWave - 1) / kWave)), dim3(kWave), 0, stream,
+                       (const fdx*)d_tw.p, d_fseed.p, (unsigned)nbins, L);
+    SDFT_TRY(hipGetLastError());
+    fseed_L = L;
+    return true;
+  }
+
   // ---- forward on device-resident buffers ------------------------------------------------
   // x: [channels] x n with stride x_stride; out: rows at out + ch*out_stride + t*N, or the row
   // pointer table `rows` (device array of channels*n device pointers)
@@ -398,7 +459,15 @@ class Plan
     if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
     const bool exact = (carry_mode == CARRY_EXACT);
-    if ((exact || chunks == 1) && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
+    // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
+    // leave most SIMDs idle; the plain serial pass when bins x channels already fill the chip
+    unsigned cL = 0, cP = 0;
+    const size_t serial_waves = ((nb + kWave / 2 - 1) / (kWave / 2)) * channels;
+    const bool use_chain = exact && chunks > 1 && opt_chain && fid_canonical && chain_geometry(cL, cP) &&
+                           (opt_chain >= 2 || serial_waves <= 1024);
+    last_chain = use_chain;
+    if ((exact || chunks == 1) && !use_chain && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
+    if (use_chain && !ensure_fseed(cL)) return false;
 
     // K0: differences + delay line
     if (!prof_begin(ST_DELTA)) return false;
@@ -460,7 +529,25 @@ class Plan
     else if (exact)
     {
       const unsigned eblocks = (unsigned)((nb + kWave / 2 - 1) / (kWave / 2));
-      for (long sg = 0; sg < segments; ++sg)
+      for (long sg = 0; sg < segments && use_chain; ++sg)
+      {
+        const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
+        ChainArgs<FD> cc;
+        cc.delta = d_delta.p; cc.tw = d_tw.p; cc.fseed = d_fseed.p; cc.carry = d_carry.p;
+        cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
+        cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
+        cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.debug = (unsigned)opt_chain_debug & 3u; cc.stats = nullptr;
+        if (opt_chain_debug & 16) { if (!d_chain_stats.reserve(64)) return false; cc.stats = d_chain_stats.p; }
+        const unsigned cblocks = eblocks * (unsigned)channels;
+        bool ok = true;
+        if (cL == 32) { if constexpr (sizeof(FD) == 4) ok = launch_chain<32>(cc, cblocks, carry_stream); }
+        else if (cL == 16) ok = launch_chain<16>(cc, cblocks, carry_stream);
+        else ok = launch_chain<8>(cc, cblocks, carry_stream);
+        if (!ok) return false;
+        if (segments > 1) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
+      }
+      for (long sg = 0; sg < segments && !use_chain; ++sg)
       {
         const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
         CarryArgs<FD> cs = ca;
@@ -509,7 +596,8 @@ class Plan
     if (!prof_begin(ST_FORWARD)) return false;
     ForwardArgs<FD> fa;
     fa.delta = d_delta.p; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = d_carry.p;
-    fa.seed = use_seed ? d_seed.p : nullptr;
+    fa.seed = (use_seed && !use_chain) ? d_seed.p : nullptr;
+    fa.fseed = use_chain ? d_fseed.p : nullptr; fa.fseed_L = use_chain ? cL : 0;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = rows;
     fa.acc_state = acc_p(); fa.fid_state = fid_p(); fa.n = n;
     fa.total_waves = (unsigned long long)channels * (unsigned long long)chunks * (unsigned long long)ntiles;
@@ -536,6 +624,10 @@ class Plan
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
 
+    // fid stays on the canonical rotation sequence unless this call seeded chunks from the closed-form
+    // table; a call that crosses the roll-over with serial fid arithmetic puts it back
+    if (!use_seed) fid_canonical = false;
+    else if (cursor + n >= span) fid_canonical = true;
     cursor = (cursor + n) % span;
     return true;
   }
@@ -581,6 +673,7 @@ class Plan
     if (!prof_end(ST_FORWARD)) return false;
     hist_cur ^= 1; st_cur ^= 1;
     last_kernel = 3;
+    if (cursor + n >= span) fid_canonical = true;
     cursor = (cursor + n) % span;
     return true;
   }
@@ -684,6 +777,13 @@ class Plan
 
   // synchronous calls: short ones poll the stream (a sleeping hipStreamSynchronize wakes up late --
   // tens of microseconds, more than a whole 100-sample hop takes on the device)
+  bool chain_stats(unsigned long long* out32)
+  {
+    if (!d_chain_stats.p) return false;
+    SDFT_TRY(hipMemcpy(out32, d_chain_stats.p, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return true;
+  }
+
   bool finish(size_t work = 0)
   {
     if (async) return true;
@@ -936,7 +1036,7 @@ class Plan
     {
       if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }
       if (acc) SDFT_TRY(hipMemcpy(acc_p(), acc, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
-      if (fid) SDFT_TRY(hipMemcpy(fid_p(), fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
+      if (fid) { SDFT_TRY(hipMemcpy(fid_p(), fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice)); fid_canonical = false; }
       if (hist) SDFT_TRY(hipMemcpy(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD), hipMemcpyHostToDevice));
     }
     cursor = cur;

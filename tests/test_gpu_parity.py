@@ -98,6 +98,74 @@ def test_fast_carry_double_chunked(window):
 
 
 @pytest.mark.parametrize("combo", ["f32f32", "f64f32", "f32f64"])
+@pytest.mark.parametrize("m,block", [(256, 32), (1000, 16), (100, 8), (7, 0)])
+def test_exact_carry_chain_form_bit_exact(combo, m, block):
+    """Exact carries in chain form: fid regenerated from the plan's seed table by producer waves, one
+    dependent addition per sample on the consumer wave.  Must reproduce the reference bit for bit for
+    every block length the geometry allows (2N divisible by 32 / 16 / 8; otherwise the serial pass
+    runs), for calls that start mid-period and mid-block, across roll-overs, in time segments, for
+    batched channels -- and agree with the serial pass it replaces."""
+    td, fd, fdx = O.combo_types(combo)
+    ch = 2
+    lens = (3 * m + 5, 4 * m + 8 * 37, 555)                      # cursors at arbitrary offsets
+    xb = np.stack([noise(sum(lens), seed=3 + c, dtype=td) for c in range(ch)])
+    for segments in (1, 3):
+        refs = [O.best(m, "blackman", 1.0, combo) for _ in range(ch)]
+        with make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=2, segments=segments) as p, \
+             make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=0, segments=segments) as q:
+            i = 0
+            for n in lens:
+                seg = np.ascontiguousarray(xb[:, i:i + n])
+                got, old = p.sdft(seg), q.sdft(seg)
+                assert p.get_option("last_chain") == (1 if block else 0) and q.get_option("last_chain") == 0
+                assert p.get_option("last_chunks") > 2 or m == 7
+                for c in range(ch):
+                    want = refs[c].sdft(seg[c])
+                    assert np.array_equal(got[c], want), (combo, m, n, c, rel_err(got[c], want))
+                assert np.array_equal(got, old)
+                i += n
+            acc, fid, hist, cur = p.state()
+            for c in range(ch):
+                racc, rfid, rhist, rcur = refs[c].state()
+                assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid)
+    # forced block lengths / producer counts
+    if block:
+        x = noise(5 * m + 77, seed=9, dtype=td)
+        want = O.best(m, "hann", 1.0, combo).sdft(x)
+        for L, P in ((8, 1), (8, 7), (block if block < 32 or combo.endswith("f32") else 16, 2)):
+            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, chain_producers=P) as p:
+                got = p.sdft(x)
+                assert p.get_option("last_chain") == 1
+                assert np.array_equal(got, want), (combo, m, L, P)
+
+
+def test_exact_chain_falls_back_while_fid_is_off_the_canonical_sequence():
+    """The seed table holds the rotation sequence that starts from 1 at the roll-over.  After a
+    chunk-parallel call (fid seeded from the closed-form table) or set_state the stream's fid is not
+    on it: the serial pass runs until the next roll-over puts fid back to exactly 1."""
+    m = 128
+    x = noise(40 * m, seed=2)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    with make(m, "hann", 1.0, "f32f64", chunk=64, carry=0) as p:
+        a = p.sdft(x[:700])                                      # fast carries: fid leaves the sequence
+        ref.sdft(x[:700])
+        assert p.get_option("last_chain") == 0
+        p.set_option("carry", 1); p.set_option("chain", 2)
+        b = p.sdft(x[700:700 + 5 * m])                           # serial pass (and crosses the roll-over)
+        assert p.get_option("last_chain") == 0
+        c = p.sdft(x[700 + 5 * m:])                              # back on the sequence: chain form
+        assert p.get_option("last_chain") == 1
+        wb = ref.sdft(x[700:700 + 5 * m]); wc = ref.sdft(x[700 + 5 * m:])
+        assert rel_err(b, wb) <= 1e-11 and rel_err(c, wc) <= 1e-11
+    # from a clean start the same sequence of exact calls is bit-identical throughout
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    with make(m, "hann", 1.0, "f32f64", chunk=64, carry=1, chain=2) as p:
+        for lo, hi in ((0, 700), (700, 700 + 5 * m), (700 + 5 * m, 40 * m)):
+            assert np.array_equal(p.sdft(x[lo:hi]), ref.sdft(x[lo:hi]))
+            assert p.get_option("last_chain") == 1
+
+
+@pytest.mark.parametrize("combo", ["f32f32", "f64f32", "f32f64"])
 @pytest.mark.parametrize("window", ["hann", "blackman"])
 @pytest.mark.parametrize("segments", [1, 3, 7, 30])
 def test_exact_carry_chunked_bit_exact(combo, window, segments):
