@@ -44,6 +44,26 @@ sdft_t*     sdft_hip_alloc_batch(const sdft_size_t dftsize, const sdft_window_t 
                                  const sdft_double_t latency, const sdft_size_t channels) SDFT_HIP_SYMBOL(alloc_batch);
 sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
 
+/* ---- fused analysis -> spectral operation -> synthesis -------------------------------------------
+   The reference's contract materialises the (nsamples, dftsize) matrix between sdft_sdft_n and
+   sdft_isdft_n (README.md:42-47 of the reference); a host that only wants the processed signal back
+   pays two HBM streams of 16 KiB per sample for it.  sdft_hip_process_n computes
+       out[t] = sdft_isdft( op( sdft_sdft(samples[t]) ) )
+   with the same arithmetic and the same plan state update as the two calls, but the rows stay
+   inside the workgroup that produced them (calls of 512 samples or more, dftsize up to 1024 double /
+   2048 float bins; other shapes run analysis + synthesis back to back through a bounded workspace).
+     sdft_hip_op_identity  params = NULL
+     sdft_hip_op_gain      params = sdft_fd_t gains[dftsize]  (host or device): X'[k] = X[k] * gains[k]
+     sdft_hip_op_shift     params = const long* (host): X'[k] = X[k - *params], zero outside the spectrum
+   dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
+   (identity / gain only).  Batched plans: samples / out [channels][nsamples].
+   Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the analysis path's
+   bar; bit-identical where the analysis is (FD float, option carry = 1, calls shorter than 512
+   samples) -- see option "fused_exact".  Returns 0, or -1 with sdft_hip_last_error() set. */
+enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2 };
+int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t* samples, sdft_td_t* const out,
+                       const int op, const void* params, sdft_fdx_t* dfts) SDFT_HIP_SYMBOL(process_n);
+
 /* ---- streams ---------------------------------------------------------------------------------
    Every plan owns a HIP stream.  Calls with host pointers always return with the output
    complete.  Calls with device pointers do too unless option "async" is 1; then they return after
@@ -67,12 +87,22 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "interior"      bin-owning lanes per wave of the independent-tile kernel
    "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
    "target_waves"  waves the time chunking aims for
-   "pointers"      0 = classify every pointer (hipPointerGetAttributes), 1 = all device, 2 = all host
+   "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis)
+   "spin"          1 (default) = synchronous short calls poll the stream instead of sleeping on it
+   "chain"         exact carries: 1 (default) = chain form (seed table + producer/consumer waves) while
+                       bins x channels leave SIMDs idle, 0 = always the serial pass, 2 = chain form whenever
+                       the geometry allows ("chain_block" 8|16|32 steps, "chain_producers" 1..7)
+   "fused_exact"   sdft_hip_process_n sums bins in the reference's order (1), by a wave-parallel tree (0),
+                       or (-1, default) in order exactly when the analysis itself is bit-exact
+   "pointers"      0 = classify each distinct pointer once (cached), 1 = all device, 2 = all host,
+                       3 = query on every call
    "stage_bytes"   segment size of the host-pointer staging path
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
-   "last_chunk_len", "last_kernel", "last_segments", "last_fused", "cursor", "device". */
+   "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
+   "last_chain", "last_fused_exact", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
+   "cursor", "device". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);
 

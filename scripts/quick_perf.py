@@ -31,7 +31,40 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
           f"fwd {f:.3f} ms ({byts/f/1e9:.0f} GB/s, {channels*n/f/1e3:.1f} Msamp/s) carry {c:.3f} delta {d:.3f} inv {i:.3f} ms ({byts/i/1e9:.0f} GB/s) wall/iter {wall*1e3:.3f} ms", flush=True)
     p.close(); del out
 
+def run_process(n, m, window="hann", combo="f32f64", channels=1, reps=5, op="identity", **opts):
+    td = np.float32 if combo[:3] == "f32" else np.float64
+    x = torch.from_numpy(np.stack([sine_sweep(n, dtype=td)] * channels) if channels > 1 else sine_sweep(n, dtype=td)).cuda()
+    p = SDFT(m, window, 1.0, combo, channels)
+    for k, v in opts.items(): p.set_option(k, v)
+    p.set_option("async", 1)
+    gain = torch.linspace(0.5, 1.5, m, dtype=torch.float64 if combo[3:] == "f64" else torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    for _ in range(2): p.process(x, op, gain=gain, shift=3, out=y)
+    p.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): p.process(x, op, gain=gain, shift=3, out=y)
+    p.synchronize(); wall = (time.perf_counter() - t0) / reps
+    print(f"process n={n} m={m} {window} {combo} ch={channels} op={op} opts={opts} path={p.get_option('last_process_path')} "
+          f"exact_order={p.get_option('last_fused_exact')} chunks={p.get_option('last_chunks')}: {wall*1e3:.3f} ms  {channels*n/wall/1e6:.1f} Msamples/s", flush=True)
+    p.close()
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "process":
+        for fe in (0, 1):
+            run_process(1000000, 1024, fused_exact=fe)
+        run_process(1000000, 1024, op="gain")
+        run_process(1000000, 1024, op="shift")
+        run_process(1000000, 1024, "blackman", fused_exact=0)
+        run_process(48000, 1024, channels=64, fused_exact=0)
+        run_process(48000, 1024, channels=64, fused_exact=1)
+        run_process(48000, 1024)
+        run_process(262144, 1024, "hann", "f32f32")
+        run_process(262144, 2048, "blackman", "f32f32")
+        run_process(262144, 2048, "blackman", "f32f32", fused_exact=0)
+        run_process(48000, 2048, "hann", "f32f32", channels=64)
+        run_process(1000000, 1024, carry=1)
+        run(1000000, 1024)
+        sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
     if which == "chainlen":
         for ch in (192, 256, 384, 768):

@@ -78,12 +78,34 @@ def hops(m=1000, hop=100, total=20000, combo="f32f64", **opts):
     p.close()
 
 
+def hop_process(m=1000, hop=100, total=20000, combo="f32f64"):
+    import ctypes as C
+    td = np.float32 if combo[:3] == "f32" else np.float64
+    x = torch.from_numpy(sine_sweep(total, dtype=td)).cuda()
+    y = torch.empty(total, dtype=x.dtype, device="cuda")
+    p = SDFT(m, "hann", 1.0, combo)
+    xs, ys, isz = x.data_ptr(), y.data_ptr(), x.element_size()
+    for mode in ("sync", "async"):
+        p.set_option("async", 1 if mode == "async" else 0)
+        for rep in range(2):
+            p.synchronize()
+            t0 = time.perf_counter()
+            for i in range(0, total, hop):
+                p.api.process_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ys + i * isz), 0, None, None)
+            p.synchronize()
+            w = (time.perf_counter() - t0) / (total // hop)
+        print(f"hop={hop} m={m} {combo} {mode:5s} sdft_hip_process_n (one call per hop): {w*1e6:7.1f} us/hop", flush=True)
+    p.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "ns"):
         north_star()
         north_star(pointers=1)
     if which in ("all", "hop"):
+        hop_process()
+        hop_process(combo="f32f32")
         hops()
         hops(pointers=1)
         hops(combo="f32f32")

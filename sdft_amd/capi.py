@@ -14,6 +14,7 @@ from . import build as _build
 COMBOS = _build.COMBOS
 WINDOWS = {"boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3}   # sdft.h:127-133 of the reference
 STAGES = ("delta", "carry", "forward", "inverse")
+OPS = {"identity": 0, "gain": 1, "shift": 2}                      # enum sdft_hip_op (sdft_hip.h)
 
 # every typed entry point exported per (td, fd) combination:  name -> (restype, argtypes)
 _TD = {"f32": C.c_float, "f64": C.c_double}
@@ -50,6 +51,7 @@ def typed_signatures(combo: str):
         "get_state": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
         "set_state": (C.c_int, [vp, vp, vp, vp, sz]),
         "plan_tables": (C.c_int, [sz, C.c_double, vp, vp, vp, vp]),
+        "process_n": (C.c_int, [vp, sz, vp, vp, C.c_int, vp, vp]),
     }
 
 

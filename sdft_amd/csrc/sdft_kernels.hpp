@@ -205,6 +205,13 @@ __global__ __launch_bounds__(kBlock) void delta_kernel(const TD* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 // shared pieces of the recurrence
 // ------------------------------------------------------------------------------------------
+template <typename FD> SDFT_D FD wave_sum_f(FD v)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 template <typename FD> struct BinState { cx<FD> acc, fid, tw; };
 
 // normal step (sdft.h:583-585) -- returns the demodulated bin
@@ -1549,6 +1556,54 @@ __global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD
 }
 
 // ------------------------------------------------------------------------------------------
+// Spectral operation between analysis and synthesis (fused path): what a host of the
+// reference does to the (n, N) matrix between sdft_sdft_n and sdft_isdft_n (README.md:42-47),
+// applied per bin while the row is in flight.
+//   identity            X'_k = X_k
+//   gain  g[N] (real)   X'_k = X_k * g_k          (complex times real: both parts scaled)
+//   shift s (bins)      X'_k = X_{k-s}, zero where k-s falls outside [0, N)
+// synth_term returns what sdft_isdft adds for SOURCE bin k (sdft.h:643 / :650).  The reference adds
+// output bins in ascending order; a shift keeps source bins in the same order, and the bins it
+// empties add +-0, which never changes a running sum that started at +0.
+// ------------------------------------------------------------------------------------------
+enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2 };
+template <typename FD> struct SpectralOp
+{
+  int kind;
+  const FD* gain;             // [N], OP_GAIN
+  long shift;                 // OP_SHIFT
+};
+
+template <typename FD, bool LAT1, bool OPS>
+SDFT_D FD synth_term(cx<FD> v, unsigned k, const SpectralOp<FD>& op, const cx<FD>* syn, unsigned nbins)
+{
+  long ko = (long)k;                                       // output bin whose sign / twiddle applies
+  if constexpr (OPS)                                       // (plain sdft_isdft_n instantiates without the checks)
+  {
+    if (op.kind == OP_GAIN) v = cscale(v, op.gain[k < nbins ? k : 0]);
+    else if (op.kind == OP_SHIFT)
+    {
+      ko += op.shift;
+      if (ko < 0 || ko >= (long)nbins) return (FD)0;
+    }
+  }
+  if constexpr (LAT1) return v.re * ((ko & 1) ? (FD)(-1) : (FD)(+1));               // sdft.h:643
+  else { const cx<FD> sy = syn[ko < (long)nbins ? ko : 0]; return v.re * sy.re - v.im * sy.im; }   // re of :650
+}
+
+// Fused analysis -> operation -> synthesis (forward_rows_kernel with SYN != 0): the rows never leave the
+// workgroup unless `store` asks for a copy of the processed spectrum.
+template <typename TD, typename FD> struct FuseArgs
+{
+  TD* y;                      // [channels][n]
+  size_t y_stride;
+  const cx<FD>* syn;          // [N]
+  FD sweight;
+  SpectralOp<FD> op;
+  int store;                  // also write the processed rows to ForwardArgs::out
+};
+
+// ------------------------------------------------------------------------------------------
 // K1 (row-group form)  forward for rows that fit one workgroup: 8 <= N <= 1024*BPL*S bins.
 //
 // One workgroup = all bins of one (channel, time chunk): wave w owns bins [64*BPL*w, 64*BPL*(w+1)),
@@ -1580,9 +1635,15 @@ constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockste
 // lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
 constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
 
-template <typename FD, int BPL, int WIN, bool FUSED, int S>
-__global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a)
+// SYN (fused analysis -> operation -> synthesis; S == 1 only): 0 = rows are stored (the
+// plain forward kernel), 1 = the row is turned into the terms sdft_isdft adds (sdft.h:641-651), parked in
+// LDS and summed over bins by a wave-parallel tree, 2 = summed strictly in ascending bin order like the
+// reference (lane u of wave 0 walks sample u's terms: bit-identical to sdft_sdft_n + sdft_isdft_n, at the
+// price of N dependent additions per lockstep group).  The matrix is written only if FuseArgs::store.
+template <typename FD, int BPL, int WIN, bool FUSED, int S, int SYN = 0, bool LAT1 = true, typename TD = float>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a, FuseArgs<TD, FD> fz)
 {
+  static_assert(SYN == 0 || S == 1, "the fused synthesis path is built for single-slot rows");
   constexpr int H = win_halo<WIN>::value;
   constexpr int G = (kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2;   // keeps registers roughly constant
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
@@ -1590,6 +1651,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // edgeL[buf][u][v][i] = bin (first bin of virtual wave v) - 1 - i, edgeR[..][i] = (last bin) + 1 + i
   __shared__ cx<FD> edgeL[2][G][VW][HS];
   __shared__ cx<FD> edgeR[2][G][VW][HS];
+  // SYN: terms[u][bin], one padded row per sample of the lockstep group (dynamic LDS; the pad of one
+  // 16-byte vector puts the G rows on different banks for the ordered walk)
+  extern __shared__ __align__(16) unsigned char rows_dyn_lds[];
+  FD* terms = reinterpret_cast<FD*>(rows_dyn_lds);
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1685,6 +1750,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     __builtin_assume(off_elems[q] < (1u << 20));          // < 2048*BPL bins: the byte offset fits 32 bits
   }
 
+  // SYN: padded row length of the terms image (bins of all waves + one 16-byte vector)
+  const unsigned term_bins = (unsigned)(nv * kWave * BPL);
+  const unsigned term_stride = term_bins + 16u / (unsigned)sizeof(FD);
+
   auto publish = [&](const cx<FD> (&x)[S][BPL], int buf, int u)
   {
     if constexpr (H >= 1)
@@ -1749,6 +1818,23 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         if constexpr (FUSED) y[b] = window_tap_fused<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
         else y[b] = window_tap<FD, WIN>(e[b], e[b + 1], e[b + 2], e[b + 3], e[b + 4], w);
       }
+      if constexpr (SYN != 0)
+      {
+        // spectral operation, then the scalar sdft_isdft adds for this bin, parked at terms[u][bin]
+        // (bins past N-1 in a partial last wave park +0: the walk adds whole padded rows)
+#pragma unroll
+        for (int b = 0; b < BPL; ++b)
+        {
+          const unsigned k = off_elems[q] + (unsigned)b;
+          if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], fz.op.gain[keep[q][b] ? k : 0]);
+          SpectralOp<FD> shift_only; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
+          shift_only.gain = nullptr; shift_only.shift = fz.op.shift;
+          const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
+          terms[(size_t)u * term_stride + k] = keep[q][b] ? term : (FD)0;
+        }
+      }
+      if (SYN == 0 || fz.store)
+      {
       // destination = wave-uniform row base (scalar registers) + lane-constant 32-bit offset: the
       // row advance is scalar arithmetic, no per-lane 64-bit pointer bump
       cx<FD>* p = row + off_elems[q];
@@ -1777,6 +1863,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           V vv; vv.x = y[0].re; vv.y = y[0].im;
           store_vec(reinterpret_cast<V*>(p), vv);
         }
+      }
       }
     }
     row += a.nbins;
@@ -1842,6 +1929,48 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       for (int u = 0; u < G; ++u)
         if (u < m) finish(xs[u], buf, u);
     }
+    if constexpr (SYN != 0)
+    {
+      // phase C: sum over bins -> one output sample per row of the group.  (The next group's phase B
+      // cannot overwrite the terms before every wave has passed the next barrier, which this wave
+      // reaches only after its part of phase C.)
+      __syncthreads();
+      TD* yo = fz.y + ch * fz.y_stride + t;
+      if constexpr (SYN == 2)
+      {
+        // the reference's order (sdft.h:641-651): lane u of wave 0 adds sample u's terms bin by bin
+        if (wave == 0 && lane < m)
+        {
+          typedef FD tvec __attribute__((ext_vector_type(16 / sizeof(FD))));
+          constexpr int NV = 16 / (int)sizeof(FD);
+          const FD* tr = terms + (size_t)lane * term_stride;
+          FD sum = (FD)0;
+          for (unsigned k0 = 0; k0 < term_bins; k0 += 8 * NV)       // term_bins is a multiple of 64
+          {
+            tvec tv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const tvec*>(tr + k0 + i * NV);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int e = 0; e < NV; ++e) sum += tv[i][e];
+          }
+          yo[lane] = (TD)(sum * fz.sweight);                                   // sdft.h:654-656
+        }
+      }
+      else
+      {
+        // wave-parallel: wave u sums sample u (lane-strided partial sums, shuffle reduction)
+        for (int u = wave; u < m; u += nwaves)
+        {
+          const FD* tr = terms + (size_t)u * term_stride;
+          FD part = (FD)0;
+          for (unsigned k = lane; k < term_bins; k += kWave) part += tr[k];
+          const FD sum = wave_sum_f(part);
+          if (lane == 0) yo[u] = (TD)(sum * fz.sweight);
+        }
+      }
+    }
     t += m;
     buf ^= 1;
   }
@@ -1874,6 +2003,19 @@ template <typename FD> SDFT_D FD wave_sum(FD v)
   return v;
 }
 
+// rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain)
+{
+  const size_t per = rows * nbins, total = per * channels;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
+  {
+    const size_t ch = i / per, r = i - ch * per;
+    cx<FD>* p = mat + ch * stride + r;
+    *p = cscale(*p, gain[r % nbins]);
+  }
+}
+
 template <typename TD, typename FD> struct InverseArgs
 {
   const cx<FD>* in;           // rows: in + ch*in_stride + t*N
@@ -1885,17 +2027,16 @@ template <typename TD, typename FD> struct InverseArgs
   size_t n;
   unsigned nbins, channels;
   FD sweight;
+  SpectralOp<FD> op;          // applied to every bin on the way in (identity for sdft_isdft_n)
 };
 
-template <typename TD, typename FD, bool LAT1>
+template <typename TD, typename FD, bool LAT1, bool OPS = false>
 __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
   const size_t rows = (size_t)a.channels * a.n;
-  const FD sign = (lane & 1) ? (FD)(-1) : (FD)(+1);          // k % 2 == lane % 2 (sdft.h:643)
-
   for (size_t r = (size_t)blockIdx.x * kWavesPerBlock + wib; r < rows; r += nwaves)
   {
     const size_t ch = r / a.n, t = r - ch * a.n;
@@ -1904,14 +2045,7 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 #pragma unroll 4
     for (unsigned k = lane; k < a.nbins; k += kWave)
     {
-      const cx<FD> v = row[k];
-      if constexpr (LAT1)
-        part += v.re * sign;
-      else
-      {
-        const cx<FD> s = a.syn[k];
-        part += v.re * s.re - v.im * s.im;                    // real part of sdft.h:650
-      }
+      part += synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins);
     }
     const FD sum = wave_sum(part);
     if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);
@@ -1929,7 +2063,7 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 // double calls, 16 for FD float and medium calls, 4 with an 8-deep ring for short calls (a hop of
 // 100 rows has too few rows to hide latency with row-parallelism alone).
 // ------------------------------------------------------------------------------------------
-template <typename TD, typename FD, bool LAT1, int RW, int DEPTH>
+template <typename TD, typename FD, bool LAT1, int RW, int DEPTH, bool OPS = false>
 __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, FD> a)
 {
   constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load (1 for f64, 2 for f32)
@@ -1988,10 +2122,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
         for (int b = 0; b < BPL; ++b)
         {
           const unsigned k = k0 + (unsigned)seg * BPL + b;
-          FD term;
-          if constexpr (LAT1) term = v[i][b].re * ((k & 1u) ? (FD)(-1) : (FD)(+1));            // sdft.h:643
-          else { const cx<FD> s = a.syn[k < a.nbins ? k : 0]; term = v[i][b].re * s.re - v[i][b].im * s.im; }   // re of :650
-          tile[wib][RPI * i + sub][seg * BPL + b] = term;
+          tile[wib][RPI * i + sub][seg * BPL + b] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins);
         }
     };
 
@@ -2041,7 +2172,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
 // order (every lane holds the same sum: no exec masking, same cost as one lane).  What remains is
 // the chain of N dependent additions the reference's summation order dictates.
 // ------------------------------------------------------------------------------------------
-template <typename TD, typename FD, bool LAT1>
+template <typename TD, typename FD, bool LAT1, bool OPS = false>
 __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> a)
 {
   constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load
@@ -2089,10 +2220,7 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
       {
         const unsigned kl = (unsigned)(i * kWave + lane) * BPL + b;
         const unsigned k = k0 + kl;
-        FD term;
-        if constexpr (LAT1) term = v[i][b].re * ((k & 1u) ? (FD)(-1) : (FD)(+1));              // sdft.h:643
-        else { const cx<FD> sy = a.syn[k < a.nbins ? k : 0]; term = v[i][b].re * sy.re - v[i][b].im * sy.im; }   // re of :650
-        terms[kl] = term;
+        terms[kl] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins);
       }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -143,6 +143,9 @@ class Plan
   long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
   long opt_hop_kernel = 1;       // single-chunk calls: fused delta + forward launch (forward_hop_kernel)
+  long opt_fused_exact = -1;     // fused analysis->synthesis: bins summed in the reference's order (1), by a tree (0),
+                                 // or (-1) in order exactly when the analysis itself is bit-exact (exact carries)
+  long last_fused_exact = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
@@ -232,6 +235,7 @@ class Plan
     for (int q = 0; q < 2; ++q) { d_accs[q].release(); d_fids[q].release(); }
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
     d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release(); d_fseed.release();
+    d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -441,7 +445,8 @@ class Plan
   // ---- forward on device-resident buffers ------------------------------------------------
   // x: [channels] x n with stride x_stride; out: rows at out + ch*out_stride + t*N, or the row
   // pointer table `rows` (device array of channels*n device pointers)
-  bool forward_device(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows)
+  bool forward_device(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows,
+                      const FuseArgs<TD, FD>* fuse = nullptr)
   {
     if (n == 0 || nbins == 0) return true;
     const size_t nb = nbins, span = 2 * nbins;
@@ -454,7 +459,7 @@ class Plan
     last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
     last_segments = 1; last_fused = 0;
-    if (chunks == 1 && opt_hop_kernel && nbins >= 2) return forward_hop(n, x, x_stride, out, out_stride, rows);
+    if (chunks == 1 && opt_hop_kernel && nbins >= 2 && !fuse) return forward_hop(n, x, x_stride, out, out_stride, rows);
 
     if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
@@ -617,7 +622,15 @@ class Plan
       // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
       const bool fused = use_rows && opt_fused && sizeof(FD) == 8 && !use_seed;
       last_fused = fused;
-      if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused);
+      if (fuse)
+      {
+        // rows never leave the workgroup: synthesis in the same launch (caller checked fuse_ok())
+        const bool exact_order = opt_fused_exact < 0 ? use_seed : opt_fused_exact != 0;
+        last_fused_exact = exact_order;
+        if (!launch_syn(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused && !exact_order, exact_order))
+          return false;
+      }
+      else if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused);
       else launch_forward(fa, (unsigned)blocks);
       SDFT_TRY(hipGetLastError());
     }
@@ -682,12 +695,13 @@ class Plan
   {
     constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
     const dim3 g(blocks), b(threads);
+    const FuseArgs<TD, FD> none{};
     switch (window)
     {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S>), g, b, 0, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S>), g, b, 0, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S>), g, b, 0, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S>), g, b, 0, stream, fa); break;
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
+      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
     }
   }
   template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
@@ -702,6 +716,51 @@ class Plan
   {
     if constexpr (sizeof(FD) == 8) { if (fused) { launch_forward_rows_t<true>(fa, blocks, threads); return; } }
     launch_forward_rows_t<false>(fa, blocks, threads);
+  }
+
+  // fused analysis -> operation -> synthesis: the same kernel with SYN = 1 (tree sum over bins) or 2
+  // (the reference's ascending order); the terms image lives in dynamic LDS
+  static constexpr int kSynGroup = (kRowGroup / (sizeof(fdx) == 16 ? 1 : 2)) >= 2 ? kRowGroup / (sizeof(fdx) == 16 ? 1 : 2) : 2;
+  size_t syn_lds() const
+  {
+    const size_t padded = (size_t)row_waves() * kWave * bins_per_lane();
+    return (size_t)kSynGroup * (padded + 16 / sizeof(FD)) * sizeof(FD);
+  }
+  template <int WIN, bool FUSED, int SYN, bool LAT1>
+  bool launch_syn_w(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
+  {
+    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
+    auto kern = forward_rows_kernel<FD, BPL, WIN, FUSED, 1, SYN, LAT1, TD>;
+    static thread_local int raised_on = -1;                  // dynamic LDS beyond 64 KiB has to be asked for (per device)
+    if (raised_on != device)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      raised_on = device;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(), stream, fa, fz);
+    SDFT_TRY(hipGetLastError());
+    return true;
+  }
+  template <bool FUSED, int SYN, bool LAT1>
+  bool launch_syn_t(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
+  {
+    switch (window)
+    {
+      case WIN_HANN:     return launch_syn_w<WIN_HANN, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
+      case WIN_HAMMING:  return launch_syn_w<WIN_HAMMING, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
+      case WIN_BLACKMAN: return launch_syn_w<WIN_BLACKMAN, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
+      default:           return launch_syn_w<WIN_BOXCAR, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
+    }
+  }
+  bool launch_syn(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads, bool fused, bool exact_order)
+  {
+    const bool lat1 = (latency == 1);                                           // :639 exact compare
+    if (exact_order) return lat1 ? launch_syn_t<false, 2, true>(fa, fz, blocks, threads) : launch_syn_t<false, 2, false>(fa, fz, blocks, threads);
+    if constexpr (sizeof(FD) == 8)
+    {
+      if (fused) return lat1 ? launch_syn_t<true, 1, true>(fa, fz, blocks, threads) : launch_syn_t<true, 1, false>(fa, fz, blocks, threads);
+    }
+    return lat1 ? launch_syn_t<false, 1, true>(fa, fz, blocks, threads) : launch_syn_t<false, 1, false>(fa, fz, blocks, threads);
   }
 
   template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
@@ -722,7 +781,39 @@ class Plan
   }
 
   // ---- inverse on device-resident buffers --------------------------------------------------
-  bool inverse_device(size_t n, const fdx* in, size_t in_stride, const fdx* const* rows, TD* y, size_t y_stride)
+  template <bool LAT1, bool OPS> void launch_inverse(const InverseArgs<TD, FD>& ia, size_t total_rows)
+  {
+    size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    blocks = std::min(blocks, (size_t)256 * 8 * 4);
+    if (!opt_exact_inverse)
+    {
+      hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+      return;
+    }
+    // the reference's summation order.  Measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16:
+    // 2.82, 64: 3.6 (130 VGPRs); float bins and medium calls do best with 16; short calls (a hop of
+    // 100 rows): one wave per row, the rows spread over the CUs
+    long rw = opt_inverse_rows > 0 ? opt_inverse_rows
+                                   : (total_rows <= 1024 ? 1 : total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
+    if (OPS && rw != 1) rw = 16;                                                 // one streaming instantiation with the operation built in
+    size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
+    eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
+    const dim3 g((unsigned)eb), b(kBlock);
+    if (rw == 1 && total_rows <= 0x7fffffffull)
+      hipLaunchKernelGGL((inverse_row_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
+    else if (rw >= 32)
+    {
+      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 32, 1, false>), g, b, 0, stream, ia);
+    }
+    else if (rw >= 16) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
+    else
+    {
+      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>), g, b, 0, stream, ia);
+    }
+  }
+
+  bool inverse_device(size_t n, const fdx* in, size_t in_stride, const fdx* const* rows, TD* y, size_t y_stride,
+                      const SpectralOp<FD>* op = nullptr)
   {
     if (n == 0) return true;
     SDFT_TRY(hipSetDevice(device));
@@ -730,46 +821,13 @@ class Plan
     InverseArgs<TD, FD> ia;
     ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
     ia.n = n; ia.nbins = (unsigned)nbins; ia.channels = (unsigned)channels; ia.sweight = tab.sweight;
+    ia.op.kind = OP_IDENTITY; ia.op.gain = nullptr; ia.op.shift = 0;
+    const bool ops = op && op->kind != OP_IDENTITY;
+    if (ops) ia.op = *op;
     const size_t total_rows = channels * n;
-    size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    blocks = std::min(blocks, (size_t)256 * 8 * 4);
-    if (opt_exact_inverse)
-    {
-      // the reference's summation order: a wave per 64 rows (16 rows when the call is short)
-      const bool lat1 = (latency == 1);                                         // :639 exact compare
-      // measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16: 2.82, 64: 3.6 (130 VGPRs);
-      // float bins and short calls do best with 16
-      // short calls (a hop of 100 rows): one wave per row, the rows spread over the CUs
-      const long rw = opt_inverse_rows > 0 ? opt_inverse_rows
-                                           : (total_rows <= 1024 ? 1 : total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
-      size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
-      eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
-      const dim3 g((unsigned)eb), b(kBlock);
-      if (rw == 1 && grid_fits(total_rows))
-      {
-        if (lat1) hipLaunchKernelGGL((inverse_row_kernel<TD, FD, true>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_row_kernel<TD, FD, false>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
-      }
-      else if (rw >= 32)
-      {
-        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 32, 1>), g, b, 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 32, 1>), g, b, 0, stream, ia);
-      }
-      else if (rw >= 16)
-      {
-        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 16, 1>), g, b, 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 16, 1>), g, b, 0, stream, ia);
-      }
-      else
-      {
-        if (lat1) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, true, 4, 8>), g, b, 0, stream, ia);
-        else hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, false, 4, 8>), g, b, 0, stream, ia);
-      }
-    }
-    else if (latency == 1)                                                      // :639 exact compare
-      hipLaunchKernelGGL((inverse_kernel<TD, FD, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
-    else
-      hipLaunchKernelGGL((inverse_kernel<TD, FD, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+    const bool lat1 = (latency == 1);                                            // :639 exact compare
+    if (ops) { if (lat1) launch_inverse<true, true>(ia, total_rows); else launch_inverse<false, true>(ia, total_rows); }
+    else     { if (lat1) launch_inverse<true, false>(ia, total_rows); else launch_inverse<false, false>(ia, total_rows); }
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_INVERSE)) return false;
     return true;
@@ -1024,6 +1082,103 @@ class Plan
     }
     async = saved;
     return ok;
+  }
+
+  // ---- fused analysis -> spectral operation -> synthesis ------------------------
+  // y[t] = sdft_isdft( op( sdft_sdft(x[t]) ) ) with the reference's arithmetic, without the (n, N)
+  // matrix ever reaching HBM unless the caller asks for a copy of the processed spectrum in `dfts`.
+  // params: OP_GAIN -> FD gains[N] (host or device memory), OP_SHIFT -> const long* (host).
+  DevBuf<FD> d_gain;
+  DevBuf<TD> d_stage_y;
+  bool fuse_ok() const { return rows_kernel_ok(false) && row_slots() == 1; }
+
+  bool process_n(size_t n, const TD* x, TD* y, int op_kind, const void* params, fdx* dfts)
+  {
+    if (n == 0) return true;
+    if (!bind()) return false;
+    if (op_kind < OP_IDENTITY || op_kind > OP_SHIFT) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
+    if ((op_kind != OP_IDENTITY) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
+    if (op_kind == OP_SHIFT && dfts) { set_error("sdft_hip_process_n", "a copy of the spectrum is not available with the shift operation"); return false; }
+    const bool yd = on_device(y);
+    if (nbins == 0)
+    {
+      if (yd) SDFT_TRY(hipMemsetAsync(y, 0, channels * n * sizeof(TD), stream)); else memset(y, 0, channels * n * sizeof(TD));
+      return finish();
+    }
+    if (dfts && !on_device(dfts)) { set_error("sdft_hip_process_n", "dfts must be device memory (or NULL)"); return false; }
+    SpectralOp<FD> op; op.kind = op_kind; op.gain = nullptr; op.shift = 0;
+    if (op_kind == OP_GAIN)
+    {
+      const FD* g = static_cast<const FD*>(params);
+      if (!on_device(g))
+      {
+        if (!d_gain.reserve(nbins)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, nbins * sizeof(FD), hipMemcpyHostToDevice, stream));
+        g = d_gain.p;
+      }
+      op.gain = g;
+    }
+    else if (op_kind == OP_SHIFT) op.shift = *static_cast<const long*>(params);
+
+    // samples: device pointers as they are, host pointers staged (4 bytes per sample each way)
+    const bool xd = on_device(x);
+    const TD* xs = x;
+    if (!xd)
+    {
+      if (!d_stage_td.reserve(channels * n)) return false;
+      SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, channels * n * sizeof(TD), hipMemcpyHostToDevice, stream));
+      xs = d_stage_td.p;
+    }
+    TD* ys = y;
+    if (!yd) { if (!d_stage_y.reserve(channels * n)) return false; ys = d_stage_y.p; }
+
+    bool ok;
+    long chunks, len;
+    choose_chunks(n, chunks, len, rows_kernel_ok(false));
+    if (fuse_ok() && chunks > 1)
+    {
+      FuseArgs<TD, FD> fz;
+      fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
+      last_process_path = 1;
+      ok = forward_device(n, xs, n, dfts, n * nbins, nullptr, &fz);
+    }
+    else
+    {
+      // short calls (one time chunk: the hop kernel and the row-per-wave synthesis, two launches) and
+      // shapes the row-group kernel does not cover: analysis into the caller's matrix or a bounded
+      // workspace, synthesis with the operation applied on the way in
+      const size_t row_elems = channels * nbins;
+      size_t seg = dfts ? n : std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(row_elems * sizeof(fdx), 1)));
+      if (channels > 1 && !dfts) seg = n;                    // batched layout: channel stride = n rows (workspace holds the call)
+      if (!dfts && !d_stage_fdx.reserve(row_elems * seg)) return false;
+      last_process_path = (chunks == 1) ? 2 : 3;
+      ok = true;
+      for (size_t t = 0; t < n && ok; t += seg)
+      {
+        const size_t m = std::min(seg, n - t);
+        fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
+        const size_t mstride = dfts ? n * nbins : m * nbins;
+        ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &op);
+        if (ok && op_kind == OP_GAIN && dfts) ok = scale_rows(mat, mstride, m, op.gain);
+      }
+    }
+    if (!ok) return false;
+    if (!yd)
+    {
+      SDFT_TRY(hipMemcpyAsync(y, ys, channels * n * sizeof(TD), hipMemcpyDeviceToHost, stream));
+      return synchronize();
+    }
+    return finish(channels * n * nbins);
+  }
+
+  // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)
+  bool scale_rows(fdx* mat, size_t stride, size_t rows, const FD* gain)
+  {
+    const size_t total = channels * rows * nbins;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
+    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, gain);
+    SDFT_TRY(hipGetLastError());
+    return true;
   }
 
   // checkpoint / resume: install a state previously read with get_state (any plan of the same

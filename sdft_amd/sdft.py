@@ -14,7 +14,7 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import Api, STAGES, WINDOWS, SdftHipError
+from .capi import Api, OPS, STAGES, WINDOWS, SdftHipError
 
 _NP_REAL = {"f32": np.float32, "f64": np.float64}
 _NP_CPLX = {"f32": np.complex64, "f64": np.complex128}
@@ -197,6 +197,56 @@ class SDFT:
                 out = np.empty(yshape, dtype=self.td)
             assert out.flags.c_contiguous and out.shape == yshape and out.dtype == self.td
             self.api.isdft_n(self._p, n, C.c_void_p(dfts.ctypes.data), C.c_void_p(out.ctypes.data))
+        self.api.check()
+        return out
+
+
+    def process(self, x, op="identity", gain=None, shift=0, out=None, dfts=None):
+        """Fused analysis -> spectral operation -> synthesis (``sdft_hip_process_n``): returns the
+        processed samples; the DFT matrix is not materialised unless ``dfts`` (a CUDA tensor of shape
+        (n, dftsize) [(channels, n, dftsize)]) asks for a copy of the processed spectrum.
+
+        ``op``: "identity", "gain" (``gain`` = real array of dftsize factors) or "shift" (``shift`` bins).
+        """
+        kind = OPS[op] if isinstance(op, str) else int(op)
+        params = None
+        keep = None
+        if kind == OPS["gain"]:
+            if _is_tensor(gain):
+                self._check_tensor(gain, "gain", self.fd, (self.dftsize,))
+                params = C.c_void_p(gain.data_ptr())
+            else:
+                keep = np.ascontiguousarray(gain, dtype=self.fd)
+                assert keep.shape == (self.dftsize,)
+                params = C.c_void_p(keep.ctypes.data)
+        elif kind == OPS["shift"]:
+            keep = C.c_long(int(shift))
+            params = C.cast(C.byref(keep), C.c_void_p)
+        dptr = None
+        if _is_tensor(x):
+            torch = _torch()
+            n = self._shape_x(x.shape)
+            self._check_tensor(x, "samples", self.td)
+            if out is None:
+                out = torch.empty_like(x)
+            self._check_tensor(out, "out", self.td, tuple(x.shape))
+            if dfts is not None:
+                self._check_tensor(dfts, "dfts", self.fdx, (n, self.dftsize) if x.dim() == 1 else (self.channels, n, self.dftsize))
+                dptr = C.c_void_p(dfts.data_ptr())
+            rc = self.api.process_n(self._p, n, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), kind, params, dptr)
+        else:
+            x = np.ascontiguousarray(x, dtype=self.td)
+            n = self._shape_x(x.shape)
+            if out is None:
+                out = np.empty_like(x)
+            assert out.flags.c_contiguous and out.shape == x.shape and out.dtype == self.td
+            if dfts is not None:
+                self._check_tensor(dfts, "dfts", self.fdx)
+                dptr = C.c_void_p(dfts.data_ptr())
+            rc = self.api.process_n(self._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data), kind, params, dptr)
+        if rc != 0:
+            self.api.check()
+            raise SdftHipError("sdft_hip_process_n failed")
         self.api.check()
         return out
 

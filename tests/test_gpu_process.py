@@ -1,0 +1,156 @@
+"""Fused analysis -> spectral operation -> synthesis (sdft_hip_process_n) against what
+a host of the reference computes with sdft_sdft_n, its own loop over the matrix, and sdft_isdft_n
+(README.md:42-47 of the reference): the oracle's analysis, the operation in numpy, the oracle's synthesis."""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdft_amd.signals import noise, sine_sweep
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": 1e-6, "f32": 1e-4}
+
+
+def make(dftsize, window="hann", latency=1.0, combo="f32f64", channels=1, **opts):
+    from sdft_amd.sdft import SDFT
+    p = SDFT(dftsize, window, latency, combo, channels)
+    for k, v in opts.items():
+        p.set_option(k, v)
+    return p
+
+
+def apply_op(d, op, gain, shift):
+    """What the host does to the (n, N) matrix between the two reference calls."""
+    if op == "gain":
+        return (d * gain[None, :].astype(d.real.dtype)).astype(d.dtype)     # complex * real, per component
+    if op == "shift":
+        out = np.zeros_like(d)
+        n = d.shape[1]
+        if shift >= 0:
+            out[:, shift:] = d[:, :n - shift] if shift < n else 0
+        else:
+            out[:, :n + shift] = d[:, -shift:]
+        return out
+    return d
+
+
+def reference(ref, x, op, gain, shift):
+    d = apply_op(ref.sdft(x), op, gain, shift)
+    return ref.isdft(d), d
+
+
+def rel(a, b):
+    s = float(np.abs(b).max())
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max()) / (s if s else 1.0)
+
+
+OPS = [("identity", 0), ("gain", 0), ("shift", 3), ("shift", -5)]
+
+
+@pytest.mark.parametrize("op,shift", OPS)
+@pytest.mark.parametrize("latency", [1.0, 0.5])
+def test_fused_double_fast_path(op, shift, latency):
+    """FD double, chunk-parallel analysis (not bit-exact by design): fused kernel with the tree sum,
+    and with the reference's summation order on request; state carries over to the next call."""
+    import torch
+    m, n = 1024, 6000
+    x = sine_sweep(n)
+    gain = np.linspace(0.0, 2.0, m)
+    ref = O.best(m, "hann", latency, "f32f64")
+    want, wd = reference(ref, x, op, gain, shift)
+    x2 = noise(700, seed=3)
+    want2, _ = reference(ref, x2, op, gain, shift)
+    for fused_exact in (-1, 1):
+        with make(m, "hann", latency, "f32f64", fused_exact=fused_exact) as p:
+            xd = torch.from_numpy(x).cuda()
+            y = p.process(xd, op, gain=gain, shift=shift)
+            assert p.get_option("last_process_path") == 1 and p.get_option("last_chunks") > 1
+            assert p.get_option("last_fused_exact") == (1 if fused_exact == 1 else 0)
+            assert rel(y.cpu().numpy(), want) <= TOL["f64"], (op, shift, latency, fused_exact)
+            if op != "shift":                                    # copy of the processed spectrum
+                p.reset()
+                dd = torch.empty((n, m), dtype=torch.complex128, device="cuda")
+                y = p.process(xd, op, gain=gain, dfts=dd)
+                assert rel(y.cpu().numpy(), want) <= TOL["f64"]
+                assert float(np.abs(dd.cpu().numpy() - wd).max()) <= 1e-11 * float(np.abs(wd).max())
+            y2 = p.process(torch.from_numpy(x2).cuda(), op, gain=gain, shift=shift)      # continues the stream
+            assert rel(y2.cpu().numpy(), want2) <= TOL["f64"]
+
+
+@pytest.mark.parametrize("combo,opts", [("f32f32", {}), ("f64f32", {}), ("f32f64", {"carry": 1}), ("f64f64", {"carry": 1})])
+@pytest.mark.parametrize("window", ["hann", "blackman", "boxcar"])
+def test_fused_exact_modes_are_bit_identical(combo, opts, window):
+    """Exact carries (FD float always, FD double on request): the fused kernel walks the bins in the
+    reference's order, so the samples equal the two reference calls bit for bit -- for every operation,
+    both synthesis branches, rows that do not fill the last wave, batched channels."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    for m, n, latency in ((256, 5000, 1.0), (1000, 3000, 0.5), (72, 1500, 1.0)):
+        gain = np.cos(np.arange(m) * 0.1).astype(fd)
+        ch = 2
+        xb = np.stack([noise(n, seed=7 + c, dtype=td) for c in range(ch)])
+        for op, shift in OPS:
+            with make(m, window, latency, combo, ch, **opts) as p:
+                y = p.process(torch.from_numpy(xb).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+                assert p.get_option("last_process_path") == 1 and p.get_option("last_fused_exact") == 1
+                for c in range(ch):
+                    want, _ = reference(O.best(m, window, latency, combo), xb[c], op, gain, shift)
+                    assert np.array_equal(y[c], want), (combo, window, m, op, shift, c, rel(y[c], want))
+
+
+@pytest.mark.parametrize("combo", O.COMBOS)
+def test_hop_sized_calls_and_host_pointers(combo):
+    """Calls of one time chunk (the reference's hop loop, test/test.c:69-83): hop kernel + one-wave-per-row
+    synthesis with the operation applied on the way in; bit-identical, host and device pointers."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    m, hop = 1000, 100
+    x = sine_sweep(12 * hop, dtype=td)
+    gain = (1.0 / (1.0 + np.arange(m) / 100.0)).astype(fd)
+    for op, shift in OPS:
+        ref = O.best(m, "hann", 1.0, combo)
+        with make(m, "hann", 1.0, combo) as p:
+            for i in range(0, x.size, hop):
+                want, _ = reference(ref, x[i:i + hop], op, gain, shift)
+                seg = x[i:i + hop]
+                got = p.process(seg, op, gain=gain, shift=shift) if (i // hop) % 2 else \
+                    p.process(torch.from_numpy(seg).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+                assert p.get_option("last_process_path") == 2
+                assert np.array_equal(got, want), (combo, op, shift, i)
+
+
+def test_shapes_outside_the_fused_kernel_take_the_two_pass_path():
+    """Rows longer than one slot per lane (m = 4096 at FD double) and tiny rows: analysis + synthesis
+    through the bounded workspace, same results."""
+    import torch
+    for m, n, combo in ((4096, 3000, "f32f64"), (5, 900, "f32f32"), (3000, 2000, "f32f32")):
+        td, fd, fdx = O.combo_types(combo)
+        x = noise(n, seed=1, dtype=td)
+        gain = np.linspace(1.0, 0.0, m).astype(fd)
+        for op, shift in (("gain", 0), ("shift", 2)):
+            want, _ = reference(O.best(m, "hamming", 1.0, combo), x, op, gain, shift)
+            with make(m, "hamming", 1.0, combo, stage_bytes=1 << 22) as p:
+                y = p.process(torch.from_numpy(x).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+                assert p.get_option("last_process_path") in (1, 3)
+                assert rel(y, want) <= TOL[combo[3:]], (m, op)
+
+
+def test_process_argument_errors():
+    import ctypes as C
+    import torch
+    from sdft_amd.capi import Api
+    api = Api("f32f64")
+    plan = api.alloc(64)
+    x = torch.zeros(600, dtype=torch.float32, device="cuda")
+    y = torch.full((600,), 7.0, dtype=torch.float32, device="cuda")
+    d = torch.zeros((600, 64), dtype=torch.complex128, device="cuda")
+    s = C.c_long(1)
+    for op, params, dfts in ((9, None, None), (1, None, None), (2, C.cast(C.byref(s), C.c_void_p), C.c_void_p(d.data_ptr()))):
+        assert api.process_n(plan, 600, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), op, params, dfts) == -1
+        assert api.last_error()
+        api.lib.sdft_hip_clear_error()
+    assert float(y.min()) == 7.0                                  # outputs untouched
+    assert api.process_n(plan, 0, None, None, 0, None, None) == 0
+    api.free(plan)
