@@ -168,6 +168,18 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
             p.synchronize()
             w = (time.perf_counter() - t0) / (total // hop)
         res[f"us_per_hop_{mode}"] = round(w * 1e6, 1)
+    # the fused entry point: one call per hop (hop kernel + row synthesis, no host round trip between)
+    for mode in ("sync", "async"):
+        p.set_option("async", 1 if mode == "async" else 0)
+        w = 0.0
+        for rep in range(2):
+            p.synchronize()
+            t0 = time.perf_counter()
+            for i in range(0, total, hop):
+                p.api.process_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ys + i * isz), 0, None, None)
+            p.synchronize()
+            w = (time.perf_counter() - t0) / (total // hop)
+        res[f"us_per_hop_process_n_{mode}"] = round(w * 1e6, 1)
     p.set_option("async", 1); p.set_option("profile", 1)
     for i in range(0, total, hop):
         p.api.sdft_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ds))
@@ -369,6 +381,28 @@ def main():
                 "row_lockstep_gbs": round(nbytes / (grp * 1e-3) / 1e9, 1),
                 "frac_of_best_store_only": round(achieved / (nbytes / (best_ms * 1e-3) / 1e9), 4),
             }
+        # fused analysis -> synthesis (sdft_hip_process_n): same input, no matrix traffic; VALU-bound, so
+        # it is priced against the fp64 vector peak next to the two-pass figure it replaces
+        fp = {}
+        for label, fe in (("tree_sum", 0), ("reference_order", 1)):
+            plan.set_option("fused_exact", fe)
+            yf = plan.process(x)
+            sync()
+            tf = time.perf_counter()
+            for _ in range(5):
+                plan.process(x, out=yf)
+            sync()
+            wf = (time.perf_counter() - tf) / 5
+            fp[label + "_msamples_s"] = round(count * n / wf / 1e6, 1)
+            fp[label + "_ms"] = round(wf * 1e3, 3)
+        plan.set_option("fused_exact", -1)
+        flops = 24 + 2                                     # per bin-sample: recurrence 16, Hann window 8, synthesis term + sum 2
+        fp["two_pass_msamples_s"] = round(rate_rt / 1e6, 1)
+        fp["speedup_vs_two_pass"] = round(fp["tree_sum_msamples_s"] / max(rate_rt / 1e6, 1e-9), 2)
+        fp["fp64_vector_tflops"] = round(count * n * m * flops / (fp["tree_sum_ms"] * 1e-3) / 1e12, 2)
+        fp["fp64_vector_peak_tflops"] = 78.6
+        fp["note"] = "unfused multiplies and additions count one flop each; the spec peak counts an FMA as two"
+        result["fused_process"] = fp
         if workload == "single" and out.numel() >= 48000 * m:
             result["north_star_n48000"] = north_star_shape(torch, np, SDFT, sine_sweep, out, m, window, combo, esz, td, local_rank)
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)

@@ -19,7 +19,7 @@ from sdft_amd.signals import sine_sweep
 ROWS = []
 
 
-def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True):
+def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True, **opts):
     td = np.float32 if combo[:3] == "f32" else np.float64
     esz = 16 if combo[3:] == "f64" else 8
     cdt = torch.complex128 if esz == 16 else torch.complex64
@@ -31,6 +31,8 @@ def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True):
     x = torch.from_numpy(xh).cuda()
     out = torch.empty((n, m) if channels == 1 else (channels, n, m), dtype=cdt, device="cuda")
     p = SDFT(m, window, 1.0, combo, channels)
+    for k, v in opts.items():
+        p.set_option(k, v)
     p.set_option("profile", 1); p.set_option("async", 1)
     y = None
     for _ in range(2):
@@ -45,14 +47,26 @@ def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True):
         p.isdft(out, y)
     p.synchronize(); wall_i = (time.perf_counter() - t0) / reps
     pr = p.profile()
+    geometry = (f"{p.get_option('last_chunks')}×{p.get_option('last_chunk_len')}"
+                f" (kernel {p.get_option('last_kernel')}, {'exact' if p.get_option('carry') else 'fast'} carry"
+                f"{', chain form' if p.get_option('last_chain') else ''}, {p.get_option('last_segments')} seg)")
+    # fused analysis -> synthesis on the same input (no matrix traffic)
+    p.set_option("profile", 0)
+    yf = p.process(x)
+    p.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.process(x, out=yf)
+    p.synchronize(); wall_p = (time.perf_counter() - t0) / reps
+    path = {1: "fused", 2: "hop pair", 3: "two-pass"}[p.get_option("last_process_path")]
     f = pr["forward"][0] / max(pr["forward"][1], 1)          # one event pair per call, all segments
     c = pr["carry"][0] / max(pr["carry"][1], 1)
     i = pr["inverse"][0] / max(pr["inverse"][1], 1)
     byts = channels * n * (m * esz + x.element_size())
-    ROWS.append(f"| {label} | {channels}×{n}×{m} {window} {combo} | {p.get_option('last_chunks')}×{p.get_option('last_chunk_len')}"
-                f" (kernel {p.get_option('last_kernel')}, {'exact' if p.get_option('carry') else 'fast'} carry, {p.get_option('last_segments')} seg)"
+    ROWS.append(f"| {label} | {channels}×{n}×{m} {window} {combo} | {geometry}"
                 f" | {wall_f * 1e3:.3f} | {channels * n / wall_f / 1e6:.1f} | {byts / wall_f / 1e12:.2f} | {f:.3f} | {c:.3f}"
-                f" | {wall_i * 1e3:.3f} | {channels * n / wall_i / 1e6:.1f} | {byts / wall_i / 1e12:.2f} |")
+                f" | {wall_i * 1e3:.3f} | {channels * n / wall_i / 1e6:.1f} | {byts / wall_i / 1e12:.2f}"
+                f" | {wall_p * 1e3:.3f} ({path}) | {channels * n / wall_p / 1e6:.1f} | {(wall_f + wall_i) / wall_p:.2f}× |")
     p.close()
     del out, x
 
@@ -65,9 +79,13 @@ if __name__ == "__main__":
     run("configs[3] 64 ch × m=2048 (FD float, 50.3 GB)", 48000, 2048, "hann", "f32f32", channels=64, reps=3)
     run("configs[4] one GPU's share: 64 ch × m=1024", 48000, 1024, "hann", "f32f64", channels=64, reps=3)
     run("reference test shape m=1000", 352800, 1000, "hann", "f32f64")
+    run("configs[1] with bit-exact carries (carry=1)", 1_000_000, 1024, "hann", "f32f64", carry=1)
+    run("configs[2] with the serial pass instead of the chain form", 262144, 4096, "blackman", "f32f32", chain=0)
+    run("FD float, m=1024", 262144, 1024, "hann", "f32f32")
     print(f"# BASELINE config shapes on 1× MI355X ({torch.cuda.get_device_name(0)}), device-resident buffers\n")
     print("forward = sdft_sdft_n (delta + carries + forward kernel, wall per call incl. launches); inverse = sdft_isdft_n.")
-    print("TB/s = algorithmic bytes (N·sizeof(fdx) + sizeof(td) per sample) / wall time.\n")
-    print("| config | shape | time chunks | fwd ms | fwd Msamples/s | fwd TB/s | fwd-kernel ms | carry ms (on main stream) | inv ms | inv Msamples/s | inv TB/s |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    print("TB/s = algorithmic bytes (N·sizeof(fdx) + sizeof(td) per sample) / wall time.")
+    print("process = sdft_hip_process_n (identity), the fused analysis→synthesis call; its last column is the speed-up over forward + inverse.\n")
+    print("| config | shape | time chunks | fwd ms | fwd Msamples/s | fwd TB/s | fwd-kernel ms | carry ms (on main stream) | inv ms | inv Msamples/s | inv TB/s | process ms | process Msamples/s | vs two calls |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     print("\n".join(ROWS))

@@ -1645,7 +1645,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 {
   static_assert(SYN == 0 || S == 1, "the fused synthesis path is built for single-slot rows");
   constexpr int H = win_halo<WIN>::value;
-  constexpr int G = (kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2;   // keeps registers roughly constant
+  // keeps registers roughly constant; the fused synthesis path always takes eight samples per group (its
+  // per-group cost is the walk over the bins, shared by as many lanes as there are samples)
+  constexpr int G = SYN != 0 ? kRowGroup : ((kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2);
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
   constexpr int VW = kRowWavesMax * S;                    // virtual waves
   // edgeL[buf][u][v][i] = bin (first bin of virtual wave v) - 1 - i, edgeR[..][i] = (last bin) + 1 + i

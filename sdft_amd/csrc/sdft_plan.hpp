@@ -720,7 +720,7 @@ class Plan
 
   // fused analysis -> operation -> synthesis: the same kernel with SYN = 1 (tree sum over bins) or 2
   // (the reference's ascending order); the terms image lives in dynamic LDS
-  static constexpr int kSynGroup = (kRowGroup / (sizeof(fdx) == 16 ? 1 : 2)) >= 2 ? kRowGroup / (sizeof(fdx) == 16 ? 1 : 2) : 2;
+  static constexpr int kSynGroup = kRowGroup;
   size_t syn_lds() const
   {
     const size_t padded = (size_t)row_waves() * kWave * bins_per_lane();
