@@ -58,6 +58,48 @@ def test_c_host_streaming(tmp_path, hip_library, flags, combo):
     assert np.abs(got_y - want_y).max() <= tol * np.abs(want_y).max()
 
 
+@pytest.mark.parametrize("flags,combo", [([], "f32f64"), (["-DSDFT_FD_FLOAT"], "f32f32")])
+@pytest.mark.parametrize("op", [0, 1, 2])
+def test_c_host_fused_process(tmp_path, hip_library, flags, combo, op):
+    """tests/c/host_process.c: sdft_hip_process_n from a gcc-built C host (hops of 100 and calls of 4000
+    samples) against the same host running the reference's three steps through the drop-in
+    functions, and against the oracle."""
+    td, fd, fdx = O.combo_types(combo)
+    libdir = os.path.dirname(hip_library)
+    rt = hip_runtime_dir()
+    exe = tmp_path / "host_process"
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), *flags,
+           os.path.join(ROOT, "tests", "c", "host_process.c"), "-o", str(exe),
+           "-L", libdir, "-lsdft_hip", "-L", rt, "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = 256
+    x = noise(8000, seed=4, dtype=td)
+    x.tofile(tmp_path / "x.raw")
+    gain = (1.0 / (1.0 + np.arange(m) / 64.0)).astype(fd)
+    for hop in (100, 4000):
+        r = subprocess.run([str(exe), str(m), str(hop), str(op), str(tmp_path / "x.raw"), str(tmp_path / "y1.raw"),
+                            str(tmp_path / "y2.raw")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "C-PROCESS ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+        y1 = np.fromfile(tmp_path / "y1.raw", dtype=td)
+        y2 = np.fromfile(tmp_path / "y2.raw", dtype=td)
+        ref = O.best(m, "hann", 1.0, combo)
+        want = []
+        for i in range(0, x.size, hop):
+            d = ref.sdft(x[i:i + hop])
+            if op == 1:
+                d = (d * gain[None, :]).astype(fdx)
+            if op == 2:
+                s = np.zeros_like(d); s[:, 3:] = d[:, :m - 3]; d = s
+            want.append(ref.isdft(d))
+        want = np.concatenate(want)
+        tol = 1e-6 if combo.endswith("f64") else 1e-4
+        assert np.abs(y2 - want).max() <= tol * np.abs(want).max()
+        assert np.abs(y1 - want).max() <= tol * np.abs(want).max()
+        if hop < 512 or combo.endswith("f32"):
+            assert np.array_equal(y1, want) and np.array_equal(y1, y2)      # bit-identical where the analysis is
+
+
 @pytest.mark.parametrize("t,f,combo", [("float", "double", "f32f64"), ("double", "double", "f64f64"), ("float", "float", "f32f32")])
 def test_cpp_facade_host(tmp_path, hip_library, t, f, combo):
     """C++ host using sdft::SDFT<T, F> (include/sdft/sdft.hpp, the reference's C++ interface) in the
