@@ -66,6 +66,33 @@ if __name__ == "__main__":
         run(1000000, 1024)
         sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "inv":
+        for n in (4096, 12000, 48000, 131072, 262144):
+            for rw in (1, 4, 16, 32):
+                run(n, 1024, inverse_rows=rw, reps=10)
+        for rw in (1, 4, 16):
+            run(48000, 1024, "hann", "f32f32", inverse_rows=rw, reps=10)
+            run(20000, 4096, "blackman", "f32f32", inverse_rows=rw, reps=10)
+    if which == "ns48":
+        for rep in range(2):
+            for ch in (0, 96, 128, 160, 192, 256, 384):
+                run(48000, 1024, chunk=ch, reps=20)
+        run(48000, 1024, fft_carry=0, reps=20)
+    if which == "ringp":
+        for P in (3, 4, 5, 6, 7):
+            run(262144, 1024, "hann", "f32f32", chain_producers=P, segments=1)
+        for L in (8, 16):
+            run(262144, 1024, "hann", "f32f32", chain_block=L, segments=1, chain_producers=7)
+        for P in (4, 6, 7):
+            run(1000000, 1024, carry=1, segments=1, chain_producers=P)
+    if which == "ring":
+        for ring in (0, 1):
+            run(262144, 1024, "hann", "f32f32", chain_ring=ring, segments=1)
+            run(262144, 1024, "hann", "f32f32", chain_ring=ring)
+            run(262144, 4096, "blackman", "f32f32", chain_ring=ring)
+            run(262144, 2048, "blackman", "f32f32", chain_ring=ring)
+            run(1000000, 1024, carry=1, chain_ring=ring)
+            run(1000000, 1024, carry=1, chain_ring=ring, segments=1)
     if which == "chainlen":
         for ch in (192, 256, 384, 768):
             run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chunk=ch)

@@ -760,6 +760,8 @@ template <typename FD> struct ChainArgs
   unsigned nbins, chunks, chunk_len, cursor0;
   unsigned chunk0, launch_chunks;
   unsigned L, P;              // block length (divides 2N, multiple of 8), producer waves
+  unsigned NB;                // ring form: blocks the LDS ring holds
+  unsigned chunk_shift;       // ring form: chunk j > 0 starts at sample j*chunk_len - chunk_shift (0 elsewhere)
   unsigned debug;             // measurement aid: bit 0 = consumer idles, bit 1 = producers idle (results are garbage)
   unsigned long long* stats;  // measurement aid: per wave of workgroup 0, cycles in {work, tail waits, barrier} (or nullptr)
 };
@@ -1054,6 +1056,245 @@ __global__ __launch_bounds__(kWave * 8) void carry_chain_kernel(ChainArgs<FD> a)
 }
 
 // ------------------------------------------------------------------------------------------
+// K1a-ring (exact carry, ring form)  carry_chain_kernel without rounds and without run bookkeeping.
+// There the producers and the consumer of a workgroup meet at a barrier once per round, and what the
+// consumer spends per round on bookkeeping (a lone wave pays 4.5 cycles for EVERY instruction, scalar ones
+// included), on LDS latency at run starts and at the barrier is half of its time.  Here
+//  * the products go through a RING of NB blocks of L steps: producer p fills blocks p, p+P, p+2P, ... as
+//    soon as the slot is free and publishes each with a sequence number (ready[slot] = block + 1); the
+//    consumer publishes how many blocks it has left behind.  Both sides poll LDS words; the LDS serves a
+//    wave's instructions in order, so a flag written after the data (producer) or read before it
+//    (consumer) orders them.  Every poll loop is bounded and a time-out is sticky for the workgroup: a
+//    protocol error ends the kernel with wrong carries (the parity tests would catch that) instead of
+//    hanging the GPU;
+//  * the host shifts the chunk grid so that every chunk but the first starts on a block boundary
+//    (ChainArgs::chunk_shift = cursor0 mod L; the forward kernels use the same grid): the consumer
+//    then walks WHOLE blocks -- one block's products are fetched while the previous block's are added,
+//    a chunk start is a block counter reaching zero -- and all its bookkeeping is a handful of 32-bit
+//    scalar instructions per block.
+// ------------------------------------------------------------------------------------------
+constexpr int kRingMaxBlocks = 48;
+constexpr unsigned kRingPollCap = 1u << 20;
+
+// LDS words of the ring protocol, accessed as workgroup-scope atomics on the __shared__ objects themselves
+// (a volatile access through a generic pointer compiles to flat_load/flat_store sc0 sc1 and drags a full
+// s_waitcnt behind it -- measured: 325 cycles per block on the consumer)
+SDFT_D unsigned ring_peek(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SDFT_D void ring_poke(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SDFT_D int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename FD, int L>
+__global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
+{
+  constexpr int NV = 16 / (int)sizeof(FD);                 // steps per 16-byte LDS access
+  constexpr int VB = L / NV;                               // 16-byte vectors per block and lane
+  typedef FD vec_t __attribute__((ext_vector_type(NV)));
+  extern __shared__ __align__(16) unsigned char ring_lds_raw[];
+  __shared__ unsigned ready[kRingMaxBlocks];
+  __shared__ unsigned consumed_blocks;
+  __shared__ unsigned aborted;                             // a poll loop ran out: everybody leaves
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int comp = lane & 1;
+  const unsigned bin_blocks = (a.nbins + kWave / 2 - 1) / (kWave / 2);
+  const unsigned bin = (blockIdx.x % bin_blocks) * (kWave / 2) + (lane >> 1);
+  const size_t ch = blockIdx.x / bin_blocks;
+  const bool valid = bin < a.nbins;
+  const unsigned kk = valid ? bin : a.nbins - 1;
+  const unsigned span = 2u * a.nbins;
+  const int P = (int)a.P, NB = (int)a.NB;
+  const int S = NB * L + NV;                               // a lane's row: the ring + one vector (odd multiple of 16 B)
+  FD* prod = reinterpret_cast<FD*>(ring_lds_raw) + (size_t)lane * S;
+
+  // shifted chunk grid: chunk j starts at sample j*len - shift (chunk 0 at 0), i.e. on a block boundary
+  const unsigned jend = a.chunk0 + a.launch_chunks;
+  const bool ends_call = (jend == a.chunks);
+  const long long len = a.chunk_len, sh = a.chunk_shift;
+  const long long tb = a.chunk0 ? a.chunk0 * len - sh : 0;
+  const long long te = (long long)(ends_call ? jend - 1 : jend) * len - sh;       // first step this launch does NOT take
+  const long long total = te > tb ? te - tb : 0;
+  const long long u0 = (long long)a.cursor0 + tb, u1 = u0 + total;               // absolute steps; blocks start at multiples of L
+  const long long q0 = u0 / L;
+  const int nblocks = (int)((u1 + L - 1) / L - q0);        // u1 is a block boundary whenever total > 0
+  const int off0 = (int)(u0 - q0 * L);                     // > 0 only for a launch that starts the call mid-block
+
+  if (threadIdx.x < kRingMaxBlocks) ready[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { consumed_blocks = 0; aborted = 0; }
+  __syncthreads();
+
+  if (wave == 0)
+  {
+    // ---------------- consumer: the chain ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const cx<FD> acc0 = a.acc_state[ch * a.nbins + kk];
+    FD acc = comp ? acc0.im : acc0.re;
+    unsigned j = a.chunk0;
+    FD* cptr = reinterpret_cast<FD*>(a.carry) + (((ch * a.chunks + a.chunk0) * a.nbins) + kk) * 2 + comp;
+    const size_t cstride = (size_t)a.nbins * 2;
+    const int blocks_per_chunk = (int)(len / L);
+    int ready_upto = 0;                                     // blocks known to be published (wave-uniform)
+    auto dump = [&]() { if (valid) *cptr = acc; cptr += cstride; ++j; };
+    // Wait until `want` blocks are published: one lane per slot looks at the flags; returns the new count
+    // of consecutive published blocks, or -1 when the poll budget ran out (sticky for the workgroup).
+    auto await = [&](int have, int want) -> int
+    {
+      unsigned polls = 0;
+      for (;;)
+      {
+        const int g = have + lane;
+        int slot = g % NB;
+        const unsigned flag = (lane < NB) ? ring_peek(&ready[slot]) : 0u;
+        const unsigned long long mask = __ballot(lane < NB && g < nblocks && flag == (unsigned)(g + 1));
+        have = uniform(have + (int)__builtin_ctzll(~mask));  // consecutive published blocks
+        if (have >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return have; }
+        if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return -1; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    };
+    int fslot = 0;                                          // ring slot of the next block to be fetched
+    auto fetch = [&](vec_t (&v)[VB])
+    {
+      const FD* ps = prod + fslot * L;
+      fslot = uniform((fslot + 1 == NB) ? 0 : fslot + 1);
+#pragma unroll
+      for (int q = 0; q < VB; ++q) v[q] = *reinterpret_cast<const vec_t*>(ps + q * NV);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chain = [&](const vec_t (&v)[VB])
+    {
+#pragma unroll
+      for (int q = 0; q < VB; ++q)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc = acc + v[q][e];                           // the chain (sdft.h:583)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    dump();                                                 // the chunk this launch starts with
+    int to_dump = blocks_per_chunk;                         // whole blocks until the next chunk start
+    int b = 0;
+    if (nblocks > 0 && off0 > 0)
+    {
+      // the call starts mid-block (chunk 0 only): steps off0 .. L-1 of block 0, one by one
+      ready_upto = await(0, 1);
+      if (ready_upto > 0)
+        for (int s = off0; s < L; ++s) acc = acc + prod[s];
+      if (lane == 0) ring_poke(&consumed_blocks, 1u);
+      b = 1; fslot = (NB == 1) ? 0 : 1; --to_dump;          // the shifted first chunk ends blocks_per_chunk - 1 blocks later
+      if (to_dump == 0 && b < nblocks) { dump(); to_dump = blocks_per_chunk; }
+    }
+    if (ready_upto >= 0 && b < nblocks)
+    {
+      // block b's products are in v0 while block b+1's are fetched into v1, and vice versa; a block is
+      // fetched only after its flag has been seen
+      vec_t v0[VB], v1[VB];
+      const int last = nblocks - 1;
+      if (ready_upto < b + 1) ready_upto = await(ready_upto, b + 1);
+      if (ready_upto >= 0) fetch(v0);
+      while (ready_upto >= 0)
+      {
+        if (b < last) { if (ready_upto < b + 2) ready_upto = await(ready_upto, b + 2); if (ready_upto < 0) break; fetch(v1); }
+        chain(v0);
+        b = uniform(b + 1); to_dump = uniform(to_dump - 1);
+        if (b > last) break;
+        if (to_dump == 0) { dump(); to_dump = blocks_per_chunk; }
+        if (b < last) { if (ready_upto < b + 2) ready_upto = await(ready_upto, b + 2); if (ready_upto < 0) break; fetch(v0); }
+        chain(v1);
+        b = uniform(b + 1); to_dump = uniform(to_dump - 1);
+        if (lane == 0) ring_poke(&consumed_blocks, (unsigned)b);               // once per pair of blocks
+        if (b > last) break;
+        if (to_dump == 0) { dump(); to_dump = blocks_per_chunk; }
+      }
+      if (lane == 0) ring_poke(&consumed_blocks, (unsigned)b);
+    }
+    if (j < jend) dump();                                   // the chunk that starts where this launch ends
+    if (!ends_call && valid)
+      reinterpret_cast<FD*>(a.acc_next)[((ch * a.nbins) + bin) * 2 + comp] = acc;
+    return;
+  }
+
+  // ---------------- producers ----------------
+  __builtin_amdgcn_s_setprio(2);
+  if (wave > P) return;
+  const cx<FD> tw = a.tw[kk];
+  const FD T1 = tw.re;
+  const FD T2 = comp ? tw.im : -tw.im;
+  const SDFT_CONSTANT FD* dch = as_uniform(a.delta + ch * a.n);
+  int g = wave - 1;                                          // this wave's block (relative to q0)
+  if (g >= nblocks) return;
+  unsigned cb = (unsigned)(((q0 + g) * L) % span);           // its cursor, kept in 32 bits from here on
+  const unsigned step_cb = (unsigned)(((long long)P * L) % span);
+  cx<FD> sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
+  FD dl[L];
+#pragma unroll
+  for (int s = 0; s < L; ++s) dl[s] = (FD)0;
+  {
+    const long long ub = (q0 + g) * L;
+    if (ub >= u0 && ub + L <= u1)
+    {
+#pragma unroll
+      for (int s = 0; s < L; ++s) dl[s] = dch[ub - (long long)a.cursor0 + s];
+    }
+  }
+  unsigned seen_consumed = 0;
+  int pslot = g % NB;                                        // ring slot of block g, advanced by P per block
+  const int pstep = P % NB;
+  for (; g < nblocks; g += P)
+  {
+    const long long ub = (q0 + g) * L;
+    FD f = comp ? sd.im : sd.re;
+    vec_t pv[VB];
+    if (ub >= u0 && ub + L <= u1)
+    {
+#pragma unroll
+      for (int s = 0; s < L; ++s) pv[s / NV][s % NV] = chain_step(f, dl[s], T1, T2);
+    }
+    else
+    {
+#pragma unroll
+      for (int s = 0; s < L; ++s)                            // the block the call starts in
+      {
+        const long long u = ub + s;
+        const FD d1 = (u >= u0 && u < u1) ? dch[ub - (long long)a.cursor0 + s] : (FD)0;
+        pv[s / NV][s % NV] = chain_step(f, d1, T1, T2);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next block's seed and differences: on their way while this one waits for its slot
+    const int gn = g + P;
+    cb += step_cb; if (cb >= span) cb -= span;
+    if (gn < nblocks)
+    {
+      sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
+      const long long ubn = (q0 + gn) * L;
+      if (ubn >= u0 && ubn + L <= u1)
+      {
+#pragma unroll
+        for (int s = 0; s < L; ++s) dl[s] = dch[ubn - (long long)a.cursor0 + s];
+      }
+    }
+    // the slot is free once the consumer has left block g - NB behind
+    if (g >= NB)
+    {
+      unsigned polls = 0;
+      while ((int)seen_consumed < g - NB + 1)
+      {
+        seen_consumed = ring_peek(&consumed_blocks);
+        if ((int)seen_consumed >= g - NB + 1) break;
+        if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    FD* pw = prod + pslot * L;
+#pragma unroll
+    for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
+    // publish: release store, i.e. the flag is written after the products have landed
+    if (lane == 0) __hip_atomic_store(&ready[pslot], (unsigned)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pslot += pstep; if (pslot >= NB) pslot -= NB;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // spectral window (sdft.h:350-402); e[] holds X[k-2] .. X[k+2] at index 0..4
 // ------------------------------------------------------------------------------------------
 template <typename FD, int WIN> SDFT_D cx<FD> window_tap(cx<FD> m2, cx<FD> m1, cx<FD> c0, cx<FD> p1, cx<FD> p2, FD w)
@@ -1142,6 +1383,7 @@ template <typename FD> struct ForwardArgs
   unsigned long long total_waves;
   unsigned nbins, chunks, chunk_len, tiles, interior_lanes, cursor0;
   unsigned chunk0, launch_chunks;   // this launch covers time chunks [chunk0, chunk0 + launch_chunks)
+  unsigned chunk_shift;             // chunk j > 0 starts at sample j*chunk_len - chunk_shift (exact carries, ring form; else 0)
   int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
   FD wscale;                  // weight (or weight*0.25 for Hann)
 };
@@ -1177,8 +1419,9 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(ForwardArgs<FD> a)
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
-  const size_t t0 = (size_t)chunk * a.chunk_len;
-  const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
+  const size_t t0 = chunk ? (size_t)chunk * a.chunk_len - a.chunk_shift : 0;
+  const size_t tn = (size_t)(chunk + 1) * a.chunk_len - a.chunk_shift;
+  const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
   // lane -> bins
@@ -1667,8 +1910,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
-  const size_t t0 = (size_t)chunk * a.chunk_len;
-  const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
+  const size_t t0 = chunk ? (size_t)chunk * a.chunk_len - a.chunk_shift : 0;
+  const size_t tn = (size_t)(chunk + 1) * a.chunk_len - a.chunk_shift;
+  const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group

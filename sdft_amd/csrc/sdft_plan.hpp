@@ -180,6 +180,7 @@ class Plan
   bool chain_attr[3] = {false, false, false};
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
   long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
   DevBuf<unsigned long long> d_chain_stats;
   long last_chain = 0;
 
@@ -414,9 +415,31 @@ class Plan
     if (!L) return false;
     unsigned pmax = 7;
     while (pmax > 1 && chain_lds(L, pmax) > kChainLdsBytes) --pmax;
+    if (opt_chain_ring) pmax = 7;                            // the ring's size does not depend on the producer count
     P = opt_chain_P > 0 ? std::min((unsigned)opt_chain_P, pmax) : std::min(6u, pmax);
     P = std::max(1u, P);
     return ((span / L) * nbins * sizeof(fdx)) <= ((size_t)256 << 20);      // seed table budget
+  }
+  // ring form: blocks of the LDS ring (about 384 steps of 4-byte products, 192 of 8-byte ones)
+  static unsigned ring_blocks(unsigned L)
+  {
+    const unsigned steps = sizeof(FD) == 4 ? 384u : 192u;
+    return std::max(4u, std::min((unsigned)kRingMaxBlocks, steps / L));
+  }
+  static size_t ring_lds(unsigned L, unsigned NB) { return (size_t)kWave * (NB * L + 16 / sizeof(FD)) * sizeof(FD); }
+  bool ring_attr[4] = {false, false, false, false};
+  template <int L> bool launch_ring(const ChainArgs<FD>& cc, unsigned blocks, hipStream_t on)
+  {
+    bool& raised = ring_attr[L == 8 ? 0 : (L == 16 ? 1 : (L == 32 ? 2 : 3))];
+    if (!raised)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&carry_ring_kernel<FD, L>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes));
+      raised = true;
+    }
+    hipLaunchKernelGGL((carry_ring_kernel<FD, L>), dim3(blocks), dim3(kWave * (cc.P + 1)), ring_lds(cc.L, cc.NB), on, cc);
+    SDFT_TRY(hipGetLastError());
+    return true;
   }
   template <int L> bool launch_chain(const ChainArgs<FD>& cc, unsigned blocks, hipStream_t on)
   {
@@ -461,8 +484,6 @@ class Plan
     last_segments = 1; last_fused = 0;
     if (chunks == 1 && opt_hop_kernel && nbins >= 2 && !fuse) return forward_hop(n, x, x_stride, out, out_stride, rows);
 
-    if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
-    if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
     const bool exact = (carry_mode == CARRY_EXACT);
     // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
     // leave most SIMDs idle; the plain serial pass when bins x channels already fill the chip
@@ -470,7 +491,19 @@ class Plan
     const size_t serial_waves = ((nb + kWave / 2 - 1) / (kWave / 2)) * channels;
     const bool use_chain = exact && chunks > 1 && opt_chain && fid_canonical && chain_geometry(cL, cP) &&
                            (opt_chain >= 2 || serial_waves <= 1024);
-    last_chain = use_chain;
+    // ring form: the chunk grid is shifted so that every chunk but the first starts on a block boundary
+    // of the cursor (chunk j starts at sample j*len - shift); one more chunk may be needed for the tail
+    const bool use_ring = use_chain && opt_chain_ring && !(opt_chain_debug & 19) && (len % (long)cL) == 0 && n < ((size_t)1 << 31);
+    // the ring form's cost per block (flag, slot, chunk counter) is paid half as often with blocks twice as long
+    unsigned rL = cL;
+    if (use_ring && opt_chain_L <= 0 && cL == (sizeof(FD) == 4 ? 32u : 16u) && span % (2 * cL) == 0 && len % (long)(2 * cL) == 0) rL = 2 * cL;
+    if (use_ring) cL = rL;
+    const unsigned shift = use_ring ? (unsigned)(cursor % cL) : 0u;
+    if (shift) { chunks = (long)((n + shift + (size_t)len - 1) / (size_t)len); last_chunks = chunks; }
+
+    if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
+    if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
+    last_chain = use_chain ? (use_ring ? 2 : 1) : 0;
     if ((exact || chunks == 1) && !use_chain && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
     if (use_chain && !ensure_fseed(cL)) return false;
 
@@ -542,11 +575,19 @@ class Plan
         cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
         cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
         cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
-        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.debug = (unsigned)opt_chain_debug & 3u; cc.stats = nullptr;
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 3u; cc.stats = nullptr;
         if (opt_chain_debug & 16) { if (!d_chain_stats.reserve(64)) return false; cc.stats = d_chain_stats.p; }
         const unsigned cblocks = eblocks * (unsigned)channels;
         bool ok = true;
-        if (cL == 32) { if constexpr (sizeof(FD) == 4) ok = launch_chain<32>(cc, cblocks, carry_stream); }
+        if (use_ring)
+        {
+          // ring form: blocks of 64 (FD float) / 32 (FD double) steps where the geometry allows
+          if (rL == 64) { if constexpr (sizeof(FD) == 4) ok = launch_ring<64>(cc, cblocks, carry_stream); }
+          else if (rL == 32) ok = launch_ring<32>(cc, cblocks, carry_stream);
+          else if (rL == 16) ok = launch_ring<16>(cc, cblocks, carry_stream);
+          else ok = launch_ring<8>(cc, cblocks, carry_stream);
+        }
+        else if (cL == 32) { if constexpr (sizeof(FD) == 4) ok = launch_chain<32>(cc, cblocks, carry_stream); }
         else if (cL == 16) ok = launch_chain<16>(cc, cblocks, carry_stream);
         else ok = launch_chain<8>(cc, cblocks, carry_stream);
         if (!ok) return false;
@@ -607,7 +648,7 @@ class Plan
     fa.acc_state = acc_p(); fa.fid_state = fid_p(); fa.n = n;
     fa.total_waves = (unsigned long long)channels * (unsigned long long)chunks * (unsigned long long)ntiles;
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
-    fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor;
+    fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor; fa.chunk_shift = shift;
     fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     last_segments = segments;
@@ -838,7 +879,7 @@ class Plan
   bool chain_stats(unsigned long long* out32)
   {
     if (!d_chain_stats.p) return false;
-    SDFT_TRY(hipMemcpy(out32, d_chain_stats.p, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SDFT_TRY(hipMemcpy(out32, d_chain_stats.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return true;
   }
 

@@ -109,15 +109,15 @@ def test_exact_carry_chain_form_bit_exact(combo, m, block):
     ch = 2
     lens = (3 * m + 5, 4 * m + 8 * 37, 555)                      # cursors at arbitrary offsets
     xb = np.stack([noise(sum(lens), seed=3 + c, dtype=td) for c in range(ch)])
-    for segments in (1, 3):
+    for segments, ring in ((1, 1), (3, 1), (1, 0), (3, 0)):  # products through the LDS ring / in rounds with a barrier each
         refs = [O.best(m, "blackman", 1.0, combo) for _ in range(ch)]
-        with make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=2, segments=segments) as p, \
+        with make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=2, segments=segments, chain_ring=ring) as p, \
              make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=0, segments=segments) as q:
             i = 0
             for n in lens:
                 seg = np.ascontiguousarray(xb[:, i:i + n])
                 got, old = p.sdft(seg), q.sdft(seg)
-                assert p.get_option("last_chain") == (1 if block else 0) and q.get_option("last_chain") == 0
+                assert p.get_option("last_chain") == ((2 if ring else 1) if block else 0) and q.get_option("last_chain") == 0
                 assert p.get_option("last_chunks") > 2 or m == 7
                 for c in range(ch):
                     want = refs[c].sdft(seg[c])
@@ -132,11 +132,12 @@ def test_exact_carry_chain_form_bit_exact(combo, m, block):
     if block:
         x = noise(5 * m + 77, seed=9, dtype=td)
         want = O.best(m, "hann", 1.0, combo).sdft(x)
-        for L, P in ((8, 1), (8, 7), (block if block < 32 or combo.endswith("f32") else 16, 2)):
-            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, chain_producers=P) as p:
+        for L, P, ring in ((8, 1, 1), (8, 7, 1), (8, 1, 0), (8, 7, 0), (block if block < 32 or combo.endswith("f32") else 16, 2, 1),
+                           (block if block < 32 or combo.endswith("f32") else 16, 2, 0)):
+            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, chain_producers=P, chain_ring=ring) as p:
                 got = p.sdft(x)
-                assert p.get_option("last_chain") == 1
-                assert np.array_equal(got, want), (combo, m, L, P)
+                assert p.get_option("last_chain") == (2 if ring else 1)
+                assert np.array_equal(got, want), (combo, m, L, P, ring)
 
 
 def test_exact_chain_falls_back_while_fid_is_off_the_canonical_sequence():
@@ -154,7 +155,7 @@ def test_exact_chain_falls_back_while_fid_is_off_the_canonical_sequence():
         b = p.sdft(x[700:700 + 5 * m])                           # serial pass (and crosses the roll-over)
         assert p.get_option("last_chain") == 0
         c = p.sdft(x[700 + 5 * m:])                              # back on the sequence: chain form
-        assert p.get_option("last_chain") == 1
+        assert p.get_option("last_chain") >= 1
         wb = ref.sdft(x[700:700 + 5 * m]); wc = ref.sdft(x[700 + 5 * m:])
         assert rel_err(b, wb) <= 1e-11 and rel_err(c, wc) <= 1e-11
     # from a clean start the same sequence of exact calls is bit-identical throughout
@@ -162,7 +163,7 @@ def test_exact_chain_falls_back_while_fid_is_off_the_canonical_sequence():
     with make(m, "hann", 1.0, "f32f64", chunk=64, carry=1, chain=2) as p:
         for lo, hi in ((0, 700), (700, 700 + 5 * m), (700 + 5 * m, 40 * m)):
             assert np.array_equal(p.sdft(x[lo:hi]), ref.sdft(x[lo:hi]))
-            assert p.get_option("last_chain") == 1
+            assert p.get_option("last_chain") >= 1
 
 
 @pytest.mark.parametrize("combo", ["f32f32", "f64f32", "f32f64"])
