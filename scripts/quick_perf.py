@@ -78,6 +78,15 @@ if __name__ == "__main__":
             for ch in (0, 96, 128, 160, 192, 256, 384):
                 run(48000, 1024, chunk=ch, reps=20)
         run(48000, 1024, fft_carry=0, reps=20)
+    if which == "ring64":
+        for L in (0, 16):
+            for P in (6, 7):
+                run(1000000, 1024, carry=1, segments=1, chain_block=L, chain_producers=P)
+                run(1000000, 1024, carry=1, chain_block=L, chain_producers=P)
+    if which == "ringdbg":
+        for dbg in (0, 4, 8):
+            run(262144, 1024, "hann", "f32f32", segments=1, chain_debug=dbg)
+            run(1000000, 1024, carry=1, segments=1, chain_debug=dbg)
     if which == "ringp":
         for P in (3, 4, 5, 6, 7):
             run(262144, 1024, "hann", "f32f32", chain_producers=P, segments=1)

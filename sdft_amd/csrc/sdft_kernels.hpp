@@ -807,10 +807,17 @@ SDFT_D float chain_step(float& f, float dl, float T1, float T2)
       : [dl] "s"(dl), [t1] "v"(T1), [t2] "v"(T2));
   return p;
 }
+// lane-pair partner without an `old` operand to set up (bound_ctrl; every lane of a quad has a source)
+SDFT_D double partner_nc(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 SDFT_D double chain_step(double& f, double dl, double T1, double T2)
 {
   const double p = f * dl;
-  const double g = partner(f);
+  const double g = partner_nc(f);
   const double m1 = f * T1;
   const double m2 = g * T2;
   f = m1 + m2;                                             // sdft.h:584
@@ -1127,6 +1134,7 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
   {
     // ---------------- consumer: the chain ----------------
     __builtin_amdgcn_s_setprio(3);
+    if (a.debug & 8u) return;                                // measurement aid: producers alone
     const cx<FD> acc0 = a.acc_state[ch * a.nbins + kk];
     FD acc = comp ? acc0.im : acc0.re;
     unsigned j = a.chunk0;
@@ -1139,6 +1147,7 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
     // of consecutive published blocks, or -1 when the poll budget ran out (sticky for the workgroup).
     auto await = [&](int have, int want) -> int
     {
+      if (a.debug & 4u) return want;                         // measurement aid: the consumer runs free (garbage results)
       unsigned polls = 0;
       for (;;)
       {
@@ -1215,7 +1224,7 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
 
   // ---------------- producers ----------------
   __builtin_amdgcn_s_setprio(2);
-  if (wave > P) return;
+  if (wave > P || (a.debug & 4u)) return;
   const cx<FD> tw = a.tw[kk];
   const FD T1 = tw.re;
   const FD T2 = comp ? tw.im : -tw.im;
@@ -1274,7 +1283,7 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
       }
     }
     // the slot is free once the consumer has left block g - NB behind
-    if (g >= NB)
+    if (g >= NB && !(a.debug & 8u))
     {
       unsigned polls = 0;
       while ((int)seen_consumed < g - NB + 1)

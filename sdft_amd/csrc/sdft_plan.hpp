@@ -416,7 +416,8 @@ class Plan
     unsigned pmax = 7;
     while (pmax > 1 && chain_lds(L, pmax) > kChainLdsBytes) --pmax;
     if (opt_chain_ring) pmax = 7;                            // the ring's size does not depend on the producer count
-    P = opt_chain_P > 0 ? std::min((unsigned)opt_chain_P, pmax) : std::min(6u, pmax);
+    // measured (ring form): FD float is consumer-bound from 5 producers on, FD double still gains from the 7th
+    P = opt_chain_P > 0 ? std::min((unsigned)opt_chain_P, pmax) : std::min((opt_chain_ring && sizeof(FD) == 8) ? 7u : 6u, pmax);
     P = std::max(1u, P);
     return ((span / L) * nbins * sizeof(fdx)) <= ((size_t)256 << 20);      // seed table budget
   }
@@ -575,7 +576,7 @@ class Plan
         cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
         cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
         cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
-        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 3u; cc.stats = nullptr;
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 15u; cc.stats = nullptr;
         if (opt_chain_debug & 16) { if (!d_chain_stats.reserve(64)) return false; cc.stats = d_chain_stats.p; }
         const unsigned cblocks = eblocks * (unsigned)channels;
         bool ok = true;
