@@ -78,6 +78,12 @@ if __name__ == "__main__":
             for ch in (0, 96, 128, 160, 192, 256, 384):
                 run(48000, 1024, chunk=ch, reps=20)
         run(48000, 1024, fft_carry=0, reps=20)
+    if which == "ringseg":
+        for sg in (2, 4, 6, 8, 12, 16):
+            run(262144, 4096, "blackman", "f32f32", segments=sg)
+        for sg in (2, 4, 8):
+            run(262144, 2048, "blackman", "f32f32", segments=sg)
+            run(262144, 1024, "hann", "f32f32", segments=sg)
     if which == "ring64":
         for L in (0, 16):
             for P in (6, 7):

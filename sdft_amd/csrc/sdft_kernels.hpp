@@ -1228,78 +1228,148 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
   const cx<FD> tw = a.tw[kk];
   const FD T1 = tw.re;
   const FD T2 = comp ? tw.im : -tw.im;
-  const SDFT_CONSTANT FD* dch = as_uniform(a.delta + ch * a.n);
   int g = wave - 1;                                          // this wave's block (relative to q0)
   if (g >= nblocks) return;
-  unsigned cb = (unsigned)(((q0 + g) * L) % span);           // its cursor, kept in 32 bits from here on
-  const unsigned step_cb = (unsigned)(((long long)P * L) % span);
-  cx<FD> sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
-  FD dl[L];
-#pragma unroll
-  for (int s = 0; s < L; ++s) dl[s] = (FD)0;
+  if constexpr (sizeof(FD) == 4)
   {
-    const long long ub = (q0 + g) * L;
-    if (ub >= u0 && ub + L <= u1)
-    {
+    // FD float: the block's differences sit in L scalar registers, requested one block ahead (FD double
+    // would need 64 of them for 32 steps and spills: it takes the vector form below)
+    const SDFT_CONSTANT FD* dch = as_uniform(a.delta + ch * a.n);
+    unsigned cb = (unsigned)(((q0 + g) * L) % span);         // its cursor, kept in 32 bits from here on
+    const unsigned step_cb = (unsigned)(((long long)P * L) % span);
+    cx<FD> sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
+    FD dl[L];
 #pragma unroll
-      for (int s = 0; s < L; ++s) dl[s] = dch[ub - (long long)a.cursor0 + s];
+    for (int s = 0; s < L; ++s) dl[s] = (FD)0;
+    {
+      const long long ub = (q0 + g) * L;
+      if (ub >= u0 && ub + L <= u1)
+      {
+#pragma unroll
+        for (int s = 0; s < L; ++s) dl[s] = dch[ub - (long long)a.cursor0 + s];
+      }
+    }
+    unsigned seen_consumed = 0;
+    int pslot = g % NB;                                        // ring slot of block g, advanced by P per block
+    const int pstep = P % NB;
+    for (; g < nblocks; g += P)
+    {
+      const long long ub = (q0 + g) * L;
+      FD f = comp ? sd.im : sd.re;
+      vec_t pv[VB];
+      if (ub >= u0 && ub + L <= u1)
+      {
+#pragma unroll
+        for (int s = 0; s < L; ++s) pv[s / NV][s % NV] = chain_step(f, dl[s], T1, T2);
+      }
+      else
+      {
+#pragma unroll
+        for (int s = 0; s < L; ++s)                            // the block the call starts in
+        {
+          const long long u = ub + s;
+          const FD d1 = (u >= u0 && u < u1) ? dch[ub - (long long)a.cursor0 + s] : (FD)0;
+          pv[s / NV][s % NV] = chain_step(f, d1, T1, T2);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the next block's seed and differences: on their way while this one waits for its slot
+      const int gn = g + P;
+      cb += step_cb; if (cb >= span) cb -= span;
+      if (gn < nblocks)
+      {
+        sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
+        const long long ubn = (q0 + gn) * L;
+        if (ubn >= u0 && ubn + L <= u1)
+        {
+#pragma unroll
+          for (int s = 0; s < L; ++s) dl[s] = dch[ubn - (long long)a.cursor0 + s];
+        }
+      }
+      // the slot is free once the consumer has left block g - NB behind
+      if (g >= NB && !(a.debug & 8u))
+      {
+        unsigned polls = 0;
+        while ((int)seen_consumed < g - NB + 1)
+        {
+          seen_consumed = ring_peek(&consumed_blocks);
+          if ((int)seen_consumed >= g - NB + 1) break;
+          if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      FD* pw = prod + pslot * L;
+#pragma unroll
+      for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
+      // publish: release store, i.e. the flag is written after the products have landed
+      if (lane == 0) __hip_atomic_store(&ready[pslot], (unsigned)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pslot += pstep; if (pslot >= NB) pslot -= NB;
     }
   }
-  unsigned seen_consumed = 0;
-  int pslot = g % NB;                                        // ring slot of block g, advanced by P per block
-  const int pstep = P % NB;
-  for (; g < nblocks; g += P)
+  else
   {
-    const long long ub = (q0 + g) * L;
-    FD f = comp ? sd.im : sd.re;
-    vec_t pv[VB];
-    if (ub >= u0 && ub + L <= u1)
+    // A block's differences travel in ONE vector register (lane s holds the block's step s; steps outside
+    // the launch read as 0) and are handed to the arithmetic by v_readlane, its seed in two; both are
+    // requested TWO blocks ahead.  Under a saturated HBM (the forward kernel of an earlier segment is
+    // streaming the matrix) a load takes microseconds: one block ahead left the producers waiting and
+    // stretched the pass by a third, and scalar loads cannot be queued that deep (64 SGPRs per block).
+    const FD* dvec = a.delta + ch * a.n;
+    auto load_delta = [&](int blk) -> FD
     {
-#pragma unroll
-      for (int s = 0; s < L; ++s) pv[s / NV][s % NV] = chain_step(f, dl[s], T1, T2);
-    }
-    else
+      const long long u = (q0 + blk) * L + lane;
+      const bool in = lane < L && blk < nblocks && u >= u0 && u < u1;
+      return in ? dvec[(size_t)(u - (long long)a.cursor0)] : (FD)0;
+    };
+    unsigned cb0 = (unsigned)(((q0 + g) * L) % span);          // cursors of blocks g, g+P, g+2P, kept in 32 bits
+    const unsigned step_cb = (unsigned)(((long long)P * L) % span);
+    unsigned cb1 = cb0 + step_cb; if (cb1 >= span) cb1 -= span;
+    unsigned cb2 = cb1 + step_cb; if (cb2 >= span) cb2 -= span;
+    auto load_seed = [&](unsigned cbx, int blk) -> cx<FD>
     {
+      return blk < nblocks ? a.fseed[(size_t)(cbx / L) * a.nbins + kk] : cmake<FD>((FD)1, (FD)0);
+    };
+    FD d0 = load_delta(g), d1 = load_delta(g + P), d2;
+    cx<FD> sd0 = load_seed(cb0, g), sd1 = load_seed(cb1, g + P), sd2;
+    unsigned seen_consumed = 0;
+    int pslot = g % NB;                                        // ring slot of block g, advanced by P per block
+    const int pstep = P % NB;
+    for (; g < nblocks; g += P)
+    {
+      d2 = load_delta(g + 2 * P);
+      sd2 = load_seed(cb2, g + 2 * P);
+      __builtin_amdgcn_sched_barrier(0);
+      FD f = comp ? sd0.im : sd0.re;
+      vec_t pv[VB];
 #pragma unroll
-      for (int s = 0; s < L; ++s)                            // the block the call starts in
+      for (int s = 0; s < L; ++s)
       {
-        const long long u = ub + s;
-        const FD d1 = (u >= u0 && u < u1) ? dch[ub - (long long)a.cursor0 + s] : (FD)0;
-        pv[s / NV][s % NV] = chain_step(f, d1, T1, T2);
+        FD dl;
+        if constexpr (sizeof(FD) == 4) dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), s));
+        else dl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d0), s), __builtin_amdgcn_readlane(__double2loint(d0), s));
+        pv[s / NV][s % NV] = chain_step(f, dl, T1, T2);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the next block's seed and differences: on their way while this one waits for its slot
-    const int gn = g + P;
-    cb += step_cb; if (cb >= span) cb -= span;
-    if (gn < nblocks)
-    {
-      sd = a.fseed[(size_t)(cb / L) * a.nbins + kk];
-      const long long ubn = (q0 + gn) * L;
-      if (ubn >= u0 && ubn + L <= u1)
+      __builtin_amdgcn_sched_barrier(0);
+      // the slot is free once the consumer has left block g - NB behind
+      if (g >= NB && !(a.debug & 8u))
       {
-#pragma unroll
-        for (int s = 0; s < L; ++s) dl[s] = dch[ubn - (long long)a.cursor0 + s];
+        unsigned polls = 0;
+        while ((int)seen_consumed < g - NB + 1)
+        {
+          seen_consumed = ring_peek(&consumed_blocks);
+          if ((int)seen_consumed >= g - NB + 1) break;
+          if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
+          __builtin_amdgcn_s_sleep(2);
+        }
       }
-    }
-    // the slot is free once the consumer has left block g - NB behind
-    if (g >= NB && !(a.debug & 8u))
-    {
-      unsigned polls = 0;
-      while ((int)seen_consumed < g - NB + 1)
-      {
-        seen_consumed = ring_peek(&consumed_blocks);
-        if ((int)seen_consumed >= g - NB + 1) break;
-        if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    FD* pw = prod + pslot * L;
+      FD* pw = prod + pslot * L;
 #pragma unroll
-    for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
-    // publish: release store, i.e. the flag is written after the products have landed
-    if (lane == 0) __hip_atomic_store(&ready[pslot], (unsigned)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    pslot += pstep; if (pslot >= NB) pslot -= NB;
+      for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
+      // publish: release store, i.e. the flag is written after the products have landed
+      if (lane == 0) __hip_atomic_store(&ready[pslot], (unsigned)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pslot += pstep; if (pslot >= NB) pslot -= NB;
+      d0 = d1; d1 = d2; sd0 = sd1; sd1 = sd2;
+      cb2 += step_cb; if (cb2 >= span) cb2 -= span;
+    }
   }
 }
 
