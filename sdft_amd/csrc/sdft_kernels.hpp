@@ -2155,7 +2155,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           SpectralOp<FD> shift_only; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
           shift_only.gain = nullptr; shift_only.shift = fz.op.shift;
           const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
-          terms[(size_t)u * term_stride + k] = keep[q][b] ? term : (FD)0;
+          terms[((size_t)buf * G + (size_t)u) * term_stride + k] = keep[q][b] ? term : (FD)0;
         }
       }
       if (SYN == 0 || fz.store)
@@ -2199,6 +2199,53 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     if constexpr (FUSED) return wrap ? step_wrap_fused(st, dl) : step_normal_fused(st, dl);
     else return wrap ? step_wrap(st, dl) : step_normal(st, dl);
   };
+
+  // SYN: sum over bins -> one output sample per row of a group whose terms are in buffer `tb`
+  auto sum_group = [&](int tb, int gm, size_t gt)
+  {
+    if constexpr (SYN != 0)
+    {
+      TD* yo = fz.y + ch * fz.y_stride + gt;
+      const FD* tbase = terms + (size_t)tb * G * term_stride;
+      if constexpr (SYN == 2)
+      {
+        // the reference's order (sdft.h:641-651): lane u of wave 0 adds sample u's terms bin by bin
+        if (wave == 0 && lane < gm)
+        {
+          typedef FD tvec __attribute__((ext_vector_type(16 / sizeof(FD))));
+          constexpr int NV = 16 / (int)sizeof(FD);
+          const FD* tr = tbase + (size_t)lane * term_stride;
+          FD sum = (FD)0;
+          for (unsigned k0 = 0; k0 < term_bins; k0 += 8 * NV)       // term_bins is a multiple of 64
+          {
+            tvec tv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const tvec*>(tr + k0 + i * NV);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int e = 0; e < NV; ++e) sum += tv[i][e];
+          }
+          yo[lane] = (TD)(sum * fz.sweight);                                   // sdft.h:654-656
+        }
+      }
+      else
+      {
+        // wave-parallel: wave u sums sample u (lane-strided partial sums, shuffle reduction)
+        for (int u = wave; u < gm; u += nwaves)
+        {
+          const FD* tr = tbase + (size_t)u * term_stride;
+          FD part = (FD)0;
+          for (unsigned k = lane; k < term_bins; k += kWave) part += tr[k];
+          const FD sum = wave_sum_f(part);
+          if (lane == 0) yo[u] = (TD)(sum * fz.sweight);
+        }
+      }
+    }
+  };
+  bool have_prev = false;
+  int prev_m = 0;
+  size_t prev_t = 0;
 
   int buf = 0;
   size_t t = t0;
@@ -2256,48 +2303,18 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     }
     if constexpr (SYN != 0)
     {
-      // phase C: sum over bins -> one output sample per row of the group.  (The next group's phase B
-      // cannot overwrite the terms before every wave has passed the next barrier, which this wave
-      // reaches only after its part of phase C.)
-      __syncthreads();
-      TD* yo = fz.y + ch * fz.y_stride + t;
-      if constexpr (SYN == 2)
-      {
-        // the reference's order (sdft.h:641-651): lane u of wave 0 adds sample u's terms bin by bin
-        if (wave == 0 && lane < m)
-        {
-          typedef FD tvec __attribute__((ext_vector_type(16 / sizeof(FD))));
-          constexpr int NV = 16 / (int)sizeof(FD);
-          const FD* tr = terms + (size_t)lane * term_stride;
-          FD sum = (FD)0;
-          for (unsigned k0 = 0; k0 < term_bins; k0 += 8 * NV)       // term_bins is a multiple of 64
-          {
-            tvec tv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const tvec*>(tr + k0 + i * NV);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-              for (int e = 0; e < NV; ++e) sum += tv[i][e];
-          }
-          yo[lane] = (TD)(sum * fz.sweight);                                   // sdft.h:654-656
-        }
-      }
-      else
-      {
-        // wave-parallel: wave u sums sample u (lane-strided partial sums, shuffle reduction)
-        for (int u = wave; u < m; u += nwaves)
-        {
-          const FD* tr = terms + (size_t)u * term_stride;
-          FD part = (FD)0;
-          for (unsigned k = lane; k < term_bins; k += kWave) part += tr[k];
-          const FD sum = wave_sum_f(part);
-          if (lane == 0) yo[u] = (TD)(sum * fz.sweight);
-        }
-      }
+      // phase C runs one group behind: the terms image is double-buffered, group g's terms are
+      // complete once every wave has passed the barrier of group g+1, so the walk over group g needs
+      // no barrier of its own and overlaps the other waves' recurrence of group g+1
+      if (have_prev) sum_group(buf ^ 1, prev_m, prev_t);
+      have_prev = true; prev_m = m; prev_t = t;
     }
     t += m;
     buf ^= 1;
+  }
+  if constexpr (SYN != 0)
+  {
+    if (have_prev) { __syncthreads(); sum_group(buf ^ 1, prev_m, prev_t); }      // the last group
   }
 
   if (chunk + 1 == a.chunks)

@@ -766,7 +766,7 @@ class Plan
   size_t syn_lds() const
   {
     const size_t padded = (size_t)row_waves() * kWave * bins_per_lane();
-    return (size_t)kSynGroup * (padded + 16 / sizeof(FD)) * sizeof(FD);
+    return (size_t)2 * kSynGroup * (padded + 16 / sizeof(FD)) * sizeof(FD);      // double-buffered
   }
   template <int WIN, bool FUSED, int SYN, bool LAT1>
   bool launch_syn_w(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
@@ -776,7 +776,7 @@ class Plan
     static thread_local int raised_on = -1;                  // dynamic LDS beyond 64 KiB has to be asked for (per device)
     if (raised_on != device)
     {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
       raised_on = device;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(), stream, fa, fz);
