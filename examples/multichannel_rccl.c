@@ -6,6 +6,10 @@
  *
  *   multichannel_rccl [channels_per_gpu=64] [n=48000] [dftsize=1024] [steps=5] [gpus=all]
  *
+ * Hosts without RCCL build with -DSDFT_NO_RCCL: the start/stop line then is a plain loop of
+ * hipStreamSynchronize over the devices (one host thread owns every stream, so nothing else is
+ * needed; RCCL only adds that the GPUs also rendezvous among themselves).
+ *
  * One host thread drives every GPU: plans run in async mode on their own streams, so the calls
  * return after enqueueing and all devices work concurrently.  Prints the aggregate Msamples/s and,
  * for verification, a checksum of the synthesis of channel 0 on device 0.
@@ -13,7 +17,9 @@
 
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
+#if !defined(SDFT_NO_RCCL)
 #include <rccl/rccl.h>
+#endif
 
 #include <math.h>
 #include <stdio.h>
@@ -25,7 +31,9 @@
 
 #define MAXDEV 16
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#if !defined(SDFT_NO_RCCL)
 #define CHECK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return 1; } } while (0)
+#endif
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -53,7 +61,10 @@ int main(int argc, char** argv)
   if (ndev > MAXDEV) ndev = MAXDEV;
   const size_t channels = per_gpu * (size_t)ndev;
 
-  sdft_t* plan[MAXDEV]; hipStream_t stream[MAXDEV]; ncclComm_t comm[MAXDEV];
+  sdft_t* plan[MAXDEV]; hipStream_t stream[MAXDEV];
+#if !defined(SDFT_NO_RCCL)
+  ncclComm_t comm[MAXDEV];
+#endif
   float *x[MAXDEV], *flag[MAXDEV]; sdft_fdx_t* dfts[MAXDEV];
   int devs[MAXDEV];
   float* host = (float*)malloc(per_gpu * n * sizeof(float));
@@ -74,6 +85,7 @@ int main(int argc, char** argv)
     for (size_t c = 0; c < per_gpu; ++c) sweep(host + c * n, n, (size_t)d * per_gpu + c, channels);
     CHECK_HIP(hipMemcpy(x[d], host, per_gpu * n * sizeof(float), hipMemcpyHostToDevice));
   }
+#if !defined(SDFT_NO_RCCL)
   CHECK_NCCL(ncclCommInitAll(comm, ndev, devs));
 
 #define BARRIER() do {                                                                            \
@@ -83,6 +95,12 @@ int main(int argc, char** argv)
     CHECK_NCCL(ncclGroupEnd());                                                                   \
     for (int d_ = 0; d_ < ndev; ++d_) { CHECK_HIP(hipSetDevice(d_)); CHECK_HIP(hipStreamSynchronize(stream[d_])); } \
   } while (0)
+#else
+  (void)devs;
+#define BARRIER() do {                                                                            \
+    for (int d_ = 0; d_ < ndev; ++d_) { CHECK_HIP(hipSetDevice(d_)); CHECK_HIP(hipStreamSynchronize(stream[d_])); } \
+  } while (0)
+#endif
 
   for (int d = 0; d < ndev; ++d) { CHECK_HIP(hipSetDevice(d)); sdft_sdft_n(plan[d], n, x[d], dfts[d]); }   /* warm-up */
   BARRIER();
@@ -102,6 +120,9 @@ int main(int argc, char** argv)
   for (size_t i = 0; i < n; ++i) checksum += (double)y[i] * (double)((i % 7) + 1);
   sdft_free(one);
 
+#if defined(SDFT_NO_RCCL)
+  printf("(no RCCL: host-side start line)  ");
+#endif
   printf("gpus=%d channels=%zu n=%zu dftsize=%zu steps=%d  %.3f ms/step  %.1f Msamples/s aggregate  checksum=%.9e\n",
          ndev, channels, n, m, steps, dt / steps * 1e3, (double)channels * n * steps / dt / 1e6, checksum);
 
@@ -109,7 +130,9 @@ int main(int argc, char** argv)
   {
     CHECK_HIP(hipSetDevice(d));
     sdft_free(plan[d]);
+#if !defined(SDFT_NO_RCCL)
     ncclCommDestroy(comm[d]);
+#endif
     (void)hipFree(x[d]); (void)hipFree(dfts[d]); (void)hipFree(flag[d]);
     (void)hipStreamDestroy(stream[d]);
   }

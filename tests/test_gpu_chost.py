@@ -169,21 +169,23 @@ def test_wav_tool_end_to_end(tmp_path, hip_library):
     assert np.array_equal(got_y, np.concatenate(ys))
 
 
-def test_multichannel_rccl_c_host(tmp_path, hip_library):
+@pytest.mark.parametrize("rccl", [True, False], ids=["rccl", "no_rccl"])
+def test_multichannel_rccl_c_host(tmp_path, hip_library, rccl):
     """examples/multichannel_rccl.c: the multi-channel config from a C host -- one batched plan per GPU,
-    RCCL only as a barrier (ncclCommInitAll + 1-element all-reduce).  Runs on however many GPUs the
-    box has (1 here); the synthesis checksum of channel 0 is compared with the oracle."""
+    RCCL only as a barrier (ncclCommInitAll + 1-element all-reduce), or -DSDFT_NO_RCCL: a host-side
+    start line and no librccl at all.  Runs on however many GPUs the box has (1 here); the synthesis
+    checksum of channel 0 is compared with the oracle."""
     import re
     from sdft_amd.signals import sine_sweep
     libdir = os.path.dirname(hip_library)
     rt = hip_runtime_dir()
     rocm = os.path.dirname(rt)
-    if not os.path.exists(os.path.join(rt, "librccl.so")):
+    if rccl and not os.path.exists(os.path.join(rt, "librccl.so")):
         pytest.skip("RCCL not present")
     exe = tmp_path / "multichannel_rccl"
-    cmd = ["gcc", "-std=gnu99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
+    cmd = ["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
            os.path.join(ROOT, "examples", "multichannel_rccl.c"), "-o", str(exe), "-L", libdir, "-lsdft_hip", "-L", rt,
-           "-lamdhip64", "-lrccl", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"]
+           "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"] + (["-lrccl"] if rccl else ["-DSDFT_NO_RCCL"])
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     per_gpu, n, m, steps = 3, 2000, 128, 2
