@@ -1957,7 +1957,7 @@ constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockste
 // lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
 constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
 
-// SYN (fused analysis -> operation -> synthesis; S == 1 only): 0 = rows are stored (the
+// SYN (fused analysis -> operation -> synthesis): 0 = rows are stored (the
 // plain forward kernel), 1 = the row is turned into the terms sdft_isdft adds (sdft.h:641-651), parked in
 // LDS and summed over bins by a wave-parallel tree, 2 = summed strictly in ascending bin order like the
 // reference (lane u of wave 0 walks sample u's terms: bit-identical to sdft_sdft_n + sdft_isdft_n, at the
@@ -1965,11 +1965,12 @@ constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 1
 template <typename FD, int BPL, int WIN, bool FUSED, int S, int SYN = 0, bool LAT1 = true, typename TD = float>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a, FuseArgs<TD, FD> fz)
 {
-  static_assert(SYN == 0 || S == 1, "the fused synthesis path is built for single-slot rows");
   constexpr int H = win_halo<WIN>::value;
-  // keeps registers roughly constant; the fused synthesis path always takes eight samples per group (its
-  // per-group cost is the walk over the bins, shared by as many lanes as there are samples)
-  constexpr int G = SYN != 0 ? kRowGroup : ((kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2);
+  // keeps registers roughly constant; the fused synthesis path takes eight samples per group whatever
+  // BPL is (its per-group cost is the walk over the bins, shared by as many lanes as there are samples)
+  // and four with two slots per lane (the double-buffered terms image of 2 x 4 padded rows of 2048 cx<double>
+  // / 4096 cx<float> bins is 128 KiB of LDS)
+  constexpr int G = SYN != 0 ? kRowGroup / S : ((kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2);
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
   constexpr int VW = kRowWavesMax * S;                    // virtual waves
   // edgeL[buf][u][v][i] = bin (first bin of virtual wave v) - 1 - i, edgeR[..][i] = (last bin) + 1 + i

@@ -363,10 +363,19 @@ class Plan
       const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves())
                                                       : (carry_mode == CARRY_EXACT ? 1024 : 512);   // exact: 4 overlap segments
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
-      want = std::max(1L, std::min(want, (long)(n / 192)));          // >= 192 samples per chunk
+      const bool mid = opt_target_waves <= 0 && channels * n < 36000;
+      // >= 192 samples per chunk; calls between a hop and the north star's 48000 samples are bound by the
+      // serial samples of one chunk (~0.36 us each), not by HBM: about 190 chunks of >= 32 samples
+      // (measured, N = 1024 f64: n = 1024 77 -> 31 us, 4096 77 -> 36, 12000 79 -> 53, 24000 95 -> 91)
+      if (mid) want = std::max(1L, std::min((190L + (long)channels - 1) / (long)channels, (long)(n / 32)));
+      else want = std::max(1L, std::min(want, (long)(n / 192)));
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
-      if (carry_mode == CARRY_EXACT) len = ((len + 31) / 32) * 32;   // whole trips of the exact pass's inner loop
+      if (carry_mode == CARRY_EXACT)
+      {
+        len = ((len + 31) / 32) * 32;                        // whole trips of the exact pass's inner loop
+        if (mid && len > 32) len = ((len + 63) / 64) * 64;   // whole blocks of the ring form at FD float
+      }
       len = std::max(1L, std::min(len, (long)n));
       chunks = (long)((n + len - 1) / len);
       return;
@@ -762,17 +771,23 @@ class Plan
 
   // fused analysis -> operation -> synthesis: the same kernel with SYN = 1 (tree sum over bins) or 2
   // (the reference's ascending order); the terms image lives in dynamic LDS
-  static constexpr int kSynGroup = kRowGroup;
   size_t syn_lds() const
   {
-    const size_t padded = (size_t)row_waves() * kWave * bins_per_lane();
-    return (size_t)2 * kSynGroup * (padded + 16 / sizeof(FD)) * sizeof(FD);      // double-buffered
+    const size_t group = (size_t)kRowGroup / (size_t)row_slots();               // samples per lockstep group (the kernel's G)
+    const size_t padded = (size_t)row_waves() * (size_t)row_slots() * kWave * bins_per_lane();
+    return (size_t)2 * group * (padded + 16 / sizeof(FD)) * sizeof(FD);          // double-buffered
   }
   template <int WIN, bool FUSED, int SYN, bool LAT1>
   bool launch_syn_w(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
   {
+    return row_slots() == 1 ? launch_syn_ws<WIN, FUSED, SYN, LAT1, 1>(fa, fz, blocks, threads)
+                            : launch_syn_ws<WIN, FUSED, SYN, LAT1, 2>(fa, fz, blocks, threads);
+  }
+  template <int WIN, bool FUSED, int SYN, bool LAT1, int S>
+  bool launch_syn_ws(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
+  {
     constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    auto kern = forward_rows_kernel<FD, BPL, WIN, FUSED, 1, SYN, LAT1, TD>;
+    auto kern = forward_rows_kernel<FD, BPL, WIN, FUSED, S, SYN, LAT1, TD>;
     static thread_local int raised_on = -1;                  // dynamic LDS beyond 64 KiB has to be asked for (per device)
     if (raised_on != device)
     {
@@ -833,10 +848,12 @@ class Plan
       return;
     }
     // the reference's summation order.  Measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16:
-    // 2.82, 64: 3.6 (130 VGPRs); float bins and medium calls do best with 16; short calls (a hop of
-    // 100 rows): one wave per row, the rows spread over the CUs
+    // 2.82, 64: 3.6 (130 VGPRs); float bins and medium calls do best with 16; below 64 Ki rows a wave
+    // with 16 rows and one tile of look-ahead is a chain of N/16 memory round trips (~70 us whatever
+    // n is): 4 rows with an 8-deep ring (n = 12000: 33 us against 79, n = 48000: 153 against 178,
+    // n = 131072: 397 against 355); short calls (a hop of 100 rows): one wave per row
     long rw = opt_inverse_rows > 0 ? opt_inverse_rows
-                                   : (total_rows <= 1024 ? 1 : total_rows < 4096 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
+                                   : (total_rows <= 1024 ? 1 : total_rows < 65536 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
     if (OPS && rw != 1) rw = 16;                                                 // one streaming instantiation with the operation built in
     size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
     eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
@@ -1132,7 +1149,7 @@ class Plan
   // params: OP_GAIN -> FD gains[N] (host or device memory), OP_SHIFT -> const long* (host).
   DevBuf<FD> d_gain;
   DevBuf<TD> d_stage_y;
-  bool fuse_ok() const { return rows_kernel_ok(false) && row_slots() == 1; }
+  bool fuse_ok() const { return rows_kernel_ok(false); }
 
   bool process_n(size_t n, const TD* x, TD* y, int op_kind, const void* params, fdx* dfts)
   {

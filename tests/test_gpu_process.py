@@ -100,6 +100,54 @@ def test_fused_exact_modes_are_bit_identical(combo, opts, window):
                     assert np.array_equal(y[c], want), (combo, window, m, op, shift, c, rel(y[c], want))
 
 
+@pytest.mark.parametrize("combo,opts,m,window", [("f32f32", {}, 4096, "blackman"), ("f32f32", {}, 2100, "hann"),
+                                                  ("f64f32", {}, 3000, "hamming"), ("f32f64", {"carry": 1}, 2048, "hann"),
+                                                  ("f64f64", {"carry": 1}, 1100, "blackman")])
+def test_fused_two_slot_rows_bit_identical(combo, opts, m, window):
+    """Rows of two slots per lane (1024 < N <= 2048 at FD double, 2048 < N <= 4096 at FD float; configs[2]
+    is N = 4096 Blackman FD float): the fused kernel takes four samples per lockstep group; exact carries
+    and the reference's summation order give the two reference calls bit for bit."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    n, ch = 2500, 2
+    gain = np.cos(np.arange(m) * 0.05).astype(fd)
+    xb = np.stack([noise(n, seed=11 + c, dtype=td) for c in range(ch)])
+    for latency, (op, shift) in ((1.0, OPS[0]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3])):
+        with make(m, window, latency, combo, ch, **opts) as p:
+            y = p.process(torch.from_numpy(xb).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+            assert p.get_option("last_process_path") == 1 and p.get_option("last_fused_exact") == 1
+            assert p.get_option("last_chunks") > 1
+            for c in range(ch):
+                want, _ = reference(O.best(m, window, latency, combo), xb[c], op, gain, shift)
+                assert np.array_equal(y[c], want), (combo, window, m, op, shift, c, rel(y[c], want))
+
+
+@pytest.mark.parametrize("combo,m", [("f32f64", 2048), ("f32f64", 1500), ("f32f32", 4096)])
+def test_fused_two_slot_rows_tree_sum(combo, m):
+    """Two-slot rows with the wave-parallel sum over bins (the default of the chunk-parallel FD double path;
+    on request for FD float), with and without a copy of the processed spectrum."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    n = 4000
+    x = sine_sweep(n, dtype=td)
+    gain = np.linspace(0.5, 1.5, m).astype(fd)
+    cdt = torch.complex128 if combo[3:] == "f64" else torch.complex64
+    for op, shift in OPS:
+        want, wd = reference(O.best(m, "hann", 1.0, combo), x, op, gain, shift)
+        with make(m, "hann", 1.0, combo, fused_exact=0) as p:
+            xd = torch.from_numpy(x).cuda()
+            y = p.process(xd, op, gain=gain, shift=shift)
+            assert p.get_option("last_process_path") == 1 and p.get_option("last_fused_exact") == 0
+            assert rel(y.cpu().numpy(), want) <= TOL[combo[3:]], (combo, m, op, shift)
+            if op != "shift":
+                p.reset()
+                dd = torch.empty((n, m), dtype=cdt, device="cuda")
+                y = p.process(xd, op, gain=gain, dfts=dd)
+                assert rel(y.cpu().numpy(), want) <= TOL[combo[3:]]
+                tol = 1e-11 if combo[3:] == "f64" else 0.0          # FD float analysis is bit-identical
+                assert float(np.abs(dd.cpu().numpy() - wd).max()) <= tol * float(np.abs(wd).max())
+
+
 @pytest.mark.parametrize("combo", O.COMBOS)
 def test_hop_sized_calls_and_host_pointers(combo):
     """Calls of one time chunk (the reference's hop loop, test/test.c:69-83): hop kernel + one-wave-per-row
@@ -122,8 +170,8 @@ def test_hop_sized_calls_and_host_pointers(combo):
 
 
 def test_shapes_outside_the_fused_kernel_take_the_two_pass_path():
-    """Rows longer than one slot per lane (m = 4096 at FD double) and tiny rows: analysis + synthesis
-    through the bounded workspace, same results."""
+    """Rows longer than two slots per lane (m = 4096 at FD double) and tiny rows: analysis + synthesis
+    through the bounded workspace, same results (m = 3000 at FD float is a two-slot fused shape)."""
     import torch
     for m, n, combo in ((4096, 3000, "f32f64"), (5, 900, "f32f32"), (3000, 2000, "f32f32")):
         td, fd, fdx = O.combo_types(combo)
