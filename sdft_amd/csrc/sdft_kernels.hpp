@@ -1949,6 +1949,9 @@ constexpr int kRowWavesMax = 16;
 #ifndef SDFT_ROW_GROUP
 #define SDFT_ROW_GROUP 8
 #endif
+#ifndef SDFT_SYN_GROUP_S2F
+#define SDFT_SYN_GROUP_S2F 2
+#endif
 constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockstep group (one barrier each)
 
 // Rows longer than 1024*BPL bins: every lane owns S "slots"; slot q of physical wave w is the
@@ -1956,6 +1959,8 @@ constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockste
 // are indexed by virtual wave, so slot boundaries are crossed exactly like wave boundaries.  The
 // lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
 constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
+// samples per lockstep group of the fused synthesis path (the plan sizes the terms image with it)
+constexpr int syn_group(int S, int BPL, int SYN) { return (S == 2 && BPL == 2 && SYN == 1) ? SDFT_SYN_GROUP_S2F : kRowGroup / S; }
 
 // SYN (fused analysis -> operation -> synthesis): 0 = rows are stored (the
 // plain forward kernel), 1 = the row is turned into the terms sdft_isdft adds (sdft.h:641-651), parked in
@@ -1970,7 +1975,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // BPL is (its per-group cost is the walk over the bins, shared by as many lanes as there are samples)
   // and four with two slots per lane (the double-buffered terms image of 2 x 4 padded rows of 2048 cx<double>
   // / 4096 cx<float> bins is 128 KiB of LDS)
-  constexpr int G = SYN != 0 ? kRowGroup / S : ((kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2);
+  constexpr int G = SYN != 0 ? syn_group(S, BPL, SYN) : ((kRowGroup / (S * BPL)) >= 2 ? kRowGroup / (S * BPL) : 2);
   constexpr int HS = 2;                                   // edge slots per side (H <= 2)
   constexpr int VW = kRowWavesMax * S;                    // virtual waves
   // edgeL[buf][u][v][i] = bin (first bin of virtual wave v) - 1 - i, edgeR[..][i] = (last bin) + 1 + i

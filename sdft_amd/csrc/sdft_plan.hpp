@@ -132,7 +132,8 @@ class Plan
   long opt_chunk = 0;            // forced chunk length (0 = heuristic)
   long opt_interior = 0;         // forced interior lanes per wave (0 = maximum)
   long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
-  size_t stage_bytes = (size_t)1 << 30;   // host-pointer path: staging segment size
+  static constexpr size_t kDefaultStageBytes = (size_t)1 << 30;
+  size_t stage_bytes = kDefaultStageBytes;   // host-pointer path: staging segment size
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
   long opt_pointers = 0;         // 0 = detect per call (hipPointerGetAttributes), 1 = all device, 2 = all host
@@ -771,9 +772,9 @@ class Plan
 
   // fused analysis -> operation -> synthesis: the same kernel with SYN = 1 (tree sum over bins) or 2
   // (the reference's ascending order); the terms image lives in dynamic LDS
-  size_t syn_lds() const
+  size_t syn_lds(int syn) const
   {
-    const size_t group = (size_t)kRowGroup / (size_t)row_slots();               // samples per lockstep group (the kernel's G)
+    const size_t group = (size_t)syn_group((int)row_slots(), (int)bins_per_lane(), syn);   // samples per lockstep group (the kernel's G)
     const size_t padded = (size_t)row_waves() * (size_t)row_slots() * kWave * bins_per_lane();
     return (size_t)2 * group * (padded + 16 / sizeof(FD)) * sizeof(FD);          // double-buffered
   }
@@ -794,7 +795,7 @@ class Plan
       SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
       raised_on = device;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(), stream, fa, fz);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(SYN), stream, fa, fz);
     SDFT_TRY(hipGetLastError());
     return true;
   }
@@ -1194,7 +1195,12 @@ class Plan
     bool ok;
     long chunks, len;
     choose_chunks(n, chunks, len, rows_kernel_ok(false));
-    if (fuse_ok() && chunks > 1)
+    // two-slot rows at FD float with exact carries: the ordered walk (N dependent additions shared by the
+    // four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144: 5.7 ms
+    // against 4.2 ms for the two passes); the two-pass path gives the same bits.  Option fused_exact
+    // = 0 (tree sum, 4.0 ms) or 1 still selects the fused kernel.
+    const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact < 0;
+    if (fuse_ok() && chunks > 1 && !walk_loses)
     {
       FuseArgs<TD, FD> fz;
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
@@ -1208,6 +1214,19 @@ class Plan
       // workspace, synthesis with the operation applied on the way in
       const size_t row_elems = channels * nbins;
       size_t seg = dfts ? n : std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(row_elems * sizeof(fdx), 1)));
+      if (!dfts && seg < n && stage_bytes == kDefaultStageBytes)
+      {
+        // long calls run best in one piece (time segments restart the carry pipeline): unless the host
+        // has bounded it (option stage_bytes), the workspace may take up to half of what the device has free
+        if (d_stage_fdx.cap >= row_elems * n) seg = n;
+        else
+        {
+          size_t free_b = 0, total_b = 0;
+          if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            seg = std::max(seg, std::min(n, (free_b / 2) / std::max<size_t>(row_elems * sizeof(fdx), 1)));
+          (void)hipGetLastError();
+        }
+      }
       if (channels > 1 && !dfts) seg = n;                    // batched layout: channel stride = n rows (workspace holds the call)
       if (!dfts && !d_stage_fdx.reserve(row_elems * seg)) return false;
       last_process_path = (chunks == 1) ? 2 : 3;
