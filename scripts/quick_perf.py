@@ -103,6 +103,12 @@ if __name__ == "__main__":
                     pl.synchronize(); dt = (time.perf_counter() - t0) / 50
                     print(f"{combo} n={n} chunk={ch} -> chunks={pl.get_option('last_chunks')} len={pl.get_option('last_chunk_len')}: {dt*1e6:.1f} us per call ({n*1024*out.element_size()/dt/1e12:.2f} TB/s)", flush=True)
                     pl.close()
+    if which == "segs":
+        for ch, sg in ((0, 0), (128, 8), (128, 4), (128, 16), (192, 6), (64, 8), (64, 16), (256, 8)):
+            run(262144, 4096, "blackman", "f32f32", chunk=ch, segments=sg)
+        for ch, sg in ((0, 0), (128, 8), (128, 16), (64, 16)):
+            run(262144, 1024, "hann", "f32f32", chunk=ch, segments=sg)
+            run(1000000, 1024, carry=1, chunk=ch * 2, segments=sg)
     if which == "syn2":
         # two-slot rows through the fused call, next to the two calls
         run_process(262144, 4096, "blackman", "f32f32")
@@ -376,6 +382,23 @@ if __name__ == "__main__":
                     pl.synchronize(); dt = (time.perf_counter() - t0) / 50
                     print(f"{combo} n={n} chunk={ch} -> chunks={pl.get_option('last_chunks')} len={pl.get_option('last_chunk_len')}: {dt*1e6:.1f} us per call ({n*1024*out.element_size()/dt/1e12:.2f} TB/s)", flush=True)
                     pl.close()
+    if which == "segs":
+        for ch, sg in ((0, 0), (128, 8), (128, 4), (128, 16), (192, 6), (64, 8), (64, 16), (256, 8)):
+            run(262144, 4096, "blackman", "f32f32", chunk=ch, segments=sg)
+        for ch, sg in ((0, 0), (128, 8), (128, 16), (64, 16)):
+            run(262144, 1024, "hann", "f32f32", chunk=ch, segments=sg)
+            run(1000000, 1024, carry=1, chunk=ch * 2, segments=sg)
+    if which == "vecd":
+        for dbg in (0, 32, 0, 32):
+            for P in (6, 7):
+                run(262144, 4096, "blackman", "f32f32", chain_debug=dbg, chain_producers=P)
+                run(262144, 1024, "hann", "f32f32", chain_debug=dbg, chain_producers=P, segments=1)
+    if which == "excl":
+        for ex in (0, 1, 0, 1):
+            run(262144, 4096, "blackman", "f32f32", chain_exclusive=ex)
+            run(262144, 4096, "blackman", "f32f32", chain_exclusive=ex, chunk=128, segments=8)
+            run(262144, 2048, "blackman", "f32f32", chain_exclusive=ex)
+            run(1000000, 1024, carry=1, chain_exclusive=ex)
     if which == "syn2":
         # two-slot rows through the fused call, next to the two calls
         run_process(262144, 4096, "blackman", "f32f32")

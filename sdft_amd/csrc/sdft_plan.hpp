@@ -361,15 +361,17 @@ class Plan
       // row-group kernel: one workgroup per (channel, chunk).  The forward kernel does not care
       // (256 ... 2048 workgroups: 2.91-2.95 ms at n = 1e6), the carry pre-pass gets cheaper with
       // fewer chunks (1017 chunks 0.044 ms, 511 chunks 0.029 ms): two rounds of the 256 CUs
+      // exact carries: 8 overlap segments of >= 256 workgroups (N = 4096 f32, n = 262144: 1024 chunks in 4
+      // segments 2.52 ms, 2048 in 8 2.40; FD double with carry = 1, n = 1e6: 10.4 -> 9.7 ms)
       const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves())
-                                                      : (carry_mode == CARRY_EXACT ? 1024 : 512);   // exact: 4 overlap segments
+                                                      : (carry_mode == CARRY_EXACT ? 2048 : 512);
       long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
       const bool mid = opt_target_waves <= 0 && channels * n < 36000;
       // >= 192 samples per chunk; calls between a hop and the north star's 48000 samples are bound by the
       // serial samples of one chunk (~0.36 us each), not by HBM: about 190 chunks of >= 32 samples
       // (measured, N = 1024 f64: n = 1024 77 -> 31 us, 4096 77 -> 36, 12000 79 -> 53, 24000 95 -> 91)
       if (mid) want = std::max(1L, std::min((190L + (long)channels - 1) / (long)channels, (long)(n / 32)));
-      else want = std::max(1L, std::min(want, (long)(n / 192)));
+      else want = std::max(1L, std::min(want, (long)(n / (carry_mode == CARRY_EXACT ? 128 : 192))));
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
       if (carry_mode == CARRY_EXACT)
