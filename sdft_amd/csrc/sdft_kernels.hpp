@@ -2351,6 +2351,231 @@ template <typename FD> SDFT_D FD wave_sum(FD v)
   return v;
 }
 
+// ------------------------------------------------------------------------------------------
+// K3 (folded form)  analysis -> operation -> synthesis without ever forming the windowed spectrum.
+//
+// Everything after the demodulation X = acc * conj(fid) is linear: the window is a 3- or 5-tap
+// convolution over bins (sdft.h:350-402) whose out-of-range taps are conjugate mirror images (:589-595),
+// the supported operations are a real gain per bin or a shift of bins, and sdft_isdft adds, for every bin,
+// re(Y) * (+-1) (latency 1, :643) or re(Y * twiddle) (:650).  So one output sample is
+//     y = sweight * sum over bins r of ( alpha[r] * re X[r] + beta[r] * im X[r] )
+// with coefficients that depend on the plan and the operation only (fold_coeff_kernel; beta == 0 for
+// latency 1).  Per bin and sample that leaves the recurrence, two products for re X and one
+// multiply-add: no neighbour exchange, no window arithmetic, no edge slots -- 9 instead of ~45 vector
+// instructions per bin-sample at FD double.  The sum over bins: every lane adds its own J bins, a wave
+// transposes its G x 64 partial sums through a private LDS tile (lane (u, s) adds eight of sample u's
+// values, three shuffles finish the row), the waves' sums meet in a small table, one barrier per group
+// of G samples.  The order of the additions differs from the reference's: this is the tree-sum flavour
+// of the fused call (not bit-identical; the ordered walk stays with forward_rows_kernel<SYN = 2>).
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD> struct ProcArgs
+{
+  TD* y;                      // [channels][n]
+  size_t y_stride;
+  const FD* alpha;            // [N]
+  const FD* beta;             // [N]
+  FD sweight;
+};
+
+// alpha / beta for source bin r: every virtual position m whose mirror image is r (m = r, and m = -r or
+// 2(N-1) - r at the ends), every tap i, output bin j = m - i inside the spectrum; A/B of an output bin are
+// what sdft_isdft multiplies re / im of that bin with, after the operation.
+template <typename FD>
+__global__ __launch_bounds__(kBlock) void fold_coeff_kernel(FD* alpha, FD* beta, SpectralOp<FD> op, const cx<FD>* syn,
+                                                            unsigned nbins, int lat1, FD h0, FD h1, FD h2)
+{
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x, N = (long)nbins;
+  if (r >= N) return;
+  const FD h[5] = {h2, h1, h0, h1, h2};
+  FD al = (FD)0, be = (FD)0;
+  auto add_position = [&](long m, bool flip)
+  {
+    for (int i = -2; i <= 2; ++i)
+    {
+      const long j = m - i;                                 // Y[j] takes tap i from position j + i = m
+      if (j < 0 || j >= N) continue;
+      const long ko = j + (op.kind == OP_SHIFT ? op.shift : 0);
+      if (ko < 0 || ko >= N) continue;                      // shifted out of the spectrum
+      FD A, B;
+      if (lat1) { A = (ko & 1) ? (FD)(-1) : (FD)(+1); B = (FD)0; }           // sdft.h:643
+      else { A = syn[ko].re; B = -syn[ko].im; }                              // re(Y * twiddle), :650
+      if (op.kind == OP_GAIN) { A *= op.gain[j]; B *= op.gain[j]; }
+      al += h[i + 2] * A;
+      be += (flip ? -(h[i + 2] * B) : h[i + 2] * B);        // the mirror image is the conjugate
+    }
+  };
+  add_position(r, false);
+  if (r >= 1 && r <= 2) add_position(-r, true);
+  const long mr = 2 * (N - 1) - r;
+  if (mr >= N && mr <= N + 1) add_position(mr, true);
+  alpha[r] = al;
+  beta[r] = be;
+}
+
+constexpr int kProcGroup = 8;            // samples per lockstep group
+constexpr int kProcRow = 72;             // padded row of the transpose tile: 8 segments of 8 + 1
+
+template <typename TD, typename FD, int J, bool FUSED, bool HASB>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz)
+{
+  constexpr int G = kProcGroup;
+  __shared__ FD tile[kRowWavesMax][G * kProcRow];
+  __shared__ FD part[2][G][kRowWavesMax];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const unsigned chunk = a.chunk0 + blockIdx.x % a.launch_chunks;
+  const size_t ch = blockIdx.x / a.launch_chunks;
+
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  const size_t t0 = chunk ? (size_t)chunk * a.chunk_len - a.chunk_shift : 0;
+  const size_t tn = (size_t)(chunk + 1) * a.chunk_len - a.chunk_shift;
+  const size_t t1 = tn < a.n ? tn : a.n;
+  unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
+
+  for (int i = threadIdx.x; i < 2 * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (FD)0;   // waves that do not exist add 0
+
+  BinState<FD> s[J];
+  FD al[J], be[J];
+  bool live[J];
+  const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+  {
+    const unsigned k = (unsigned)((j * nwaves + wave) * kWave + lane);         // strided: coalesced loads
+    live[j] = k < a.nbins;
+    const unsigned kk = live[j] ? k : 0u;
+    s[j].tw = a.tw[kk];
+    s[j].acc = a.carry[cbase + kk];
+    s[j].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, (long)kk, c, s[j].tw)
+             : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+    al[j] = pz.alpha[kk];
+    be[j] = pz.beta[kk];
+    if (!live[j])
+    {
+      s[j].tw = cmake<FD>((FD)0, (FD)0); s[j].acc = s[j].tw; s[j].fid = s[j].tw;
+      al[j] = (FD)0; be[j] = (FD)0;
+    }
+  }
+  __syncthreads();
+
+  // one sample: the recurrence (sdft.h:566-587) for this lane's bins, then their share of the output sample
+  auto step_all = [&](FD dl, bool wrap) -> FD
+  {
+    FD vv = (FD)0;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+    {
+      BinState<FD>& b = s[j];
+      if constexpr (FUSED)
+      {
+        b.acc.re = __builtin_fma(b.fid.re, dl, b.acc.re);
+        b.acc.im = __builtin_fma(b.fid.im, dl, b.acc.im);
+        if (wrap) b.fid = cmake<FD>((FD)1, (FD)0);
+        else
+        {
+          const FD nr = __builtin_fma(b.fid.re, b.tw.re, -(b.fid.im * b.tw.im));
+          const FD ni = __builtin_fma(b.fid.re, b.tw.im, b.fid.im * b.tw.re);
+          b.fid.re = nr; b.fid.im = ni;
+        }
+        const FD xr = __builtin_fma(b.acc.re, b.fid.re, b.acc.im * b.fid.im);          // re(acc * conj(fid))
+        vv = __builtin_fma(al[j], xr, vv);
+        if constexpr (HASB)
+        {
+          const FD xi = __builtin_fma(b.acc.im, b.fid.re, -(b.acc.re * b.fid.im));
+          vv = __builtin_fma(be[j], xi, vv);
+        }
+      }
+      else
+      {
+        if (wrap) advance_wrap(b, dl); else advance_normal(b, dl);                     // the stream state stays exact
+        const FD xr = b.acc.re * b.fid.re + b.acc.im * b.fid.im;
+        vv += al[j] * xr;
+        if constexpr (HASB)
+        {
+          const FD xi = b.acc.im * b.fid.re - b.acc.re * b.fid.im;
+          vv += be[j] * xi;
+        }
+      }
+    }
+    return vv;
+  };
+
+  const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+  TD* yo = pz.y + ch * pz.y_stride;
+  FD* my = tile[wave];
+  const int ru = lane >> 3, rs = lane & 7;                 // transposed role: sample of the group, segment of the row
+  int pbuf = 0;
+  unsigned gi = 0;
+  size_t t = t0;
+  while (t < t1)                       // all waves of the group take identical trip counts
+  {
+    const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
+    FD v[G];
+    if (m == G && c + G <= maxc)
+    {
+      FD dl[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) dl[u] = d[t + u];
+#pragma unroll
+      for (int u = 0; u < G; ++u) v[u] = step_all(dl[u], false);
+      c += G;
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+      {
+        v[u] = (FD)0;
+        if (u < m)
+        {
+          const FD dl = d[t + u];
+          const bool wrap = (c == maxc);
+          v[u] = step_all(dl, wrap);
+          c = wrap ? 0 : c + 1;
+        }
+      }
+    }
+    // this wave's 64 partial sums per sample -> one sum per sample (LDS operations of one wave execute in order)
+#pragma unroll
+    for (int u = 0; u < G; ++u) my[u * kProcRow + lane + (lane >> 3)] = v[u];
+    FD sum = (FD)0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += my[ru * kProcRow + rs * 9 + e];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    if (rs == 0) part[pbuf][ru][wave] = sum;
+    __syncthreads();
+    // the waves take turns adding the per-wave sums (the table is double-buffered: the next group writes the
+    // other half, and nobody gets to the group after that before this wave has passed the next barrier)
+    if (wave == (int)(gi % (unsigned)nwaves))
+    {
+      FD p = part[pbuf][ru][rs] + part[pbuf][ru][rs + 8];
+      p += __shfl_xor(p, 1, 64);
+      p += __shfl_xor(p, 2, 64);
+      p += __shfl_xor(p, 4, 64);
+      if (rs == 0 && ru < m) yo[t + ru] = (TD)(p * pz.sweight);                 // sdft.h:654-656
+    }
+    t += m;
+    pbuf ^= 1;
+    ++gi;
+  }
+
+  if (chunk + 1 == a.chunks)
+  {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (live[j])
+      {
+        const size_t k = (size_t)((j * nwaves + wave) * kWave + lane);
+        a.acc_state[ch * a.nbins + k] = s[j].acc;
+        a.fid_state[ch * a.nbins + k] = s[j].fid;
+      }
+  }
+}
+
 // rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
 template <typename FD>
 __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain)

@@ -146,7 +146,7 @@ class Plan
   long opt_hop_kernel = 1;       // single-chunk calls: fused delta + forward launch (forward_hop_kernel)
   long opt_fused_exact = -1;     // fused analysis->synthesis: bins summed in the reference's order (1), by a tree (0),
                                  // or (-1) in order exactly when the analysis itself is bit-exact (exact carries)
-  long last_fused_exact = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
+  long last_fused_exact = 0, last_fused_fold = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
@@ -181,6 +181,7 @@ class Plan
   bool chain_attr[3] = {false, false, false};
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
   long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
   DevBuf<unsigned long long> d_chain_stats;
   long last_chain = 0;
@@ -681,7 +682,13 @@ class Plan
         // rows never leave the workgroup: synthesis in the same launch (caller checked fuse_ok())
         const bool exact_order = opt_fused_exact < 0 ? use_seed : opt_fused_exact != 0;
         last_fused_exact = exact_order;
-        if (!launch_syn(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused && !exact_order, exact_order))
+        const bool folded = !exact_order && !fuse->store && opt_fold && coeff_ready;
+        last_fused_fold = folded;
+        if (folded)
+        {
+          if (!launch_process(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), fused)) return false;
+        }
+        else if (!launch_syn(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused && !exact_order, exact_order))
           return false;
       }
       else if (use_rows) launch_forward_rows(fa, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused);
@@ -821,6 +828,59 @@ class Plan
       if (fused) return lat1 ? launch_syn_t<true, 1, true>(fa, fz, blocks, threads) : launch_syn_t<true, 1, false>(fa, fz, blocks, threads);
     }
     return lat1 ? launch_syn_t<false, 1, true>(fa, fz, blocks, threads) : launch_syn_t<false, 1, false>(fa, fz, blocks, threads);
+  }
+
+  // folded form of the fused call (process_rows_kernel): per-bin coefficients from the plan's window and
+  // synthesis tables and the call's operation, then one launch per overlap segment
+  DevBuf<FD> d_alpha, d_beta;
+  bool coeff_ready = false;
+  int coeff_kind = -1; long coeff_shift = 0;
+  bool fold_coefficients(const SpectralOp<FD>& op)
+  {
+    coeff_ready = false;
+    if (!opt_fold || nbins < 8) return true;
+    // identity and shift depend on the plan only: folded once; a gain array may change between calls
+    if (op.kind != OP_GAIN && coeff_kind == op.kind && coeff_shift == op.shift && d_alpha.p) { coeff_ready = true; return true; }
+    if (!d_alpha.reserve(nbins) || !d_beta.reserve(nbins)) return false;
+    const FD w = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // as ForwardArgs::wscale
+    FD h0 = w, h1 = (FD)0, h2 = (FD)0;                                                   // taps of window_tap()
+    if (window == WIN_HANN) { h0 = w + w; h1 = -w; }
+    else if (window == WIN_HAMMING) { h0 = (FD)(0.54) * w; h1 = -((FD)(0.23) * w); }
+    else if (window == WIN_BLACKMAN) { h0 = (FD)(0.42) * w; h1 = -((FD)(0.25) * w); h2 = (FD)(0.04) * w; }
+    hipLaunchKernelGGL((fold_coeff_kernel<FD>), dim3((unsigned)((nbins + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       d_alpha.p, d_beta.p, op, (const fdx*)d_syn.p, (unsigned)nbins, latency == 1 ? 1 : 0, h0, h1, h2);
+    SDFT_TRY(hipGetLastError());
+    coeff_kind = op.kind; coeff_shift = op.shift;
+    coeff_ready = true;
+    return true;
+  }
+  template <int J, bool FUSED, bool HASB>
+  void launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads)
+  {
+    hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB>), dim3(blocks), dim3(threads), 0, stream, fa, pz);
+  }
+  template <bool FUSED, bool HASB>
+  void launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots)
+  {
+    if (slots <= 1) launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads);
+    else if (slots == 2) launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads);
+    else launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads);
+  }
+  bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused)
+  {
+    ProcArgs<TD, FD> pz;
+    pz.y = fz.y; pz.y_stride = fz.y_stride; pz.alpha = d_alpha.p; pz.beta = d_beta.p; pz.sweight = fz.sweight;
+    const long waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
+    const long slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
+    const unsigned threads = (unsigned)(waves * kWave);
+    const bool hasb = !(latency == 1);
+    if constexpr (sizeof(FD) == 8)
+    {
+      if (fused) { if (hasb) launch_process_t<true, true>(fa, pz, blocks, threads, slots); else launch_process_t<true, false>(fa, pz, blocks, threads, slots); SDFT_TRY(hipGetLastError()); return true; }
+    }
+    if (hasb) launch_process_t<false, true>(fa, pz, blocks, threads, slots); else launch_process_t<false, false>(fa, pz, blocks, threads, slots);
+    SDFT_TRY(hipGetLastError());
+    return true;
   }
 
   template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
@@ -1206,6 +1266,7 @@ class Plan
     {
       FuseArgs<TD, FD> fz;
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
+      if (!dfts) { if (!fold_coefficients(op)) return false; } else coeff_ready = false;
       last_process_path = 1;
       ok = forward_device(n, xs, n, dfts, n * nbins, nullptr, &fz);
     }

@@ -153,6 +153,54 @@ def test_fused_two_slot_rows_tree_sum(combo, m):
                 assert float(np.abs(dd.cpu().numpy() - wd).max()) <= tol * float(np.abs(wd).max())
 
 
+@pytest.mark.parametrize("window", ["hann", "hamming", "blackman", "boxcar"])
+@pytest.mark.parametrize("combo,m", [("f32f64", 1024), ("f32f64", 1000), ("f32f64", 72), ("f32f64", 1500), ("f64f64", 2048),
+                                     ("f32f32", 1000), ("f32f32", 3000), ("f64f32", 4096)])
+def test_folded_form_matches_reference(window, combo, m):
+    """The tree-sum flavour of the fused call folds window, operation and synthesis into per-bin coefficients
+    (process_rows_kernel): every window (3 and 5 taps, mirror images at both ends of the spectrum), every
+    operation, both synthesis branches, one / two / four bins per lane, a roll-over inside the call, the
+    stream continued by a second call -- against the two reference calls within the path's bar; with exact
+    carries (FD float) the stream state stays bit-identical."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    n = 2 * m + 700
+    x = sine_sweep(n, dtype=td) + noise(n, seed=5, dtype=td) * td(0.1)
+    x2 = noise(900, seed=6, dtype=td)
+    gain = (1.0 + 0.5 * np.sin(np.arange(m) * 0.37)).astype(fd)
+    tol = TOL[combo[3:]]
+    for latency, (op, shift) in ((1.0, OPS[0]), (1.0, OPS[1]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3]), (0.5, OPS[0])):
+        ref = O.best(m, window, latency, combo)
+        want, _ = reference(ref, x, op, gain, shift)
+        want2, _ = reference(ref, x2, op, gain, shift)
+        for fold in (1, 0):
+            with make(m, window, latency, combo, fused_exact=0, fold=fold) as p:
+                y = p.process(torch.from_numpy(x).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+                assert p.get_option("last_process_path") == 1 and p.get_option("last_fused_exact") == 0
+                assert p.get_option("last_fused_fold") == fold
+                assert rel(y, want) <= tol, (combo, window, m, latency, op, shift, fold, rel(y, want))
+                y2 = p.process(torch.from_numpy(x2).cuda(), op, gain=gain, shift=shift).cpu().numpy()
+                assert rel(y2, want2) <= tol, (combo, window, m, latency, op, shift, fold, "second call")
+                if combo[3:] == "f32" and fold == 1 and op == "identity":
+                    ref2 = O.best(m, window, latency, combo)
+                    ref2.sdft(x); ref2.sdft(x2)
+                    x3 = noise(300, seed=8, dtype=td)
+                    assert np.array_equal(p.sdft(x3), ref2.sdft(x3))           # exact carries: the state is the reference's
+
+
+def test_folded_form_batched_channels_and_host_pointers():
+    """Folded form on a batched plan (channels on the grid), host-pointer input / output staged by the library."""
+    m, n, ch = 1024, 5000, 3
+    xb = np.stack([noise(n, seed=20 + c) for c in range(ch)])
+    gain = np.linspace(2.0, 0.0, m)
+    with make(m, "hann", 1.0, "f32f64", ch) as p:
+        y = p.process(xb, "gain", gain=gain)
+        assert p.get_option("last_fused_fold") == 1
+        for c in range(ch):
+            want, _ = reference(O.best(m, "hann", 1.0, "f32f64"), xb[c], "gain", gain, 0)
+            assert rel(y[c], want) <= TOL["f64"], c
+
+
 @pytest.mark.parametrize("combo", O.COMBOS)
 def test_hop_sized_calls_and_host_pointers(combo):
     """Calls of one time chunk (the reference's hop loop, test/test.c:69-83): hop kernel + one-wave-per-row
