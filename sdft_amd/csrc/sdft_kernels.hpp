@@ -2364,10 +2364,27 @@ template <typename FD> SDFT_D FD wave_sum(FD v)
 // multiply-add: no neighbour exchange, no window arithmetic, no edge slots -- 9 instead of ~45 vector
 // instructions per bin-sample at FD double.  The sum over bins: every lane adds its own J bins, a wave
 // transposes its G x 64 partial sums through a private LDS tile (lane (u, s) adds eight of sample u's
-// values, three shuffles finish the row), the waves' sums meet in a small table, one barrier per group
-// of G samples.  The order of the additions differs from the reference's: this is the tree-sum flavour
+// values, three DPP steps finish the row), the waves' sums meet in a ring of small tables, one barrier
+// per four groups of G samples.  The order of the additions differs from the reference's: this is the tree-sum flavour
 // of the fused call (not bit-identical; the ordered walk stays with forward_rows_kernel<SYN = 2>).
 // ------------------------------------------------------------------------------------------
+// sum over aligned groups of eight lanes, every lane of the group receiving it: two quad permutes and a
+// mirror of the half row -- vector-ALU moves, no trip through the LDS crossbar like ds_bpermute
+template <int CTRL> SDFT_D float dpp_move(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> SDFT_D double dpp_move(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <typename FD> SDFT_D FD sum_of_eight(FD v)
+{
+  v += dpp_move<0xB1>(v);                                  // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4E>(v);                                  // quad_perm:[2,3,0,1]
+  v += dpp_move<0x141>(v);                                 // row_half_mirror: lane i <-> 7 - i of its eight
+  return v;
+}
+
 template <typename TD, typename FD> struct ProcArgs
 {
   TD* y;                      // [channels][n]
@@ -2412,15 +2429,18 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(FD* alpha, FD* beta,
   beta[r] = be;
 }
 
-constexpr int kProcGroup = 8;            // samples per lockstep group
+constexpr int kProcGroup = 8;            // samples per group
 constexpr int kProcRow = 72;             // padded row of the transpose tile: 8 segments of 8 + 1
+constexpr int kProcRing = 8;             // groups whose per-wave sums are in flight (a ring of tables)
+constexpr int kProcSync = 4;             // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
 
 template <typename TD, typename FD, int J, bool FUSED, bool HASB>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz)
 {
   constexpr int G = kProcGroup;
+  constexpr int R = kProcRing, K = kProcSync;
   __shared__ FD tile[kRowWavesMax][G * kProcRow];
-  __shared__ FD part[2][G][kRowWavesMax];
+  __shared__ FD part[R][G][kRowWavesMax];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2434,7 +2454,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
-  for (int i = threadIdx.x; i < 2 * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (FD)0;   // waves that do not exist add 0
+  for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (FD)0;   // waves that do not exist add 0
 
   BinState<FD> s[J];
   FD al[J], be[J];
@@ -2506,7 +2526,19 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   TD* yo = pz.y + ch * pz.y_stride;
   FD* my = tile[wave];
   const int ru = lane >> 3, rs = lane & 7;                 // transposed role: sample of the group, segment of the row
-  int pbuf = 0;
+  // the waves' sums of group g wait in part[g % R]; every K groups a barrier, after which K waves add one
+  // finished group each (tables K .. 2K-1 groups back are rewritten only after the barrier that follows)
+  auto finish_groups = [&](unsigned first, unsigned count)
+  {
+    for (unsigned g = first + (unsigned)wave; g < first + count; g += (unsigned)nwaves)
+    {
+      const size_t tg = t0 + (size_t)g * G;
+      const int mg = (t1 - tg < (size_t)G) ? (int)(t1 - tg) : G;
+      FD p = part[g % R][ru][rs] + part[g % R][ru][rs + 8];
+      p = sum_of_eight(p);
+      if (rs == 0 && ru < mg) yo[tg + ru] = (TD)(p * pz.sweight);               // sdft.h:654-656
+    }
+  };
   unsigned gi = 0;
   size_t t = t0;
   while (t < t1)                       // all waves of the group take identical trip counts
@@ -2543,24 +2575,20 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     FD sum = (FD)0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += my[ru * kProcRow + rs * 9 + e];
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
-    if (rs == 0) part[pbuf][ru][wave] = sum;
-    __syncthreads();
-    // the waves take turns adding the per-wave sums (the table is double-buffered: the next group writes the
-    // other half, and nobody gets to the group after that before this wave has passed the next barrier)
-    if (wave == (int)(gi % (unsigned)nwaves))
-    {
-      FD p = part[pbuf][ru][rs] + part[pbuf][ru][rs + 8];
-      p += __shfl_xor(p, 1, 64);
-      p += __shfl_xor(p, 2, 64);
-      p += __shfl_xor(p, 4, 64);
-      if (rs == 0 && ru < m) yo[t + ru] = (TD)(p * pz.sweight);                 // sdft.h:654-656
-    }
+    sum = sum_of_eight(sum);
+    if (rs == 0) part[gi % R][ru][wave] = sum;
     t += m;
-    pbuf ^= 1;
     ++gi;
+    if (gi % K == 0)
+    {
+      __syncthreads();
+      finish_groups(gi - K, K);
+    }
+  }
+  if (gi % K != 0)
+  {
+    __syncthreads();
+    finish_groups(gi - gi % K, gi % K);
   }
 
   if (chunk + 1 == a.chunks)
