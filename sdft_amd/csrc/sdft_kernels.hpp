@@ -2429,10 +2429,13 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(FD* alpha, FD* beta,
   beta[r] = be;
 }
 
+#ifndef SDFT_PROC_RING
+#define SDFT_PROC_RING 4
+#endif
 constexpr int kProcGroup = 8;            // samples per group
-constexpr int kProcRow = 72;             // padded row of the transpose tile: 8 segments of 8 + 1
-constexpr int kProcRing = 8;             // groups whose per-wave sums are in flight (a ring of tables)
-constexpr int kProcSync = 4;             // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
+constexpr int kProcRow = 72;             // row stride of the transpose tile: 64 + 8, see the bank note in the kernel
+constexpr int kProcRing = SDFT_PROC_RING;             // groups whose per-wave sums are in flight (a ring of tables)
+constexpr int kProcSync = SDFT_PROC_RING / 2;         // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
 
 template <typename TD, typename FD, int J, bool FUSED, bool HASB>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz)
@@ -2570,11 +2573,14 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
       }
     }
     // this wave's 64 partial sums per sample -> one sum per sample (LDS operations of one wave execute in order)
+    // (rows are written contiguously: 16 consecutive lanes = 32 consecutive banks; lane (u, s) reads its eight
+    // columns rotated by s, which with a row stride of 8 mod 32 doublewords puts the 32 lanes of a read on 32
+    // different bank pairs)
 #pragma unroll
-    for (int u = 0; u < G; ++u) my[u * kProcRow + lane + (lane >> 3)] = v[u];
-    FD sum = (FD)0;
+    for (int u = 0; u < G; ++u) my[u * kProcRow + lane] = v[u];
+    FD sum = my[ru * kProcRow + rs * 8 + (rs & 7)];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sum += my[ru * kProcRow + rs * 9 + e];
+    for (int e = 1; e < 8; ++e) sum += my[ru * kProcRow + rs * 8 + ((e + rs) & 7)];
     sum = sum_of_eight(sum);
     if (rs == 0) part[gi % R][ru][wave] = sum;
     t += m;
