@@ -2443,7 +2443,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   constexpr int G = kProcGroup;
   constexpr int R = kProcRing, K = kProcSync;
   __shared__ FD tile[kRowWavesMax][G * kProcRow];
-  __shared__ FD part[R][G][kRowWavesMax];
+  __shared__ FD part[R][kRowWavesMax][G];                  // [group][wave][sample]: eight lanes write eight neighbours
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2537,7 +2537,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     {
       const size_t tg = t0 + (size_t)g * G;
       const int mg = (t1 - tg < (size_t)G) ? (int)(t1 - tg) : G;
-      FD p = part[g % R][ru][rs] + part[g % R][ru][rs + 8];
+      FD p = part[g % R][rs][ru] + part[g % R][rs + 8][ru];
       p = sum_of_eight(p);
       if (rs == 0 && ru < mg) yo[tg + ru] = (TD)(p * pz.sweight);               // sdft.h:654-656
     }
@@ -2582,7 +2582,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
 #pragma unroll
     for (int e = 1; e < 8; ++e) sum += my[ru * kProcRow + rs * 8 + ((e + rs) & 7)];
     sum = sum_of_eight(sum);
-    if (rs == 0) part[gi % R][ru][wave] = sum;
+    if (rs == 0) part[gi % R][wave][ru] = sum;
     t += m;
     ++gi;
     if (gi % K == 0)

@@ -135,16 +135,17 @@ def disassemble(combo, hip_library):
 def test_kernels_contain_no_fused_multiply_add(hip_library, combo):
     """Parity depends on unfused a*b+c in the recurrence, the window and the synthesis terms (SURVEY.md
     section 7): every kernel of every (TD, FD) translation unit is disassembled and must contain NO fused
-    floating point instruction at all -- except the two places that ask for them by name: the FUSED
-    instantiations of forward_rows_kernel (chunk-parallel FD double path only) and chunk_sum_kernel
-    (feeds carries whose summation order differs from the reference anyway)."""
+    floating point instruction at all -- except the places that ask for them by name: the FUSED
+    instantiations of forward_rows_kernel and process_rows_kernel (chunk-parallel FD double path only) and
+    chunk_sum_kernel (feeds carries whose summation order differs from the reference anyway)."""
     kernels = disassemble(combo, hip_library)
     assert any(k.startswith("forward_rows_kernel") for k in kernels) and any(k.startswith("inverse_exact_kernel") for k in kernels)
     checked = 0
     for name, body in kernels.items():
         args = re.search(r"<(.*)>", name)
         params = [a.strip() for a in args.group(1).split(",")] if args else []
-        deliberately_fused = name.startswith("chunk_sum_kernel") or (name.startswith("forward_rows_kernel") and params[3] == "true")
+        deliberately_fused = name.startswith("chunk_sum_kernel") or \
+            (name.startswith(("forward_rows_kernel", "process_rows_kernel")) and params[3] == "true")
         fused = [l for l in body if re.search(FUSED_OPS, l)]
         if deliberately_fused:
             continue
