@@ -57,9 +57,11 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
      sdft_hip_op_shift     params = const long* (host): X'[k] = X[k - *params], zero outside the spectrum
    dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
    (identity / gain only).  Batched plans: samples / out [channels][nsamples].
-   Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the analysis path's
-   bar; bit-identical where the analysis is (FD float, option carry = 1, calls shorter than 512
-   samples) -- see option "fused_exact".  Returns 0, or -1 with sdft_hip_last_error() set. */
+   Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the path's bar (1e-6
+   relative at FD double, 1e-4 at FD float); calls shorter than 512 samples are bit-identical, longer
+   ones on request (option "fused_exact" = 1 with exact carries: FD float, or FD double with carry = 1);
+   the stream state a call leaves behind is the one the two calls leave.  Returns 0, or -1 with
+   sdft_hip_last_error() set. */
 enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2 };
 int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t* samples, sdft_td_t* const out,
                        const int op, const void* params, sdft_fdx_t* dfts) SDFT_HIP_SYMBOL(process_n);
@@ -92,8 +94,11 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "chain"         exact carries: 1 (default) = chain form (seed table + producer/consumer waves) while
                        bins x channels leave SIMDs idle, 0 = always the serial pass, 2 = chain form whenever
                        the geometry allows ("chain_block" 8|16|32 steps, "chain_producers" 1..7)
-   "fused_exact"   sdft_hip_process_n sums bins in the reference's order (1), by a wave-parallel tree (0),
-                       or (-1, default) in order exactly when the analysis itself is bit-exact
+   "fused_exact"   sdft_hip_process_n: 0 = folded form (window, operation and synthesis folded into per-bin
+                       coefficients, sum over bins by a tree), 1 = bins summed in the reference's order by the
+                       fastest route that gives those bits, 2 = in that order by the fused kernel,
+                       -1 (default) = 1 when the host set carry = 1 at FD double, else 0
+   "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
    "pointers"      0 = classify each distinct pointer once (cached), 1 = all device, 2 = all host,
                        3 = query on every call
    "stage_bytes"   segment size of the host-pointer staging path
@@ -101,7 +106,7 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
-   "last_chain", "last_fused_exact", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
+   "last_chain", "last_fused_exact", "last_fused_fold", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
    "cursor", "device". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);

@@ -345,82 +345,6 @@ if __name__ == "__main__":
             run(48000, 1024, channels=64, inverse_rows=rw)
         for rw in (16, 32):
             run(48000, 1000, inverse_rows=rw)
-    if which == "invonly":
-        # synthesis alone, repeated on the same matrix (no analysis in between), against the round trip
-        for n, m, ch in ((48000, 1024, 1), (131072, 1024, 1), (12000, 1024, 1), (48000, 1024, 4)):
-            x = torch.from_numpy(sine_sweep(n) if ch == 1 else np.stack([sine_sweep(n)] * ch)).cuda()
-            pl = SDFT(m, "hann", 1.0, "f32f64", ch); pl.set_option("async", 1)
-            out = torch.empty((n, m) if ch == 1 else (ch, n, m), dtype=torch.complex128, device="cuda")
-            pl.sdft(x, out); y = pl.isdft(out); pl.synchronize()
-            for rw in (1, 4, 16, 32):
-                pl.set_option("inverse_rows", rw)
-                pl.isdft(out, y); pl.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(50): pl.isdft(out, y)
-                pl.synchronize(); dt = (time.perf_counter() - t0) / 50
-                print(f"n={n} m={m} ch={ch} inverse only, rows per wave {rw}: {dt*1e3:.3f} ms ({ch*n*m*16/dt/1e12:.2f} TB/s)", flush=True)
-            pl.set_option("inverse_rows", 0)
-            for what in ("inverse only", "forward only", "round trip"):
-                t0 = time.perf_counter()
-                for _ in range(50):
-                    if what != "inverse only": pl.sdft(x, out)
-                    if what != "forward only": pl.isdft(out, y)
-                pl.synchronize(); dt = (time.perf_counter() - t0) / 50
-                print(f"n={n} m={m} ch={ch} {what}: {dt*1e3:.3f} ms per iteration ({ch*n*m*16/dt/1e12:.2f} TB/s per pass)", flush=True)
-            pl.close(); del out
-    if which == "mid":
-        # calls between a hop and the north star's 48000 samples: chunk length against wall time per call
-        for combo in ("f32f64", "f32f32"):
-            for n in (1024, 2048, 4096, 12000, 24000, 48000):
-                x = torch.from_numpy(sine_sweep(n)).cuda()
-                out = torch.empty((n, 1024), dtype=torch.complex128 if combo == "f32f64" else torch.complex64, device="cuda")
-                for ch in (0, 32, 64, 96, 128, 192):
-                    pl = SDFT(1024, "hann", 1.0, combo); pl.set_option("async", 1); pl.set_option("chunk", ch)
-                    pl.sdft(x, out); pl.sdft(x, out); pl.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(50): pl.sdft(x, out)
-                    pl.synchronize(); dt = (time.perf_counter() - t0) / 50
-                    print(f"{combo} n={n} chunk={ch} -> chunks={pl.get_option('last_chunks')} len={pl.get_option('last_chunk_len')}: {dt*1e6:.1f} us per call ({n*1024*out.element_size()/dt/1e12:.2f} TB/s)", flush=True)
-                    pl.close()
-    if which == "segs":
-        for ch, sg in ((0, 0), (128, 8), (128, 4), (128, 16), (192, 6), (64, 8), (64, 16), (256, 8)):
-            run(262144, 4096, "blackman", "f32f32", chunk=ch, segments=sg)
-        for ch, sg in ((0, 0), (128, 8), (128, 16), (64, 16)):
-            run(262144, 1024, "hann", "f32f32", chunk=ch, segments=sg)
-            run(1000000, 1024, carry=1, chunk=ch * 2, segments=sg)
-    if which == "vecd":
-        for dbg in (0, 32, 0, 32):
-            for P in (6, 7):
-                run(262144, 4096, "blackman", "f32f32", chain_debug=dbg, chain_producers=P)
-                run(262144, 1024, "hann", "f32f32", chain_debug=dbg, chain_producers=P, segments=1)
-    if which == "excl":
-        for ex in (0, 1, 0, 1):
-            run(262144, 4096, "blackman", "f32f32", chain_exclusive=ex)
-            run(262144, 4096, "blackman", "f32f32", chain_exclusive=ex, chunk=128, segments=8)
-            run(262144, 2048, "blackman", "f32f32", chain_exclusive=ex)
-            run(1000000, 1024, carry=1, chain_exclusive=ex)
-    if which == "syn2":
-        # two-slot rows through the fused call, next to the two calls
-        run_process(262144, 4096, "blackman", "f32f32")
-        run_process(262144, 4096, "blackman", "f32f32", fused_exact=0)
-        run(262144, 4096, "blackman", "f32f32")
-        run_process(48000, 2048, "hann", "f32f64", channels=64)
-        run_process(48000, 2048, "hann", "f32f64", channels=64, fused_exact=1)
-        run_process(500000, 2048, "hann", "f32f64")
-        run(500000, 2048)
-        run_process(48000, 2048, "hann", "f32f32", channels=64)
-        run_process(48000, 2048, "hann", "f32f32", channels=64, fused_exact=0)
-    if which == "c3f32":
-        for sg in (0, 8):
-            for ch in (0, 1504, 752):
-                run(48000, 2048, "hann", "f32f32", channels=64, segments=sg, chunk=ch)
-        run(48000, 2048, "hann", "f32f32", channels=64, chain=2)
-    if which == "sizes":
-        # partial-sum forms: 2N a power of two (FFT), 2/3/5-smooth (mixed radix), other primes (direct sums)
-        for m in (1024, 1000, 960, 1022, 1018, 1009, 500, 509, 2048, 2000, 2042):
-            run(1000000 if m <= 1024 else 500000, m)
-        for m in (1024, 1000, 1022):
-            run(48000, m, reps=20)
     if which == "inv":
         for rep in range(2):
             run(1000000, 1024)

@@ -2385,12 +2385,16 @@ template <typename FD> SDFT_D FD sum_of_eight(FD v)
   return v;
 }
 
+// The sum over bins runs in double whatever FD is: the folded terms alpha * re X are an order of magnitude
+// larger than the windowed terms the reference adds (the window's cancellation between neighbouring bins has
+// moved into the coefficients), which in float arithmetic costs a digit (1.2e-4 against the reference's
+// float result at N = 3000); in double the folded sum is the more accurate of the two.
 template <typename TD, typename FD> struct ProcArgs
 {
   TD* y;                      // [channels][n]
   size_t y_stride;
-  const FD* alpha;            // [N]
-  const FD* beta;             // [N]
+  const double* alpha;        // [N]
+  const double* beta;         // [N]
   FD sweight;
 };
 
@@ -2398,13 +2402,13 @@ template <typename TD, typename FD> struct ProcArgs
 // 2(N-1) - r at the ends), every tap i, output bin j = m - i inside the spectrum; A/B of an output bin are
 // what sdft_isdft multiplies re / im of that bin with, after the operation.
 template <typename FD>
-__global__ __launch_bounds__(kBlock) void fold_coeff_kernel(FD* alpha, FD* beta, SpectralOp<FD> op, const cx<FD>* syn,
+__global__ __launch_bounds__(kBlock) void fold_coeff_kernel(double* alpha, double* beta, SpectralOp<FD> op, const cx<FD>* syn,
                                                             unsigned nbins, int lat1, FD h0, FD h1, FD h2)
 {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x, N = (long)nbins;
   if (r >= N) return;
-  const FD h[5] = {h2, h1, h0, h1, h2};
-  FD al = (FD)0, be = (FD)0;
+  const double h[5] = {(double)h2, (double)h1, (double)h0, (double)h1, (double)h2};
+  double al = 0.0, be = 0.0;
   auto add_position = [&](long m, bool flip)
   {
     for (int i = -2; i <= 2; ++i)
@@ -2413,10 +2417,10 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(FD* alpha, FD* beta,
       if (j < 0 || j >= N) continue;
       const long ko = j + (op.kind == OP_SHIFT ? op.shift : 0);
       if (ko < 0 || ko >= N) continue;                      // shifted out of the spectrum
-      FD A, B;
-      if (lat1) { A = (ko & 1) ? (FD)(-1) : (FD)(+1); B = (FD)0; }           // sdft.h:643
-      else { A = syn[ko].re; B = -syn[ko].im; }                              // re(Y * twiddle), :650
-      if (op.kind == OP_GAIN) { A *= op.gain[j]; B *= op.gain[j]; }
+      double A, B;
+      if (lat1) { A = (ko & 1) ? -1.0 : +1.0; B = 0.0; }                     // sdft.h:643
+      else { A = (double)syn[ko].re; B = -(double)syn[ko].im; }              // re(Y * twiddle), :650
+      if (op.kind == OP_GAIN) { A *= (double)op.gain[j]; B *= (double)op.gain[j]; }
       al += h[i + 2] * A;
       be += (flip ? -(h[i + 2] * B) : h[i + 2] * B);        // the mirror image is the conjugate
     }
@@ -2442,8 +2446,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
 {
   constexpr int G = kProcGroup;
   constexpr int R = kProcRing, K = kProcSync;
-  __shared__ FD tile[kRowWavesMax][G * kProcRow];
-  __shared__ FD part[R][kRowWavesMax][G];                  // [group][wave][sample]: eight lanes write eight neighbours
+  using AT = double;                                        // arithmetic type of everything after the recurrence
+  __shared__ AT tile[kRowWavesMax][G * kProcRow];
+  __shared__ AT part[R][kRowWavesMax][G];                  // [group][wave][sample]: eight lanes write eight neighbours
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2457,10 +2462,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
-  for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (FD)0;   // waves that do not exist add 0
+  for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (AT)0;   // waves that do not exist add 0
 
   BinState<FD> s[J];
-  FD al[J], be[J];
+  AT al[J], be[J];
   bool live[J];
   const size_t cbase = (ch * a.chunks + chunk) * a.nbins;
 #pragma unroll
@@ -2478,15 +2483,15 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     if (!live[j])
     {
       s[j].tw = cmake<FD>((FD)0, (FD)0); s[j].acc = s[j].tw; s[j].fid = s[j].tw;
-      al[j] = (FD)0; be[j] = (FD)0;
+      al[j] = (AT)0; be[j] = (AT)0;
     }
   }
   __syncthreads();
 
   // one sample: the recurrence (sdft.h:566-587) for this lane's bins, then their share of the output sample
-  auto step_all = [&](FD dl, bool wrap) -> FD
+  auto step_all = [&](FD dl, bool wrap) -> AT
   {
-    FD vv = (FD)0;
+    AT vv = (AT)0;
 #pragma unroll
     for (int j = 0; j < J; ++j)
     {
@@ -2513,11 +2518,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
       else
       {
         if (wrap) advance_wrap(b, dl); else advance_normal(b, dl);                     // the stream state stays exact
-        const FD xr = b.acc.re * b.fid.re + b.acc.im * b.fid.im;
+        const AT ar = (AT)b.acc.re, ai = (AT)b.acc.im, fr = (AT)b.fid.re, fi = (AT)b.fid.im;
+        const AT xr = ar * fr + ai * fi;
         vv += al[j] * xr;
         if constexpr (HASB)
         {
-          const FD xi = b.acc.im * b.fid.re - b.acc.re * b.fid.im;
+          const AT xi = ai * fr - ar * fi;
           vv += be[j] * xi;
         }
       }
@@ -2527,7 +2533,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
   TD* yo = pz.y + ch * pz.y_stride;
-  FD* my = tile[wave];
+  AT* my = tile[wave];
   const int ru = lane >> 3, rs = lane & 7;                 // transposed role: sample of the group, segment of the row
   // the waves' sums of group g wait in part[g % R]; every K groups a barrier, after which K waves add one
   // finished group each (tables K .. 2K-1 groups back are rewritten only after the barrier that follows)
@@ -2537,9 +2543,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     {
       const size_t tg = t0 + (size_t)g * G;
       const int mg = (t1 - tg < (size_t)G) ? (int)(t1 - tg) : G;
-      FD p = part[g % R][rs][ru] + part[g % R][rs + 8][ru];
+      AT p = part[g % R][rs][ru] + part[g % R][rs + 8][ru];
       p = sum_of_eight(p);
-      if (rs == 0 && ru < mg) yo[tg + ru] = (TD)(p * pz.sweight);               // sdft.h:654-656
+      if (rs == 0 && ru < mg) yo[tg + ru] = (TD)(p * (AT)pz.sweight);           // sdft.h:654-656
     }
   };
   unsigned gi = 0;
@@ -2547,7 +2553,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   while (t < t1)                       // all waves of the group take identical trip counts
   {
     const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
-    FD v[G];
+    AT v[G];
     if (m == G && c + G <= maxc)
     {
       FD dl[G];
@@ -2562,7 +2568,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
 #pragma unroll
       for (int u = 0; u < G; ++u)
       {
-        v[u] = (FD)0;
+        v[u] = (AT)0;
         if (u < m)
         {
           const FD dl = d[t + u];
@@ -2578,7 +2584,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     // different bank pairs)
 #pragma unroll
     for (int u = 0; u < G; ++u) my[u * kProcRow + lane] = v[u];
-    FD sum = my[ru * kProcRow + rs * 8 + (rs & 7)];
+    AT sum = my[ru * kProcRow + rs * 8 + (rs & 7)];
 #pragma unroll
     for (int e = 1; e < 8; ++e) sum += my[ru * kProcRow + rs * 8 + ((e + rs) & 7)];
     sum = sum_of_eight(sum);

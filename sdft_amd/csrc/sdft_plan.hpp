@@ -144,8 +144,9 @@ class Plan
   long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
   long opt_hop_kernel = 1;       // single-chunk calls: fused delta + forward launch (forward_hop_kernel)
-  long opt_fused_exact = -1;     // fused analysis->synthesis: bins summed in the reference's order (1), by a tree (0),
-                                 // or (-1) in order exactly when the analysis itself is bit-exact (exact carries)
+  long opt_fused_exact = -1;     // fused analysis->synthesis: 0 = folded / tree sum; 1 = bins summed in the reference's order
+                                 // (the fastest route that gives those bits), 2 = in that order by the fused kernel;
+                                 // -1 = in order exactly when the host asked for exact carries at FD double (carry = 1)
   long last_fused_exact = 0, last_fused_fold = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
 
@@ -680,7 +681,7 @@ class Plan
       if (fuse)
       {
         // rows never leave the workgroup: synthesis in the same launch (caller checked fuse_ok())
-        const bool exact_order = opt_fused_exact < 0 ? use_seed : opt_fused_exact != 0;
+        const bool exact_order = opt_fused_exact < 0 ? (use_seed && sizeof(FD) == 8) : opt_fused_exact != 0;
         last_fused_exact = exact_order;
         const bool folded = !exact_order && !fuse->store && opt_fold && coeff_ready;
         last_fused_fold = folded;
@@ -832,7 +833,7 @@ class Plan
 
   // folded form of the fused call (process_rows_kernel): per-bin coefficients from the plan's window and
   // synthesis tables and the call's operation, then one launch per overlap segment
-  DevBuf<FD> d_alpha, d_beta;
+  DevBuf<double> d_alpha, d_beta;
   bool coeff_ready = false;
   int coeff_kind = -1; long coeff_shift = 0;
   bool fold_coefficients(const SpectralOp<FD>& op)
@@ -1257,11 +1258,10 @@ class Plan
     bool ok;
     long chunks, len;
     choose_chunks(n, chunks, len, rows_kernel_ok(false));
-    // two-slot rows at FD float with exact carries: the ordered walk (N dependent additions shared by the
-    // four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144: 5.7 ms
-    // against 4.2 ms for the two passes); the two-pass path gives the same bits.  Option fused_exact
-    // = 0 (tree sum, 4.0 ms) or 1 still selects the fused kernel.
-    const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact < 0;
+    // reference order asked for on two-slot rows at FD float: the ordered walk (N dependent additions shared
+    // by the four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144:
+    // 5.7 ms against 4.1 ms for the two passes, which give the same bits); fused_exact = 2 insists on the kernel
+    const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
     if (fuse_ok() && chunks > 1 && !walk_loses)
     {
       FuseArgs<TD, FD> fz;

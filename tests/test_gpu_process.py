@@ -79,11 +79,12 @@ def test_fused_double_fast_path(op, shift, latency):
             assert rel(y2.cpu().numpy(), want2) <= TOL["f64"]
 
 
-@pytest.mark.parametrize("combo,opts", [("f32f32", {}), ("f64f32", {}), ("f32f64", {"carry": 1}), ("f64f64", {"carry": 1})])
+@pytest.mark.parametrize("combo,opts", [("f32f32", {"fused_exact": 1}), ("f64f32", {"fused_exact": 1}),
+                                        ("f32f64", {"carry": 1}), ("f64f64", {"carry": 1})])
 @pytest.mark.parametrize("window", ["hann", "blackman", "boxcar"])
 def test_fused_exact_modes_are_bit_identical(combo, opts, window):
-    """Exact carries (FD float always, FD double on request): the fused kernel walks the bins in the
-    reference's order, so the samples equal the two reference calls bit for bit -- for every operation,
+    """Exact carries (FD float with fused_exact = 1, FD double with carry = 1): the fused kernel walks the bins in
+    the reference's order, so the samples equal the two reference calls bit for bit -- for every operation,
     both synthesis branches, rows that do not fill the last wave, batched channels."""
     import torch
     td, fd, fdx = O.combo_types(combo)
@@ -114,12 +115,12 @@ def test_fused_two_slot_rows_bit_identical(combo, opts, m, window):
     xb = np.stack([noise(n, seed=11 + c, dtype=td) for c in range(ch)])
     for latency, (op, shift) in ((1.0, OPS[0]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3])):
         want = [reference(O.best(m, window, latency, combo), xb[c], op, gain, shift)[0] for c in range(ch)]
-        # FD float: by default these shapes take the two passes (the ordered walk over 4096 bins costs more
-        # than the pass it saves); fused_exact = 1 asks for the fused kernel -- same bits either way
-        for fused_exact in ((-1, 1) if combo[3:] == "f32" else (-1,)):
+        # FD float: fused_exact = 1 takes the two passes for these shapes (the ordered walk over 4096 bins costs
+        # more than the pass it saves); fused_exact = 2 insists on the fused kernel -- same bits either way
+        for fused_exact in ((1, 2) if combo[3:] == "f32" else (-1,)):
             with make(m, window, latency, combo, ch, fused_exact=fused_exact, **opts) as p:
                 y = p.process(torch.from_numpy(xb).cuda(), op, gain=gain, shift=shift).cpu().numpy()
-                fused = not (combo[3:] == "f32" and fused_exact < 0)
+                fused = not (combo[3:] == "f32" and fused_exact == 1)
                 assert p.get_option("last_process_path") == (1 if fused else 3)
                 assert not fused or p.get_option("last_fused_exact") == 1
                 assert p.get_option("last_chunks") > 1
