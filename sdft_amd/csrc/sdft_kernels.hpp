@@ -2616,6 +2616,180 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K3h (folded form, calls of one time chunk)  a hop of the reference's streaming driver through the fused
+// call in ONE launch: like forward_hop_kernel every 64 bins are one wave and one workgroup (the tiles land
+// on different CUs), differences are formed from the input and the delay line by scalar loads, the state is
+// double-buffered; like process_rows_kernel a bin contributes alpha * re X + beta * im X.  A wave leaves its
+// sum per sample in partial[ch][tile][t]; the workgroup that takes the channel's last ticket (agent-scope
+// acquire/release on a counter) adds the tiles in ascending order and writes the samples.  The recurrence is
+// the unfused one: the state a call leaves behind is bit-identical to the reference's.
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD> struct ProcHopArgs
+{
+  const TD* x;                // [channels][n]
+  size_t x_stride;
+  TD* y;                      // [channels][n]
+  size_t y_stride;
+  const TD* hist_in;          // [channels][2N] delay line in time order
+  TD* hist_out;
+  const cx<FD>* tw;           // [N]
+  const cx<FD>* acc_in;       // [channels][N]
+  const cx<FD>* fid_in;
+  cx<FD>* acc_out;
+  cx<FD>* fid_out;
+  const double* alpha;        // [N]
+  const double* beta;
+  double* partial;            // [channels][tiles][n]
+  unsigned* tickets;          // [channels], zero between calls
+  size_t n;
+  unsigned nbins, tiles, cursor0;
+  FD sweight;
+};
+
+template <typename TD, typename FD, bool HASB>
+__global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> a)
+{
+  constexpr int G = kProcGroup;
+  using AT = double;
+  __shared__ AT tile_lds[G * kProcRow];
+  __shared__ unsigned last_flag;
+
+  const int lane = threadIdx.x;
+  const unsigned tile = blockIdx.x % a.tiles;
+  const size_t ch = blockIdx.x / a.tiles;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  unsigned c = a.cursor0;
+
+  const unsigned k = tile * kWave + (unsigned)lane;
+  const bool live = k < a.nbins;
+  const unsigned kk = live ? k : 0u;
+  const size_t sbase = ch * a.nbins;
+  BinState<FD> s;
+  s.tw = a.tw[kk]; s.acc = a.acc_in[sbase + kk]; s.fid = a.fid_in[sbase + kk];
+  AT al = a.alpha[kk], be = a.beta[kk];
+  if (!live) { s.tw = cmake<FD>((FD)0, (FD)0); s.acc = s.tw; s.fid = s.tw; al = (AT)0; be = (AT)0; }
+
+  // delay line for the next call: element i of the last 2N samples of (hist ++ x)
+  {
+    const TD* xv = a.x + ch * a.x_stride;
+    const TD* hv = a.hist_in + ch * span;
+    TD* ho = a.hist_out + ch * span;
+    for (size_t i = (size_t)tile * kWave + lane; i < span; i += (size_t)a.tiles * kWave)
+    {
+      const size_t j = a.n + i;
+      ho[i] = (j >= span) ? xv[j - span] : hv[j];
+    }
+  }
+
+  const SDFT_CONSTANT TD* xs = as_uniform(a.x + ch * a.x_stride);
+  const SDFT_CONSTANT TD* hs = as_uniform(a.hist_in + ch * span);
+  double* mine = a.partial + (ch * a.tiles + tile) * a.n;
+  const int ru = lane >> 3, rs = lane & 7;
+
+  auto step = [&](FD dl, bool wrap) -> AT
+  {
+    if (wrap) advance_wrap(s, dl); else advance_normal(s, dl);                         // sdft.h:566-587, unfused
+    const AT ar = (AT)s.acc.re, ai = (AT)s.acc.im, fr = (AT)s.fid.re, fi = (AT)s.fid.im;
+    AT vv = al * (ar * fr + ai * fi);
+    if constexpr (HASB) vv += be * (ai * fr - ar * fi);
+    return vv;
+  };
+
+  for (size_t t = 0; t < a.n; t += G)
+  {
+    const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
+    // differences of the group (sdft.h:564): the old sample comes from the delay line while t < 2N, from the
+    // call's own input afterwards; the subtraction in TD precision.  All scalar loads of a group are requested
+    // before the first is used.
+    TD dd[G];
+    if (m == G)
+    {
+      TD cur[G], old[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) cur[u] = xs[t + u];
+      if (t + G <= span)
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u) old[u] = hs[t + u];
+      }
+      else if (t >= span)
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u) old[u] = xs[t - span + u];
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u) old[u] = (t + u < span) ? hs[t + u] : xs[t + u - span];
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) dd[u] = cur[u] - old[u];
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+      {
+        dd[u] = (TD)0;
+        if (u < m) { const size_t tt = t + u; dd[u] = xs[tt] - ((tt < span) ? hs[tt] : xs[tt - span]); }
+      }
+    }
+    AT v[G];
+    if (m == G && c + G <= maxc)
+    {
+#pragma unroll
+      for (int u = 0; u < G; ++u) v[u] = step((FD)dd[u], false);
+      c += G;
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+      {
+        v[u] = (AT)0;
+        if (u < m)
+        {
+          const bool wrap = (c == maxc);
+          v[u] = step((FD)dd[u], wrap);
+          c = wrap ? 0 : c + 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) tile_lds[u * kProcRow + lane] = v[u];
+    AT sum = tile_lds[ru * kProcRow + rs * 8 + (rs & 7)];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) sum += tile_lds[ru * kProcRow + rs * 8 + ((e + rs) & 7)];
+    sum = sum_of_eight(sum);
+    if (rs == 0 && ru < m) mine[t + ru] = sum;
+  }
+
+  if (live)
+  {
+    a.acc_out[sbase + k] = s.acc;
+    a.fid_out[sbase + k] = s.fid;
+  }
+
+  // the channel's last workgroup adds the tiles (release: this wave's stores; acquire: everybody else's)
+  if (lane == 0)
+  {
+    const unsigned ticket = __hip_atomic_fetch_add(a.tickets + ch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (ticket + 1u == a.tiles) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  if (lane == 0) __hip_atomic_store(a.tickets + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+  const double* all = a.partial + ch * a.tiles * a.n;
+  TD* yo = a.y + ch * a.y_stride;
+  for (size_t t = lane; t < a.n; t += kWave)
+  {
+    AT p = (AT)0;
+    for (unsigned q = 0; q < a.tiles; ++q) p += all[(size_t)q * a.n + t];
+    yo[t] = (TD)(p * (AT)a.sweight);                                                    // sdft.h:654-656
+  }
+}
+
 // rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
 template <typename FD>
 __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain)

@@ -240,6 +240,7 @@ class Plan
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
     d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release(); d_fseed.release();
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
+    d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -681,7 +682,7 @@ class Plan
       if (fuse)
       {
         // rows never leave the workgroup: synthesis in the same launch (caller checked fuse_ok())
-        const bool exact_order = opt_fused_exact < 0 ? (use_seed && sizeof(FD) == 8) : opt_fused_exact != 0;
+        const bool exact_order = wants_reference_order();
         last_fused_exact = exact_order;
         const bool folded = !exact_order && !fuse->store && opt_fold && coeff_ready;
         last_fused_fold = folded;
@@ -748,6 +749,41 @@ class Plan
     if (!prof_end(ST_FORWARD)) return false;
     hist_cur ^= 1; st_cur ^= 1;
     last_kernel = 3;
+    if (cursor + n >= span) fid_canonical = true;
+    cursor = (cursor + n) % span;
+    return true;
+  }
+
+  // fused call, one time chunk, folded form: one launch (process_hop_kernel); the caller has folded the coefficients
+  DevBuf<double> d_partial;
+  DevBuf<unsigned> d_tickets;
+  bool process_hop(size_t n, const TD* x, size_t x_stride, TD* y, size_t y_stride)
+  {
+    const size_t nb = nbins, span = 2 * nbins;
+    const size_t ptiles = (nb + kWave - 1) / kWave;
+    if (!grid_fits(channels * ptiles)) return false;
+    if (!d_partial.reserve(channels * ptiles * n)) return false;
+    if (d_tickets.cap < channels)
+    {
+      if (!d_tickets.reserve(channels)) return false;
+      SDFT_TRY(hipMemsetAsync(d_tickets.p, 0, channels * sizeof(unsigned), stream));
+    }
+    ProcHopArgs<TD, FD> pa;
+    pa.x = x; pa.x_stride = x_stride; pa.y = y; pa.y_stride = y_stride;
+    pa.hist_in = d_hist[hist_cur].p; pa.hist_out = d_hist[hist_cur ^ 1].p;
+    pa.tw = d_tw.p;
+    pa.acc_in = d_accs[st_cur].p; pa.fid_in = d_fids[st_cur].p;
+    pa.acc_out = d_accs[st_cur ^ 1].p; pa.fid_out = d_fids[st_cur ^ 1].p;
+    pa.alpha = d_alpha.p; pa.beta = d_beta.p; pa.partial = d_partial.p; pa.tickets = d_tickets.p;
+    pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
+    if (!prof_begin(ST_FORWARD)) return false;
+    if (latency == 1) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    else              hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    SDFT_TRY(hipGetLastError());
+    if (!prof_end(ST_FORWARD)) return false;
+    hist_cur ^= 1; st_cur ^= 1;
+    last_kernel = 3; last_chunks = 1; last_chunk_len = (long)n; last_segments = 1; last_fused = 0;
+    last_fused_exact = 0; last_fused_fold = 1;
     if (cursor + n >= span) fid_canonical = true;
     cursor = (cursor + n) % span;
     return true;
@@ -1214,6 +1250,11 @@ class Plan
   DevBuf<FD> d_gain;
   DevBuf<TD> d_stage_y;
   bool fuse_ok() const { return rows_kernel_ok(false); }
+  // fused call: bins summed in the reference's order?  (-1: exactly when the host asked for exact carries at FD double)
+  bool wants_reference_order() const
+  {
+    return opt_fused_exact < 0 ? (carry_mode == CARRY_EXACT && sizeof(FD) == 8) : opt_fused_exact != 0;
+  }
 
   bool process_n(size_t n, const TD* x, TD* y, int op_kind, const void* params, fdx* dfts)
   {
@@ -1262,7 +1303,16 @@ class Plan
     // by the four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144:
     // 5.7 ms against 4.1 ms for the two passes, which give the same bits); fused_exact = 2 insists on the kernel
     const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
-    if (fuse_ok() && chunks > 1 && !walk_loses)
+    // calls of one time chunk: the folded form in one launch (process_hop_kernel) unless the reference's order
+    // is wanted -- then the hop kernel + row synthesis pair below, which is bit-identical
+    const bool one_chunk_folded = chunks == 1 && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel;
+    if (one_chunk_folded)
+    {
+      if (!fold_coefficients(op)) return false;
+      last_process_path = 1;
+      ok = coeff_ready && process_hop(n, xs, n, ys, n);
+    }
+    else if (fuse_ok() && chunks > 1 && !walk_loses)
     {
       FuseArgs<TD, FD> fz;
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
