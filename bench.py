@@ -168,7 +168,7 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
             p.synchronize()
             w = (time.perf_counter() - t0) / (total // hop)
         res[f"us_per_hop_{mode}"] = round(w * 1e6, 1)
-    # the fused entry point: one call per hop (hop kernel + row synthesis, no host round trip between)
+    # the fused entry point: one call and one launch per hop (process_hop_kernel: folded form, tiles combined in the kernel)
     for mode in ("sync", "async"):
         p.set_option("async", 1 if mode == "async" else 0)
         w = 0.0

@@ -2437,6 +2437,7 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(double* alpha, doubl
 #define SDFT_PROC_RING 4
 #endif
 constexpr int kProcGroup = 8;            // samples per group
+constexpr int kHopMax = 512;             // calls of one time chunk are shorter than this (Plan::choose_chunks)
 constexpr int kProcRow = 72;             // row stride of the transpose tile: 64 + 8, see the bank note in the kernel
 constexpr int kProcRing = SDFT_PROC_RING;             // groups whose per-wave sums are in flight (a ring of tables)
 constexpr int kProcSync = SDFT_PROC_RING / 2;         // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
@@ -2653,6 +2654,7 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
   constexpr int G = kProcGroup;
   using AT = double;
   __shared__ AT tile_lds[G * kProcRow];
+  __shared__ TD diff_lds[kHopMax + G];
   __shared__ unsigned last_flag;
 
   const int lane = threadIdx.x;
@@ -2682,8 +2684,20 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
     }
   }
 
-  const SDFT_CONSTANT TD* xs = as_uniform(a.x + ch * a.x_stride);
-  const SDFT_CONSTANT TD* hs = as_uniform(a.hist_in + ch * span);
+  // differences of the whole call (sdft.h:564; the old sample comes from the delay line while t < 2N, from the
+  // call's own input afterwards; the subtraction in TD precision) staged in LDS up front: one round of vector
+  // loads instead of a scalar-load latency (~1 us for a lone wave) in front of every group of samples
+  {
+    const TD* xv = a.x + ch * a.x_stride;
+    const TD* hv = a.hist_in + ch * span;
+    for (size_t tt = lane; tt < a.n; tt += kWave)
+    {
+      const TD cur = xv[tt];
+      const TD old = (tt < span) ? hv[tt] : xv[tt - span];
+      diff_lds[tt] = cur - old;
+    }
+    for (size_t tt = a.n + lane; tt < ((a.n + G - 1) / G) * G; tt += kWave) diff_lds[tt] = (TD)0;
+  }
   double* mine = a.partial + (ch * a.tiles + tile) * a.n;
   const int ru = lane >> 3, rs = lane & 7;
 
@@ -2699,42 +2713,9 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
   for (size_t t = 0; t < a.n; t += G)
   {
     const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
-    // differences of the group (sdft.h:564): the old sample comes from the delay line while t < 2N, from the
-    // call's own input afterwards; the subtraction in TD precision.  All scalar loads of a group are requested
-    // before the first is used.
     TD dd[G];
-    if (m == G)
-    {
-      TD cur[G], old[G];
 #pragma unroll
-      for (int u = 0; u < G; ++u) cur[u] = xs[t + u];
-      if (t + G <= span)
-      {
-#pragma unroll
-        for (int u = 0; u < G; ++u) old[u] = hs[t + u];
-      }
-      else if (t >= span)
-      {
-#pragma unroll
-        for (int u = 0; u < G; ++u) old[u] = xs[t - span + u];
-      }
-      else
-      {
-#pragma unroll
-        for (int u = 0; u < G; ++u) old[u] = (t + u < span) ? hs[t + u] : xs[t + u - span];
-      }
-#pragma unroll
-      for (int u = 0; u < G; ++u) dd[u] = cur[u] - old[u];
-    }
-    else
-    {
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-      {
-        dd[u] = (TD)0;
-        if (u < m) { const size_t tt = t + u; dd[u] = xs[tt] - ((tt < span) ? hs[tt] : xs[tt - span]); }
-      }
-    }
+    for (int u = 0; u < G; ++u) dd[u] = diff_lds[t + u];                                // broadcast reads
     AT v[G];
     if (m == G && c + G <= maxc)
     {

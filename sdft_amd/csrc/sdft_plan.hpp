@@ -1305,7 +1305,7 @@ class Plan
     const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
     // calls of one time chunk: the folded form in one launch (process_hop_kernel) unless the reference's order
     // is wanted -- then the hop kernel + row synthesis pair below, which is bit-identical
-    const bool one_chunk_folded = chunks == 1 && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel;
+    const bool one_chunk_folded = chunks == 1 && n <= (size_t)kHopMax && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel;
     if (one_chunk_folded)
     {
       if (!fold_coefficients(op)) return false;
