@@ -2658,6 +2658,12 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
   __shared__ unsigned last_flag;
 
   const int lane = threadIdx.x;
+#ifdef SDFT_HOP_STAMPS
+  unsigned long long stamp[6]; stamp[0] = __builtin_amdgcn_s_memrealtime();
+#define SDFT_HOP_STAMP(i) stamp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define SDFT_HOP_STAMP(i)
+#endif
   const unsigned tile = blockIdx.x % a.tiles;
   const size_t ch = blockIdx.x / a.tiles;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
@@ -2700,6 +2706,7 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
   }
   double* mine = a.partial + (ch * a.tiles + tile) * a.n;
   const int ru = lane >> 3, rs = lane & 7;
+  SDFT_HOP_STAMP(1);
 
   auto step = [&](FD dl, bool wrap) -> AT
   {
@@ -2746,6 +2753,7 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
     if (rs == 0 && ru < m) mine[t + ru] = sum;
   }
 
+  SDFT_HOP_STAMP(2);
   if (live)
   {
     a.acc_out[sbase + k] = s.acc;
@@ -2759,17 +2767,39 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
     last_flag = (ticket + 1u == a.tiles) ? 1u : 0u;
   }
   __syncthreads();
+  SDFT_HOP_STAMP(3);
   if (!last_flag) return;
   if (lane == 0) __hip_atomic_store(a.tickets + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
   const double* all = a.partial + ch * a.tiles * a.n;
   TD* yo = a.y + ch * a.y_stride;
-  for (size_t t = lane; t < a.n; t += kWave)
+  // (all loads of a batch -- 16 tiles x 2 samples per lane -- are requested before the first is added: the
+  // partial sums come from other XCDs' L2s through memory, a microsecond per dependent round trip)
+  for (size_t tb = 0; tb < a.n; tb += 2 * kWave)
   {
-    AT p = (AT)0;
-    for (unsigned q = 0; q < a.tiles; ++q) p += all[(size_t)q * a.n + t];
-    yo[t] = (TD)(p * (AT)a.sweight);                                                    // sdft.h:654-656
+    const size_t t0 = tb + lane, t1 = tb + kWave + lane;
+    AT p0 = (AT)0, p1 = (AT)0;
+    for (unsigned q0 = 0; q0 < a.tiles; q0 += 16)
+    {
+      AT pv0[16], pv1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+      {
+        const bool tq = q0 + (unsigned)i < a.tiles;
+        pv0[i] = (tq && t0 < a.n) ? all[(size_t)(q0 + i) * a.n + t0] : (AT)0;
+        pv1[i] = (tq && t1 < a.n) ? all[(size_t)(q0 + i) * a.n + t1] : (AT)0;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { p0 += pv0[i]; p1 += pv1[i]; }
+    }
+    if (t0 < a.n) yo[t0] = (TD)(p0 * (AT)a.sweight);                                    // sdft.h:654-656
+    if (t1 < a.n) yo[t1] = (TD)(p1 * (AT)a.sweight);
   }
+#ifdef SDFT_HOP_STAMPS
+  SDFT_HOP_STAMP(4);
+  if (lane == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<unsigned long long*>(a.partial + (size_t)gridDim.x * a.n)[i] = stamp[i];
+#endif
 }
+#undef SDFT_HOP_STAMP
 
 // rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
 template <typename FD>

@@ -762,7 +762,8 @@ class Plan
     const size_t nb = nbins, span = 2 * nbins;
     const size_t ptiles = (nb + kWave - 1) / kWave;
     if (!grid_fits(channels * ptiles)) return false;
-    if (!d_partial.reserve(channels * ptiles * n)) return false;
+    if (!d_partial.reserve(channels * ptiles * n + 8)) return false;     // + stamps of the development build
+    last_partial_elems = channels * ptiles * n;
     if (d_tickets.cap < channels)
     {
       if (!d_tickets.reserve(channels)) return false;
@@ -994,8 +995,19 @@ class Plan
 
   // synchronous calls: short ones poll the stream (a sleeping hipStreamSynchronize wakes up late --
   // tens of microseconds, more than a whole 100-sample hop takes on the device)
+  size_t last_partial_elems = 0;
   bool chain_stats(unsigned long long* out32)
   {
+#ifdef SDFT_HOP_STAMPS
+    // development build: realtime stamps (100 MHz) of the last process_hop_kernel's last workgroup
+    if (d_partial.p && last_partial_elems)
+    {
+      memset(out32, 0, 32 * sizeof(unsigned long long));
+      SDFT_TRY(hipStreamSynchronize(stream));
+      SDFT_TRY(hipMemcpy(out32, d_partial.p + last_partial_elems, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      return true;
+    }
+#endif
     if (!d_chain_stats.p) return false;
     SDFT_TRY(hipMemcpy(out32, d_chain_stats.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return true;
