@@ -1,0 +1,29 @@
+"""Copies the artefacts scripts/r02_profile.sh left under gpurun_out/r02/ into profiles/ (the tracked copies the
+documents cite) and rebuilds the per-launch HBM traffic summary from the two counter passes."""
+import csv, json, os, shutil
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(R, "gpurun_out", "r02")
+P = os.path.join(R, "profiles")
+for src, dst in (("bench_n1e6_m1024.json", "r02_bench_n1e6_m1024.json"), ("bench_under_rocprof.json", "r02_bench_n1e6_m1024_under_rocprof.json"),
+                 ("trace/bench_kernel_stats.csv", "r02_bench_n1e6_m1024_kernel_stats.csv"),
+                 ("trace_all/bench_all_kernel_stats.csv", "r02_bench_all_side_measurements_kernel_stats.csv"),
+                 ("configs.md", "r02_configs.md"), ("process_perf.txt", "r02_fused_process_perf.txt"), ("latency_probe.txt", "r02_latency_probes.txt")):
+    shutil.copy(os.path.join(O, src), os.path.join(P, dst))
+cols = ("Counter_Name", "Counter_Value", "Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Start_Timestamp", "End_Timestamp")
+rows, vals = [], {}
+for tag, f in (("WRITE_SIZE", "pmc_w/w_counter_collection.csv"), ("FETCH_SIZE", "pmc_f/f_counter_collection.csv")):
+    sel = [x for x in csv.DictReader(open(os.path.join(O, f))) if "forward_rows_kernel" in x["Kernel_Name"] and x["Counter_Name"] == tag]
+    vals[tag] = [float(x["Counter_Value"]) for x in sel]
+    rows += [[x[k] for k in cols] for x in sel]
+with open(os.path.join(P, "r02_bench_n1e6_m1024_pmc.csv"), "w", newline="") as f:
+    w = csv.writer(f); w.writerow(cols); w.writerows(rows)
+W = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]); F = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
+j = json.load(open(os.path.join(P, "hbm_traffic.json")))
+j["WRITE_SIZE_KiB"] = W; j["FETCH_SIZE_KiB_raw"] = F; j["bytes_per_launch"] = int(W * 1024 + 2 * F * 1024)
+json.dump(j, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+b = json.loads(open(os.path.join(P, "r02_bench_n1e6_m1024.json")).read())
+u = json.loads(open(os.path.join(P, "r02_bench_n1e6_m1024_under_rocprof.json")).read())
+print("launches", len(vals["WRITE_SIZE"]), "WRITE KiB", W, "FETCH KiB", F, "bytes", j["bytes_per_launch"])
+print("value", b["value"], "pair", b["analysis_plus_synthesis_msamples_s"], "frac", b["roofline"]["frac"], "avg ms", b["roofline"]["avg_launch_ms"], "| under rocprof", u["value"], u["roofline"]["avg_launch_ms"])
+print("fused", b["fused_process"]["tree_sum_msamples_s"], "n48000", b["north_star_n48000"]["sync"]["frac_of_peak_wall"], b["north_star_n48000"]["async"]["frac_of_peak_wall"])
+print("hop", b["hop100_m1000"])
