@@ -98,3 +98,76 @@ def test_random_geometry_parity(seed):
         else:
             assert rel_err(g2, w2) <= 1e-11, (tag, rel_err(g2, w2))
         assert np.array_equal(y, ref.isdft(g2)), tag       # synthesis of the same matrix: bit-identical
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_fused_call_parity(seed):
+    """sdft_hip_process_n over random sizes, windows, latencies, operations, channel counts, call lengths (one time
+    chunk / several), with and without the reference's summation order: within the path's bar of the two
+    reference calls relative to the stream, bit-identical where asked for and possible, and the stream state
+    (checked through a following analysis call) the one the two calls leave."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    rng = np.random.default_rng(7000 + seed)
+    for case in range(5):
+        combo = O.COMBOS[int(rng.integers(0, 4))]
+        td, fd, fdx = O.combo_types(combo)
+        m = int(rng.choice([8, 9, 31, 63, 64, 65, 127, 129, 500, 1000, 1023, 1024, 1025, 1100, 2047, 2048, 2049, 2500, 4096, 4100]))
+        if m > 1100 and rng.random() < 0.6:
+            m = int(rng.integers(8, 400))
+        window = WINDOWS[int(rng.integers(0, 4))]
+        latency = float(rng.choice([1.0, 0.5, 0.3]))
+        ch = int(rng.choice([1, 1, 2, 3]))
+        lens = [int(rng.integers(1, max(2, min(5000, 2_000_000 // max(m * ch, 1))))), int(rng.integers(1, 511)), int(rng.integers(1, 300))]
+        op = ("identity", "gain", "shift")[int(rng.integers(0, 3))]
+        shift = int(rng.integers(-6, 7))
+        gain = (rng.random(m) * 2.0).astype(fd)
+        opts = {"fused_exact": int(rng.choice([-1, 0, 1])), "carry": int(rng.integers(0, 2)), "fold": int(rng.choice([1, 1, 0]))}
+        tag = (seed, case, combo, m, window, latency, ch, lens, op, shift, opts)
+        refs = [O.best(m, window, latency, combo) for _ in range(ch)]
+        gots, wants = [], []
+        bit_identical = True
+        with SDFT(m, window, latency, combo, channels=ch) as p:
+            for k, v in opts.items():
+                p.set_option(k, v)
+            for i, n in enumerate(lens):
+                xb = np.stack([noise(n, seed=seed * 1000 + case * 10 + i * 3 + c, dtype=td) for c in range(ch)])
+                want = []
+                for c, r in enumerate(refs):
+                    d = r.sdft(xb[c])
+                    if op == "gain":
+                        d = (d * gain[None, :].astype(d.real.dtype)).astype(d.dtype)
+                    elif op == "shift":
+                        s = np.zeros_like(d)
+                        if shift >= 0:
+                            s[:, shift:] = d[:, :m - shift] if shift < m else 0
+                        else:
+                            s[:, :m + shift] = d[:, -shift:]
+                        d = s
+                    want.append(r.isdft(d))
+                want = np.stack(want)
+                xin = xb if ch > 1 else xb[0]
+                got = p.process(torch.from_numpy(xin).cuda(), op, gain=gain, shift=shift).cpu().numpy() if i % 2 == 0 else \
+                    p.process(xin, op, gain=gain, shift=shift)
+                got = got if ch > 1 else got[None, :]
+                # bits: reference order asked for (or implied by carry = 1 at FD double) AND the analysis exact
+                exact_analysis = bit_identical and (combo[3:] == "f32" or opts["carry"] == 1 or p.get_option("last_chunks") == 1)
+                bit_identical = exact_analysis                      # a chunk-parallel FD double call leaves a state off by rounding
+                ordered = opts["fused_exact"] == 1 or (opts["fused_exact"] < 0 and opts["carry"] == 1 and combo[3:] == "f64")
+                if ordered and exact_analysis:
+                    assert np.array_equal(got, want), (tag, i)
+                gots.append(got); wants.append(want)
+            x3 = noise(60, seed=seed + 77, dtype=td)
+            state_exact = bit_identical
+            g3 = p.sdft(np.stack([x3] * ch) if ch > 1 else x3)
+            g3 = g3 if ch > 1 else g3[None]
+            for c, r in enumerate(refs):
+                w3 = r.sdft(x3)
+                if state_exact:
+                    assert np.array_equal(g3[c], w3), (tag, "state", c)
+                else:
+                    assert rel_err(g3[c], w3) <= 1e-11, (tag, "state", c)
+        tol = 1e-6 if combo[3:] == "f64" else 1e-4
+        allg, allw = np.concatenate(gots, axis=1), np.concatenate(wants, axis=1)
+        for c in range(ch):
+            assert rel_err(allg[c], allw[c]) <= tol, (tag, c, rel_err(allg[c], allw[c]))
