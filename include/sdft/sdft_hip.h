@@ -55,14 +55,15 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
      sdft_hip_op_identity  params = NULL
      sdft_hip_op_gain      params = sdft_fd_t gains[dftsize]  (host or device): X'[k] = X[k] * gains[k]
      sdft_hip_op_shift     params = const long* (host): X'[k] = X[k - *params], zero outside the spectrum
+     sdft_hip_op_cgain     params = sdft_fdx_t gains[dftsize] (host or device): X'[k] = X[k] * gains[k], complex
    dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
-   (identity / gain only).  Batched plans: samples / out [channels][nsamples].
+   (not with the shift).  Batched plans: samples / out [channels][nsamples].
    Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the path's bar (1e-6
    relative at FD double, 1e-4 at FD float; measured 1e-13 / 1.2e-5); bit-identical on request (option
    "fused_exact" = 1) wherever the analysis is: calls shorter than 512 samples, FD float, FD double with
    carry = 1.  The stream state a call leaves behind is the one the two calls leave.  Returns 0, or -1
    with sdft_hip_last_error() set. */
-enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2 };
+enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2, sdft_hip_op_cgain = 3 };
 int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t* samples, sdft_td_t* const out,
                        const int op, const void* params, sdft_fdx_t* dfts) SDFT_HIP_SYMBOL(process_n);
 

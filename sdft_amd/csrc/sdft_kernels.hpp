@@ -1888,11 +1888,11 @@ __global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD
 // output bins in ascending order; a shift keeps source bins in the same order, and the bins it
 // empties add +-0, which never changes a running sum that started at +0.
 // ------------------------------------------------------------------------------------------
-enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2 };
+enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2, OP_CGAIN = 3 };
 template <typename FD> struct SpectralOp
 {
   int kind;
-  const FD* gain;             // [N], OP_GAIN
+  const FD* gain;             // OP_GAIN: [N] real factors; OP_CGAIN: [N] complex factors (re, im interleaved)
   long shift;                 // OP_SHIFT
 };
 
@@ -1903,6 +1903,7 @@ SDFT_D FD synth_term(cx<FD> v, unsigned k, const SpectralOp<FD>& op, const cx<FD
   if constexpr (OPS)                                       // (plain sdft_isdft_n instantiates without the checks)
   {
     if (op.kind == OP_GAIN) v = cscale(v, op.gain[k < nbins ? k : 0]);
+    else if (op.kind == OP_CGAIN) v = cmul(v, reinterpret_cast<const cx<FD>*>(op.gain)[k < nbins ? k : 0]);
     else if (op.kind == OP_SHIFT)
     {
       ko += op.shift;
@@ -2158,6 +2159,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         {
           const unsigned k = off_elems[q] + (unsigned)b;
           if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], fz.op.gain[keep[q][b] ? k : 0]);
+          else if (fz.op.kind == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(fz.op.gain)[keep[q][b] ? k : 0]);
           SpectralOp<FD> shift_only; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
           shift_only.gain = nullptr; shift_only.shift = fz.op.shift;
           const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
@@ -2421,6 +2423,13 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(double* alpha, doubl
       if (lat1) { A = (ko & 1) ? -1.0 : +1.0; B = 0.0; }                     // sdft.h:643
       else { A = (double)syn[ko].re; B = -(double)syn[ko].im; }              // re(Y * twiddle), :650
       if (op.kind == OP_GAIN) { A *= (double)op.gain[j]; B *= (double)op.gain[j]; }
+      else if (op.kind == OP_CGAIN)
+      {
+        // term = re(Y * g * (A - iB)): the factors of re Y and im Y after the complex gain
+        const cx<FD> g = reinterpret_cast<const cx<FD>*>(op.gain)[j];
+        const double cr = (double)g.re * A + (double)g.im * B, ci = (double)g.im * A - (double)g.re * B;
+        A = cr; B = -ci;
+      }
       al += h[i + 2] * A;
       be += (flip ? -(h[i + 2] * B) : h[i + 2] * B);        // the mirror image is the conjugate
     }
@@ -2803,14 +2812,15 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
 
 // rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
 template <typename FD>
-__global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain)
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain,
+                                                            int complex_gain)
 {
   const size_t per = rows * nbins, total = per * channels;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
   {
     const size_t ch = i / per, r = i - ch * per;
     cx<FD>* p = mat + ch * stride + r;
-    *p = cscale(*p, gain[r % nbins]);
+    *p = complex_gain ? cmul(*p, reinterpret_cast<const cx<FD>*>(gain)[r % nbins]) : cscale(*p, gain[r % nbins]);
   }
 }
 

@@ -778,8 +778,8 @@ class Plan
     pa.alpha = d_alpha.p; pa.beta = d_beta.p; pa.partial = d_partial.p; pa.tickets = d_tickets.p;
     pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
     if (!prof_begin(ST_FORWARD)) return false;
-    if (latency == 1) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
-    else              hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    else                 hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
     hist_cur ^= 1; st_cur ^= 1;
@@ -871,14 +871,16 @@ class Plan
   // folded form of the fused call (process_rows_kernel): per-bin coefficients from the plan's window and
   // synthesis tables and the call's operation, then one launch per overlap segment
   DevBuf<double> d_alpha, d_beta;
-  bool coeff_ready = false;
+  bool coeff_ready = false, coeff_has_beta = false;
   int coeff_kind = -1; long coeff_shift = 0;
   bool fold_coefficients(const SpectralOp<FD>& op)
   {
     coeff_ready = false;
     if (!opt_fold || nbins < 8) return true;
     // identity and shift depend on the plan only: folded once; a gain array may change between calls
-    if (op.kind != OP_GAIN && coeff_kind == op.kind && coeff_shift == op.shift && d_alpha.p) { coeff_ready = true; return true; }
+    const bool has_array = op.kind == OP_GAIN || op.kind == OP_CGAIN;
+    coeff_has_beta = !(latency == 1) || op.kind == OP_CGAIN;                     // im X enters through the synthesis twiddle or a complex gain
+    if (!has_array && coeff_kind == op.kind && coeff_shift == op.shift && d_alpha.p) { coeff_ready = true; return true; }
     if (!d_alpha.reserve(nbins) || !d_beta.reserve(nbins)) return false;
     const FD w = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // as ForwardArgs::wscale
     FD h0 = w, h1 = (FD)0, h2 = (FD)0;                                                   // taps of window_tap()
@@ -911,7 +913,7 @@ class Plan
     const long waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
     const long slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
     const unsigned threads = (unsigned)(waves * kWave);
-    const bool hasb = !(latency == 1);
+    const bool hasb = coeff_has_beta;
     if constexpr (sizeof(FD) == 8)
     {
       if (fused) { if (hasb) launch_process_t<true, true>(fa, pz, blocks, threads, slots); else launch_process_t<true, false>(fa, pz, blocks, threads, slots); SDFT_TRY(hipGetLastError()); return true; }
@@ -1258,7 +1260,7 @@ class Plan
   // ---- fused analysis -> spectral operation -> synthesis ------------------------
   // y[t] = sdft_isdft( op( sdft_sdft(x[t]) ) ) with the reference's arithmetic, without the (n, N)
   // matrix ever reaching HBM unless the caller asks for a copy of the processed spectrum in `dfts`.
-  // params: OP_GAIN -> FD gains[N] (host or device memory), OP_SHIFT -> const long* (host).
+  // params: OP_GAIN -> FD gains[N], OP_CGAIN -> cx<FD> gains[N] (host or device memory), OP_SHIFT -> const long* (host).
   DevBuf<FD> d_gain;
   DevBuf<TD> d_stage_y;
   bool fuse_ok() const { return rows_kernel_ok(false); }
@@ -1272,7 +1274,7 @@ class Plan
   {
     if (n == 0) return true;
     if (!bind()) return false;
-    if (op_kind < OP_IDENTITY || op_kind > OP_SHIFT) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
+    if (op_kind < OP_IDENTITY || op_kind > OP_CGAIN) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
     if ((op_kind != OP_IDENTITY) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
     if (op_kind == OP_SHIFT && dfts) { set_error("sdft_hip_process_n", "a copy of the spectrum is not available with the shift operation"); return false; }
     const bool yd = on_device(y);
@@ -1283,13 +1285,14 @@ class Plan
     }
     if (dfts && !on_device(dfts)) { set_error("sdft_hip_process_n", "dfts must be device memory (or NULL)"); return false; }
     SpectralOp<FD> op; op.kind = op_kind; op.gain = nullptr; op.shift = 0;
-    if (op_kind == OP_GAIN)
+    if (op_kind == OP_GAIN || op_kind == OP_CGAIN)
     {
       const FD* g = static_cast<const FD*>(params);
+      const size_t per_bin = op_kind == OP_CGAIN ? 2 : 1;          // real factors, or (re, im) pairs
       if (!on_device(g))
       {
-        if (!d_gain.reserve(nbins)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, nbins * sizeof(FD), hipMemcpyHostToDevice, stream));
+        if (!d_gain.reserve(nbins * 2)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, nbins * per_bin * sizeof(FD), hipMemcpyHostToDevice, stream));
         g = d_gain.p;
       }
       op.gain = g;
@@ -1362,7 +1365,7 @@ class Plan
         fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
         const size_t mstride = dfts ? n * nbins : m * nbins;
         ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &op);
-        if (ok && op_kind == OP_GAIN && dfts) ok = scale_rows(mat, mstride, m, op.gain);
+        if (ok && (op_kind == OP_GAIN || op_kind == OP_CGAIN) && dfts) ok = scale_rows(mat, mstride, m, op.gain, op_kind == OP_CGAIN);
       }
     }
     if (!ok) return false;
@@ -1375,11 +1378,11 @@ class Plan
   }
 
   // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)
-  bool scale_rows(fdx* mat, size_t stride, size_t rows, const FD* gain)
+  bool scale_rows(fdx* mat, size_t stride, size_t rows, const FD* gain, bool complex_gain)
   {
     const size_t total = channels * rows * nbins;
     const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
-    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, gain);
+    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, gain, complex_gain ? 1 : 0);
     SDFT_TRY(hipGetLastError());
     return true;
   }

@@ -206,17 +206,19 @@ class SDFT:
         processed samples; the DFT matrix is not materialised unless ``dfts`` (a CUDA tensor of shape
         (n, dftsize) [(channels, n, dftsize)]) asks for a copy of the processed spectrum.
 
-        ``op``: "identity", "gain" (``gain`` = real array of dftsize factors) or "shift" (``shift`` bins).
+        ``op``: "identity", "gain" (``gain`` = real array of dftsize factors), "cgain" (``gain`` = complex array)
+        or "shift" (``shift`` bins).
         """
         kind = OPS[op] if isinstance(op, str) else int(op)
         params = None
         keep = None
-        if kind == OPS["gain"]:
+        if kind in (OPS["gain"], OPS["cgain"]):
+            gdt = self.fd if kind == OPS["gain"] else self.fdx
             if _is_tensor(gain):
-                self._check_tensor(gain, "gain", self.fd, (self.dftsize,))
+                self._check_tensor(gain, "gain", gdt, (self.dftsize,))
                 params = C.c_void_p(gain.data_ptr())
             else:
-                keep = np.ascontiguousarray(gain, dtype=self.fd)
+                keep = np.ascontiguousarray(gain, dtype=gdt)
                 assert keep.shape == (self.dftsize,)
                 params = C.c_void_p(keep.ctypes.data)
         elif kind == OPS["shift"]:

@@ -5,7 +5,7 @@
  * steps through the drop-in functions on a second plan.  Built by tests/test_gpu_chost.py with
  *   gcc -std=c99 -Iinclude [-DSDFT_FD_FLOAT] host_process.c -lsdft_hip -lamdhip64 -lm
  *
- * usage: host_process <dftsize> <hopsize> <op: 0 identity | 1 gain | 2 shift> <x.raw> <y_fused.raw> <y_threestep.raw>
+ * usage: host_process <dftsize> <hopsize> <op: 0 identity | 1 gain | 2 shift | 3 complex gain> <x.raw> <y_fused.raw> <y_threestep.raw>
  */
 
 #include <stdio.h>
@@ -35,7 +35,14 @@ int main(int argc, char* argv[])
   sdft_fd_t* gain = (sdft_fd_t*)malloc(m * sizeof(sdft_fd_t));
   for (size_t k = 0; k < m; ++k) gain[k] = (sdft_fd_t)(1.0 / (1.0 + (double)k / 64.0));
   const long shift = 3;
-  const void* params = op == 1 ? (const void*)gain : (op == 2 ? (const void*)&shift : NULL);
+  /* complex factors: the real ones with the phase of a two-sample delay at every other bin (exact in binary) */
+  sdft_fdx_t* cgain = (sdft_fdx_t*)malloc(m * sizeof(sdft_fdx_t));
+  for (size_t k = 0; k < m; ++k)
+  {
+    cgain[k].r = (k % 4 == 0) ? gain[k] : (k % 4 == 2 ? -gain[k] : 0);
+    cgain[k].i = (k % 4 == 1) ? gain[k] : (k % 4 == 3 ? -gain[k] : 0);
+  }
+  const void* params = op == 1 ? (const void*)gain : (op == 2 ? (const void*)&shift : (op == 3 ? (const void*)cgain : NULL));
 
   sdft_t* fused = sdft_alloc_custom(m, sdft_window_hann, 1);
   sdft_t* plain = sdft_alloc_custom(m, sdft_window_hann, 1);
@@ -58,6 +65,13 @@ int main(int argc, char* argv[])
     {
       sdft_fdx_t* row = dfts + t * m;
       if (op == 1) for (size_t k = 0; k < m; ++k) { row[k].r *= gain[k]; row[k].i *= gain[k]; }
+      if (op == 3)
+        for (size_t k = 0; k < m; ++k)
+        {
+          const sdft_fdx_t v = row[k], g = cgain[k];
+          row[k].r = v.r * g.r - v.i * g.i;
+          row[k].i = v.r * g.i + v.i * g.r;
+        }
       if (op == 2)
       {
         for (size_t k = 0; k < m; ++k)
@@ -74,7 +88,7 @@ int main(int argc, char* argv[])
 
   f = fopen(argv[5], "wb"); fwrite(y1, sizeof(sdft_td_t), n, f); fclose(f);
   f = fopen(argv[6], "wb"); fwrite(y2, sizeof(sdft_td_t), n, f); fclose(f);
-  free(tmp); free(dfts); free(y2); free(y1); free(gain); free(x);
+  free(tmp); free(dfts); free(y2); free(y1); free(cgain); free(gain); free(x);
   sdft_free(fused); sdft_free(plain);
   printf("C-PROCESS ok n=%zu hops=%zu\n", n, n / hop);
   return 0;

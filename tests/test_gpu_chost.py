@@ -59,7 +59,7 @@ def test_c_host_streaming(tmp_path, hip_library, flags, combo):
 
 
 @pytest.mark.parametrize("flags,combo", [([], "f32f64"), (["-DSDFT_FD_FLOAT"], "f32f32")])
-@pytest.mark.parametrize("op", [0, 1, 2])
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
 def test_c_host_fused_process(tmp_path, hip_library, flags, combo, op):
     """tests/c/host_process.c: sdft_hip_process_n from a gcc-built C host (hops of 100 and calls of 4000
     samples) against the same host running the reference's three steps through the drop-in
@@ -91,6 +91,9 @@ def test_c_host_fused_process(tmp_path, hip_library, flags, combo, op):
                 d = (d * gain[None, :]).astype(fdx)
             if op == 2:
                 s = np.zeros_like(d); s[:, 3:] = d[:, :m - 3]; d = s
+            if op == 3:                                       # gain * i^k: a multiplication by 1, i, -1, -i is exact
+                cg = (gain.astype(np.float64) * (1j ** (np.arange(m) % 4))).astype(fdx)
+                d = (d * cg[None, :]).astype(fdx)
             want.append(ref.isdft(d))
         want = np.concatenate(want)
         tol = 1e-6 if combo.endswith("f64") else 1e-4

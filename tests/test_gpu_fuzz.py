@@ -119,9 +119,10 @@ def test_random_fused_call_parity(seed):
         latency = float(rng.choice([1.0, 0.5, 0.3]))
         ch = int(rng.choice([1, 1, 2, 3]))
         lens = [int(rng.integers(1, max(2, min(5000, 2_000_000 // max(m * ch, 1))))), int(rng.integers(1, 511)), int(rng.integers(1, 300))]
-        op = ("identity", "gain", "shift")[int(rng.integers(0, 3))]
+        op = ("identity", "gain", "shift", "cgain")[int(rng.integers(0, 4))]
         shift = int(rng.integers(-6, 7))
         gain = (rng.random(m) * 2.0).astype(fd)
+        cgain = (gain.astype(np.float64) * np.exp(1j * rng.random(m) * 6.28)).astype(fdx)
         opts = {"fused_exact": int(rng.choice([-1, 0, 1])), "carry": int(rng.integers(0, 2)), "fold": int(rng.choice([1, 1, 0]))}
         tag = (seed, case, combo, m, window, latency, ch, lens, op, shift, opts)
         refs = [O.best(m, window, latency, combo) for _ in range(ch)]
@@ -137,6 +138,11 @@ def test_random_fused_call_parity(seed):
                     d = r.sdft(xb[c])
                     if op == "gain":
                         d = (d * gain[None, :].astype(d.real.dtype)).astype(d.dtype)
+                    elif op == "cgain":
+                        e = np.empty_like(d)                         # (ac - bd) + (ad + bc)i, every operation rounded
+                        e.real = d.real * cgain.real[None, :] - d.imag * cgain.imag[None, :]
+                        e.imag = d.real * cgain.imag[None, :] + d.imag * cgain.real[None, :]
+                        d = e
                     elif op == "shift":
                         s = np.zeros_like(d)
                         if shift >= 0:
@@ -147,8 +153,9 @@ def test_random_fused_call_parity(seed):
                     want.append(r.isdft(d))
                 want = np.stack(want)
                 xin = xb if ch > 1 else xb[0]
-                got = p.process(torch.from_numpy(xin).cuda(), op, gain=gain, shift=shift).cpu().numpy() if i % 2 == 0 else \
-                    p.process(xin, op, gain=gain, shift=shift)
+                g = cgain if op == "cgain" else gain
+                got = p.process(torch.from_numpy(xin).cuda(), op, gain=g, shift=shift).cpu().numpy() if i % 2 == 0 else \
+                    p.process(xin, op, gain=g, shift=shift)
                 got = got if ch > 1 else got[None, :]
                 # bits: reference order asked for (or implied by carry = 1 at FD double) AND the analysis exact
                 exact_analysis = bit_identical and (combo[3:] == "f32" or opts["carry"] == 1 or p.get_option("last_chunks") == 1)
@@ -167,7 +174,11 @@ def test_random_fused_call_parity(seed):
                     assert np.array_equal(g3[c], w3), (tag, "state", c)
                 else:
                     assert rel_err(g3[c], w3) <= 1e-11, (tag, "state", c)
+        # (streams shorter than 2N samples are still in their start-up: the synthesized samples are cancellation
+        # residue orders of magnitude below the input, so the bar is taken relative to the larger of the two scales)
         tol = 1e-6 if combo[3:] == "f64" else 1e-4
         allg, allw = np.concatenate(gots, axis=1), np.concatenate(wants, axis=1)
         for c in range(ch):
-            assert rel_err(allg[c], allw[c]) <= tol, (tag, c, rel_err(allg[c], allw[c]))
+            scale = max(float(np.abs(allw[c]).max()), 1.0)                       # noise(): unit variance input
+            err = float(np.abs(allg[c].astype(np.float64) - allw[c]).max()) / scale
+            assert err <= tol, (tag, c, err)

@@ -13,11 +13,24 @@ pytestmark = pytest.mark.gpu
 TOL = {"f64": 1e-6, "f32": 1e-4}
 
 
+def cgain_of(gain, fdx):
+    """The complex factors the "cgain" cases use: the test's real gains with a phase that turns with the bin."""
+    g = np.asarray(gain, dtype=np.float64)
+    return (g * np.exp(1j * 0.37 * np.arange(g.size))).astype(fdx)
+
+
 def make(dftsize, window="hann", latency=1.0, combo="f32f64", channels=1, **opts):
     from sdft_amd.sdft import SDFT
     p = SDFT(dftsize, window, latency, combo, channels)
     for k, v in opts.items():
         p.set_option(k, v)
+    plain = p.process
+
+    def process(x, op="identity", gain=None, shift=0, **kw):          # "cgain": complex factors derived from the real ones
+        if op == "cgain":
+            gain = cgain_of(gain, p.fdx)
+        return plain(x, op, gain=gain, shift=shift, **kw)
+    p.process = process
     return p
 
 
@@ -25,6 +38,12 @@ def apply_op(d, op, gain, shift):
     """What the host does to the (n, N) matrix between the two reference calls."""
     if op == "gain":
         return (d * gain[None, :].astype(d.real.dtype)).astype(d.dtype)     # complex * real, per component
+    if op == "cgain":
+        g = cgain_of(gain, d.dtype)
+        out = np.empty_like(d)                                               # (ac - bd) + (ad + bc)i, every operation rounded
+        out.real = d.real * g.real[None, :] - d.imag * g.imag[None, :]
+        out.imag = d.real * g.imag[None, :] + d.imag * g.real[None, :]
+        return out
     if op == "shift":
         out = np.zeros_like(d)
         n = d.shape[1]
@@ -46,7 +65,7 @@ def rel(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - b).max()) / (s if s else 1.0)
 
 
-OPS = [("identity", 0), ("gain", 0), ("shift", 3), ("shift", -5)]
+OPS = [("identity", 0), ("gain", 0), ("shift", 3), ("shift", -5), ("cgain", 0)]
 
 
 @pytest.mark.parametrize("op,shift", OPS)
@@ -113,7 +132,7 @@ def test_fused_two_slot_rows_bit_identical(combo, opts, m, window):
     n, ch = 2500, 2
     gain = np.cos(np.arange(m) * 0.05).astype(fd)
     xb = np.stack([noise(n, seed=11 + c, dtype=td) for c in range(ch)])
-    for latency, (op, shift) in ((1.0, OPS[0]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3])):
+    for latency, (op, shift) in ((1.0, OPS[0]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3]), (1.0, OPS[4])):
         want = [reference(O.best(m, window, latency, combo), xb[c], op, gain, shift)[0] for c in range(ch)]
         # FD float: fused_exact = 1 takes the two passes for these shapes (the ordered walk over 4096 bins costs
         # more than the pass it saves); fused_exact = 2 insists on the fused kernel -- same bits either way
@@ -170,7 +189,7 @@ def test_folded_form_matches_reference(window, combo, m):
     x2 = noise(900, seed=6, dtype=td)
     gain = (1.0 + 0.5 * np.sin(np.arange(m) * 0.37)).astype(fd)
     tol = TOL[combo[3:]]
-    for latency, (op, shift) in ((1.0, OPS[0]), (1.0, OPS[1]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3]), (0.5, OPS[0])):
+    for latency, (op, shift) in ((1.0, OPS[0]), (1.0, OPS[1]), (0.5, OPS[1]), (1.0, OPS[2]), (0.5, OPS[3]), (0.5, OPS[0]), (1.0, OPS[4]), (0.5, OPS[4])):
         ref = O.best(m, window, latency, combo)
         want, _ = reference(ref, x, op, gain, shift)
         want2, _ = reference(ref, x2, op, gain, shift)
