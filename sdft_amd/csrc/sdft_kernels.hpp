@@ -8,10 +8,19 @@
 //   chunk_sum_kernel      K1a  the same sums directly (any other N)
 //   carry_scan_kernel     K1b  exclusive scan over chunks -> carry-in of every time chunk
 //   carry_exact_kernel    K1a' serial pass with the reference's rounding sequence (FD float)
-//   forward_rows_kernel   K1   one workgroup per (chunk, row): LDS edge exchange, lockstep row stores
+//   fid_seed_kernel, carry_ring_kernel, carry_chain_kernel
+//                         K1a' exact carries, chain form: rotations regenerated from a seed table by producer
+//                              waves, one dependent addition per step on a consumer wave (LDS ring / rounds)
+//   forward_rows_kernel   K1   one workgroup per (chunk, row): LDS edge exchange, lockstep row stores;
+//                              SYN != 0: fused synthesis (terms in LDS, tree sum or the reference's order)
 //   forward_kernel        K1   independent waves with halo lanes (any N, row-pointer outputs)
+//   forward_hop_kernel    K1h  calls of one time chunk: differences + analysis in one launch
 //   inverse_exact_kernel  K2   synthesis, bins summed in the reference's order (LDS transpose)
+//   inverse_row_kernel    K2   the same for few rows: one wave per row
 //   inverse_kernel        K2   synthesis, wave-parallel tree sum (measurement alternative)
+//   fold_coeff_kernel, process_rows_kernel, process_hop_kernel
+//                         K3   fused analysis -> operation -> synthesis, folded form: one coefficient per bin
+//                              instead of window + operation + synthesis term; long calls / calls of one chunk
 //
 // Common decomposition: lanes <-> frequency bins (one complex bin per lane for 16-byte bins, two
 // adjacent bins per lane for 8-byte bins, so a lane always stores 16 B), the sample loop is carried
@@ -22,8 +31,9 @@
 //
 // Arithmetic follows the reference's struct-complex formulas operation by operation and the
 // translation units are compiled with -ffp-contract=off: given the same carry-in a wave
-// reproduces the reference bit for bit (the FUSED instantiation of forward_rows_kernel is the
-// one deliberate exception, used only where the carry-in already differs in summation order).
+// reproduces the reference bit for bit (the FUSED instantiations of forward_rows_kernel and
+// process_rows_kernel are the deliberate exceptions, used only where the carry-in already differs
+// in summation order).
 
 #pragma once
 
