@@ -2662,6 +2662,10 @@ template <typename TD, typename FD> struct ProcHopArgs
   const double* beta;
   double* partial;            // [channels][tiles][n]
   unsigned* tickets;          // [channels], zero between calls
+  unsigned* done_flag;        // host-visible word (pinned memory) or nullptr: set to done_seq once every channel's
+  unsigned done_seq;          //   samples are written -- a synchronous host polls it instead of the stream
+  unsigned* done_count;       // channels finished (zero between calls)
+  unsigned channels;
   size_t n;
   unsigned nbins, tiles, cursor0;
   FD sweight;
@@ -2812,6 +2816,17 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
     }
     if (t0 < a.n) yo[t0] = (TD)(p0 * (AT)a.sweight);                                    // sdft.h:654-656
     if (t1 < a.n) yo[t1] = (TD)(p1 * (AT)a.sweight);
+  }
+  // completion word for a synchronous host: the launch's last channel publishes it after its samples (a kernel's
+  // end reaches the host ~6 us later than a store to pinned memory does)
+  if (a.done_flag && lane == 0)
+  {
+    const unsigned finished = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (finished + 1u == a.channels)
+    {
+      __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 #ifdef SDFT_HOP_STAMPS
   SDFT_HOP_STAMP(4);

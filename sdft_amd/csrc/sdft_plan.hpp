@@ -241,6 +241,7 @@ class Plan
     d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release(); d_fseed.release();
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
+    if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -757,17 +758,33 @@ class Plan
   // fused call, one time chunk, folded form: one launch (process_hop_kernel); the caller has folded the coefficients
   DevBuf<double> d_partial;
   DevBuf<unsigned> d_tickets;
-  bool process_hop(size_t n, const TD* x, size_t x_stride, TD* y, size_t y_stride)
+  // completion word in pinned host memory (process_hop_kernel writes it, finish() polls it)
+  unsigned* h_done_flag = nullptr;
+  unsigned* d_done_flag = nullptr;
+  unsigned flag_seq = 0;
+  bool flag_pending = false;
+  bool ensure_flag()
+  {
+    if (h_done_flag) return true;
+    if (hipHostMalloc((void**)&h_done_flag, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_done_flag = nullptr; return false; }
+    *h_done_flag = 0;
+    if (hipHostGetDevicePointer((void**)&d_done_flag, h_done_flag, 0) != hipSuccess)
+    {
+      (void)hipGetLastError(); (void)hipHostFree(h_done_flag); h_done_flag = nullptr; return false;
+    }
+    return true;
+  }
+  bool process_hop(size_t n, const TD* x, size_t x_stride, TD* y, size_t y_stride, bool want_flag)
   {
     const size_t nb = nbins, span = 2 * nbins;
     const size_t ptiles = (nb + kWave - 1) / kWave;
     if (!grid_fits(channels * ptiles)) return false;
     if (!d_partial.reserve(channels * ptiles * n + 8)) return false;     // + stamps of the development build
     last_partial_elems = channels * ptiles * n;
-    if (d_tickets.cap < channels)
+    if (d_tickets.cap < channels + 1)                        // [channels] tickets + the count of finished channels
     {
-      if (!d_tickets.reserve(channels)) return false;
-      SDFT_TRY(hipMemsetAsync(d_tickets.p, 0, channels * sizeof(unsigned), stream));
+      if (!d_tickets.reserve(channels + 1)) return false;
+      SDFT_TRY(hipMemsetAsync(d_tickets.p, 0, (channels + 1) * sizeof(unsigned), stream));
     }
     ProcHopArgs<TD, FD> pa;
     pa.x = x; pa.x_stride = x_stride; pa.y = y; pa.y_stride = y_stride;
@@ -777,6 +794,13 @@ class Plan
     pa.acc_out = d_accs[st_cur ^ 1].p; pa.fid_out = d_fids[st_cur ^ 1].p;
     pa.alpha = d_alpha.p; pa.beta = d_beta.p; pa.partial = d_partial.p; pa.tickets = d_tickets.p;
     pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
+    // synchronous device-pointer calls: the kernel tells the host through a word of pinned memory
+    pa.done_flag = nullptr; pa.done_seq = 0; pa.done_count = d_tickets.p + channels; pa.channels = (unsigned)channels;
+    flag_pending = false;
+    if (want_flag && !async && !profile && opt_spin && ensure_flag())
+    {
+      pa.done_flag = d_done_flag; pa.done_seq = ++flag_seq; flag_pending = true;
+    }
     if (!prof_begin(ST_FORWARD)) return false;
     if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
     else                 hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
@@ -1018,6 +1042,15 @@ class Plan
   bool finish(size_t work = 0)
   {
     if (async) return true;
+    if (flag_pending)
+    {
+      // the kernel's completion word: visible ~6 us before the stream reports the kernel done
+      flag_pending = false;
+      volatile unsigned* f = h_done_flag;
+      for (int spins = 0; spins < 4000000; ++spins)
+        if (*f == flag_seq) return true;
+      return synchronize();                                  // never seen: fall back to the stream
+    }
     if (opt_spin && work && work <= ((size_t)1 << 24))
     {
       for (int spins = 0; spins < 20000; ++spins)
@@ -1325,7 +1358,7 @@ class Plan
     {
       if (!fold_coefficients(op)) return false;
       last_process_path = 1;
-      ok = coeff_ready && process_hop(n, xs, n, ys, n);
+      ok = coeff_ready && process_hop(n, xs, n, ys, n, xd && yd);
     }
     else if (fuse_ok() && chunks > 1 && !walk_loses)
     {
