@@ -224,6 +224,27 @@ template <typename FD> SDFT_D FD wave_sum_f(FD v)
 
 template <typename FD> struct BinState { cx<FD> acc, fid, tw; };
 
+// Completion word for synchronous short calls.  A kernel's end reaches the host ~6 us later than a store to pinned
+// host memory does (scripts/launch_latency.hip): the launch's last workgroup -- found by an agent-scope ticket that
+// also publishes the workgroup's stores -- sets `flag` to `seq`, and the host polls that word instead of the stream.
+struct DoneSignal
+{
+  unsigned* flag;             // pinned host memory, or nullptr: no signal wanted
+  unsigned* count;            // device word, zero between launches
+  unsigned seq, total;        // value to publish, workgroups that must have finished
+};
+// call with the workgroup's stores issued; one lane of the workgroup's last wave
+SDFT_D void signal_done(const DoneSignal& d)
+{
+  if (!d.flag) return;
+  const unsigned finished = __hip_atomic_fetch_add(d.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (finished + 1u == d.total)
+  {
+    __hip_atomic_store(d.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // normal step (sdft.h:583-585) -- returns the demodulated bin
 template <typename FD> SDFT_D cx<FD> step_normal(BinState<FD>& s, FD delta)
 {
@@ -1695,6 +1716,7 @@ template <typename TD, typename FD> struct HopArgs
   unsigned nbins, tiles, interior_lanes, cursor0;
   int vec_store;
   FD wscale;
+  DoneSignal done;            // WPB == 1 launches only: total = workgroups
 };
 
 template <typename TD, typename FD, int BPL, int WIN, bool ROWS, int WPB>
@@ -1885,6 +1907,7 @@ __global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD
       a.acc_out[sbase + kfirst + b] = s[b].acc;
       a.fid_out[sbase + kfirst + b] = s[b].fid;
     }
+  if constexpr (WPB == 1) { if (lane == 0) signal_done(a.done); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2662,10 +2685,7 @@ template <typename TD, typename FD> struct ProcHopArgs
   const double* beta;
   double* partial;            // [channels][tiles][n]
   unsigned* tickets;          // [channels], zero between calls
-  unsigned* done_flag;        // host-visible word (pinned memory) or nullptr: set to done_seq once every channel's
-  unsigned done_seq;          //   samples are written -- a synchronous host polls it instead of the stream
-  unsigned* done_count;       // channels finished (zero between calls)
-  unsigned channels;
+  DoneSignal done;            // total = channels: every channel's last workgroup reports
   size_t n;
   unsigned nbins, tiles, cursor0;
   FD sweight;
@@ -2819,15 +2839,7 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
   }
   // completion word for a synchronous host: the launch's last channel publishes it after its samples (a kernel's
   // end reaches the host ~6 us later than a store to pinned memory does)
-  if (a.done_flag && lane == 0)
-  {
-    const unsigned finished = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (finished + 1u == a.channels)
-    {
-      __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  if (lane == 0) signal_done(a.done);
 #ifdef SDFT_HOP_STAMPS
   SDFT_HOP_STAMP(4);
   if (lane == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<unsigned long long*>(a.partial + (size_t)gridDim.x * a.n)[i] = stamp[i];
@@ -2861,6 +2873,7 @@ template <typename TD, typename FD> struct InverseArgs
   unsigned nbins, channels;
   FD sweight;
   SpectralOp<FD> op;          // applied to every bin on the way in (identity for sdft_isdft_n)
+  DoneSignal done;            // inverse_row_kernel only: total = rows
 };
 
 template <typename TD, typename FD, bool LAT1, bool OPS = false>
@@ -3086,7 +3099,11 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);                   // sdft.h:654-656
+  if (lane == 0)
+  {
+    a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);                                 // sdft.h:654-656
+    signal_done(a.done);
+  }
 }
 
 }  // namespace sdfthip

@@ -242,6 +242,7 @@ class Plan
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
+    d_done_count.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -257,7 +258,7 @@ class Plan
   }
 
   // a host driving several GPUs from one process may have switched the current device
-  bool bind() { SDFT_TRY(hipSetDevice(device)); return true; }
+  bool bind() { flag_pending = false; flag_wanted = false; SDFT_TRY(hipSetDevice(device)); return true; }
 
   // sdft.h:517-529
   bool reset()
@@ -491,6 +492,7 @@ class Plan
     if (n == 0 || nbins == 0) return true;
     const size_t nb = nbins, span = 2 * nbins;
     SDFT_TRY(hipSetDevice(device));
+    flag_pending = false;                                    // only the hop kernel signals its completion
 
     const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
@@ -743,6 +745,7 @@ class Plan
     const bool wide = ha.total_waves > 2048;
     const unsigned long long blocks = wide ? (ha.total_waves + 3) / 4 : ha.total_waves;
     if (!grid_fits(blocks)) return false;
+    ha.done = arm_flag(wide ? 0u : (unsigned)blocks);
     if (!prof_begin(ST_FORWARD)) return false;
     if (rows) { if (wide) launch_hop_t<true, 4>(ha, (unsigned)blocks); else launch_hop_t<true, 1>(ha, (unsigned)blocks); }
     else      { if (wide) launch_hop_t<false, 4>(ha, (unsigned)blocks); else launch_hop_t<false, 1>(ha, (unsigned)blocks); }
@@ -758,14 +761,19 @@ class Plan
   // fused call, one time chunk, folded form: one launch (process_hop_kernel); the caller has folded the coefficients
   DevBuf<double> d_partial;
   DevBuf<unsigned> d_tickets;
-  // completion word in pinned host memory (process_hop_kernel writes it, finish() polls it)
+  // completion word in pinned host memory: the kernels of short synchronous calls set it (signal_done), finish()
+  // polls it.  flag_wanted: the public entry point has device pointers on both sides and will end in finish();
+  // flag_pending: the call's LAST launch was armed (every entry point starts with both false, see bind()).
   unsigned* h_done_flag = nullptr;
   unsigned* d_done_flag = nullptr;
+  DevBuf<unsigned> d_done_count;
   unsigned flag_seq = 0;
-  bool flag_pending = false;
+  bool flag_pending = false, flag_wanted = false;
   bool ensure_flag()
   {
     if (h_done_flag) return true;
+    if (!d_done_count.reserve(2)) return false;
+    if (hipMemsetAsync(d_done_count.p, 0, 2 * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipHostMalloc((void**)&h_done_flag, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_done_flag = nullptr; return false; }
     *h_done_flag = 0;
     if (hipHostGetDevicePointer((void**)&d_done_flag, h_done_flag, 0) != hipSuccess)
@@ -774,17 +782,28 @@ class Plan
     }
     return true;
   }
-  bool process_hop(size_t n, const TD* x, size_t x_stride, TD* y, size_t y_stride, bool want_flag)
+  DoneSignal arm_flag(unsigned total)
+  {
+    DoneSignal d; d.flag = nullptr; d.count = nullptr; d.seq = 0; d.total = total;
+    flag_pending = false;
+    if (flag_wanted && !async && !profile && opt_spin && total > 0 && ensure_flag())
+    {
+      d.flag = d_done_flag; d.count = d_done_count.p; d.seq = ++flag_seq;
+      flag_pending = true;
+    }
+    return d;
+  }
+  bool process_hop(size_t n, const TD* x, size_t x_stride, TD* y, size_t y_stride)
   {
     const size_t nb = nbins, span = 2 * nbins;
     const size_t ptiles = (nb + kWave - 1) / kWave;
     if (!grid_fits(channels * ptiles)) return false;
     if (!d_partial.reserve(channels * ptiles * n + 8)) return false;     // + stamps of the development build
     last_partial_elems = channels * ptiles * n;
-    if (d_tickets.cap < channels + 1)                        // [channels] tickets + the count of finished channels
+    if (d_tickets.cap < channels)
     {
-      if (!d_tickets.reserve(channels + 1)) return false;
-      SDFT_TRY(hipMemsetAsync(d_tickets.p, 0, (channels + 1) * sizeof(unsigned), stream));
+      if (!d_tickets.reserve(channels)) return false;
+      SDFT_TRY(hipMemsetAsync(d_tickets.p, 0, channels * sizeof(unsigned), stream));
     }
     ProcHopArgs<TD, FD> pa;
     pa.x = x; pa.x_stride = x_stride; pa.y = y; pa.y_stride = y_stride;
@@ -794,13 +813,7 @@ class Plan
     pa.acc_out = d_accs[st_cur ^ 1].p; pa.fid_out = d_fids[st_cur ^ 1].p;
     pa.alpha = d_alpha.p; pa.beta = d_beta.p; pa.partial = d_partial.p; pa.tickets = d_tickets.p;
     pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
-    // synchronous device-pointer calls: the kernel tells the host through a word of pinned memory
-    pa.done_flag = nullptr; pa.done_seq = 0; pa.done_count = d_tickets.p + channels; pa.channels = (unsigned)channels;
-    flag_pending = false;
-    if (want_flag && !async && !profile && opt_spin && ensure_flag())
-    {
-      pa.done_flag = d_done_flag; pa.done_seq = ++flag_seq; flag_pending = true;
-    }
+    pa.done = arm_flag((unsigned)channels);                  // every channel's last workgroup reports
     if (!prof_begin(ST_FORWARD)) return false;
     if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
     else                 hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
@@ -969,6 +982,7 @@ class Plan
   {
     size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = std::min(blocks, (size_t)256 * 8 * 4);
+    flag_pending = false;                                    // only the row form below signals its completion
     if (!opt_exact_inverse)
     {
       hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
@@ -986,7 +1000,11 @@ class Plan
     eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
     const dim3 g((unsigned)eb), b(kBlock);
     if (rw == 1 && total_rows <= 0x7fffffffull)
-      hipLaunchKernelGGL((inverse_row_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ia);
+    {
+      InverseArgs<TD, FD> ir = ia;
+      ir.done = arm_flag((unsigned)total_rows);
+      hipLaunchKernelGGL((inverse_row_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ir);
+    }
     else if (rw >= 32)
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 32, 1, false>), g, b, 0, stream, ia);
@@ -1008,6 +1026,7 @@ class Plan
     ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
     ia.n = n; ia.nbins = (unsigned)nbins; ia.channels = (unsigned)channels; ia.sweight = tab.sweight;
     ia.op.kind = OP_IDENTITY; ia.op.gain = nullptr; ia.op.shift = 0;
+    ia.done.flag = nullptr; ia.done.count = nullptr; ia.done.seq = 0; ia.done.total = 0;
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;
     const size_t total_rows = channels * n;
@@ -1100,7 +1119,12 @@ class Plan
     const bool xd = x_class < 0 ? on_device(x) : x_class != 0;
     const bool od = on_device(dfts);
     if (xd && od)
-      return forward_device(n, x, n, dfts, n * nbins, nullptr) && finish(channels * n * nbins);
+    {
+      flag_wanted = true;                                    // a call of one time chunk may signal its own completion
+      const bool ok = forward_device(n, x, n, dfts, n * nbins, nullptr);
+      flag_wanted = false;
+      return ok && finish(channels * n * nbins);
+    }
 
     // staged path (host pointers): time segments so that the staging matrix stays bounded;
     // the stream state carries over from segment to segment exactly like hop-wise calls do
@@ -1198,7 +1222,12 @@ class Plan
       return finish();
     }
     if (id && yd)
-      return inverse_device(n, dfts, n * nbins, nullptr, y, n) && finish(channels * n * nbins);
+    {
+      flag_wanted = true;
+      const bool ok = inverse_device(n, dfts, n * nbins, nullptr, y, n);
+      flag_wanted = false;
+      return ok && finish(channels * n * nbins);
+    }
     const size_t row_bytes = channels * nbins * sizeof(fdx);
     size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
     seg = std::min(seg, n);
@@ -1358,7 +1387,9 @@ class Plan
     {
       if (!fold_coefficients(op)) return false;
       last_process_path = 1;
-      ok = coeff_ready && process_hop(n, xs, n, ys, n, xd && yd);
+      flag_wanted = xd && yd;
+      ok = coeff_ready && process_hop(n, xs, n, ys, n);
+      flag_wanted = false;
     }
     else if (fuse_ok() && chunks > 1 && !walk_loses)
     {
