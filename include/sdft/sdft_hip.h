@@ -91,7 +91,9 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
    "target_waves"  waves the time chunking aims for
    "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis)
-   "spin"          1 (default) = synchronous short calls poll the stream instead of sleeping on it
+   "spin"          1 (default) = synchronous short calls do not sleep on the stream: calls of one time chunk
+                       poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
+                       before the stream reports the kernel finished), other short calls poll the stream
    "chain"         exact carries: 1 (default) = chain form (seed table + producer/consumer waves) while
                        bins x channels leave SIMDs idle, 0 = always the serial pass, 2 = chain form whenever
                        the geometry allows ("chain_block" 8|16|32 steps, "chain_producers" 1..7)
