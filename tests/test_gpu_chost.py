@@ -172,6 +172,48 @@ def test_wav_tool_end_to_end(tmp_path, hip_library):
     assert np.array_equal(got_y, np.concatenate(ys))
 
 
+def test_stream_filter_example(tmp_path, hip_library):
+    """examples/stream_filter.c: the reference's hop loop with a low-pass mask as ONE fused call per hop.  A two-tone
+    signal goes in as 16-bit PCM; what comes out must equal the oracle's three steps (analysis, the mask applied by
+    the host, synthesis) within the path's bar, with the tone above the cut-off gone and the other one kept."""
+    import struct
+    import wave
+    libdir = os.path.dirname(hip_library)
+    rt = hip_runtime_dir()
+    exe = tmp_path / "stream_filter"
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "stream_filter.c"),
+           "-o", str(exe), "-L", libdir, "-lsdft_hip", "-L", rt, "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rt}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rate, n, m, hop, cutoff = 44100, 12000, 1000, 100, 2000.0
+    t = np.arange(n) / rate
+    sig = 0.4 * np.sin(2 * np.pi * 500.0 * t) + 0.4 * np.sin(2 * np.pi * 8000.0 * t)
+    pcm = np.round(sig * 32767.0).astype(np.int16)
+    with wave.open(str(tmp_path / "in.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(pcm.tobytes())
+    r = subprocess.run([str(exe), str(m), str(hop), str(cutoff), str(tmp_path / "in.wav"), str(tmp_path / "out.wav")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "low-pass 2000 Hz" in r.stdout, (r.stdout, r.stderr)
+    raw = open(tmp_path / "out.wav", "rb").read()
+    got = np.frombuffer(raw[44:], dtype=np.float32)
+    assert got.size == n
+
+    x = (pcm / 32768.0).astype(np.float32)                  # the tool's (dr_wav-style) scaling
+    hz = np.arange(m) * rate / (2.0 * m)
+    edge = cutoff * 1.4142135623730951
+    mask = np.where(hz <= cutoff, 1.0, np.where(hz >= edge, 0.0, 0.5 * (1.0 + np.cos(np.pi * (hz - cutoff) / (edge - cutoff)))))
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = np.concatenate([ref.isdft((ref.sdft(x[i:i + hop]) * mask[None, :])) for i in range(0, n, hop)])
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    # the spectrum of the settled part: 500 Hz kept, 8 kHz gone
+    tail = got[4000:].astype(np.float64) * np.hanning(n - 4000)
+    spec = np.abs(np.fft.rfft(tail))
+    f = np.fft.rfftfreq(n - 4000, 1.0 / rate)
+    low, high = spec[np.abs(f - 500.0).argmin()], spec[np.abs(f - 8000.0).argmin()]
+    assert high < 1e-4 * low, (low, high)
+
+
 @pytest.mark.parametrize("rccl", [True, False], ids=["rccl", "no_rccl"])
 def test_multichannel_rccl_c_host(tmp_path, hip_library, rccl):
     """examples/multichannel_rccl.c: the multi-channel config from a C host -- one batched plan per GPU,
