@@ -102,6 +102,7 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        fastest route that gives those bits, 2 = in that order by the fused kernel,
                        -1 (default) = 1 when the host set carry = 1 at FD double, else 0
    "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
+   "fuse_delta"    1 (default) = chunk-parallel calls form the sample differences inside the carry kernel
    "pointers"      0 = classify each distinct pointer once (cached), 1 = all device, 2 = all host,
                        3 = query on every call
    "stage_bytes"   segment size of the host-pointer staging path

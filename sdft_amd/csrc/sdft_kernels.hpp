@@ -374,24 +374,87 @@ __global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
 // One workgroup per (chunk, channel): fold the chunk into LDS, radix-2 decimation-in-frequency
 // in place (log2(2N) barriers), read bin k from its bit-reversed slot.  O(N log N) per chunk
 // instead of O(L*N): 149 us -> ~15 us at n = 1e6, N = 1024.
-template <typename FD>
-__global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsigned log2m)
+// Differences formed by the carry pass itself (one launch less in front of the forward kernel): when `x` is set the
+// FFT kernels below compute delta[t] = (FD)(x[t] - x[t - 2N]) (sdft.h:564, the subtraction in TD precision) for their
+// chunk, fold it into LDS AND write it to delta_out for the forward kernel; the workgroup of the call's last chunk
+// (which has no partial sum to form) writes its differences and the channel's new delay line.
+template <typename TD, typename FD> struct DeltaIn
+{
+  const TD* x;                // [channels][n], or nullptr: read CarryArgs::delta as before
+  size_t x_stride;
+  const TD* hist_in;          // [channels][2N] delay line in time order
+  TD* hist_out;
+  FD* delta_out;              // [channels][n]
+};
+template <typename TD, typename FD>
+SDFT_D FD chunk_delta(const DeltaIn<TD, FD>& di, const TD* xs, const TD* hs, size_t t, size_t span)
+{
+  const TD cur = xs[t];
+  const TD old = (t < span) ? hs[t] : xs[t - span];
+  const TD dd = cur - old;                                  // TD precision
+  return (FD)dd;
+}
+// fold one chunk into the 2N LDS cells (cell v = sum of the chunk's samples v, v + 2N, ...); returns false for the
+// workgroup of the last chunk, which has only differences and the delay line to write
+template <typename TD, typename FD>
+SDFT_D bool chunk_fold(const CarryArgs<FD>& a, const DeltaIn<TD, FD>& di, cx<FD>* x, unsigned m, unsigned j, size_t ch)
+{
+  const size_t t0 = (size_t)j * a.chunk_len;
+  if (!di.x)
+  {
+    const FD* d = a.delta + ch * a.n + t0;
+    for (unsigned v = threadIdx.x; v < m; v += kBlock)
+    {
+      FD acc = (FD)0;
+      for (size_t u = v; u < a.chunk_len; u += m) acc += d[u];
+      x[v] = cmake<FD>(acc, (FD)0);
+    }
+    return true;
+  }
+  const size_t span = 2 * (size_t)a.nbins;
+  const TD* xs = di.x + ch * di.x_stride;
+  const TD* hs = di.hist_in + ch * span;
+  FD* dout = di.delta_out + ch * a.n;
+  const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
+  if (j + 1 == a.chunks)
+  {
+    for (size_t t = t0 + threadIdx.x; t < t1; t += kBlock) dout[t] = chunk_delta(di, xs, hs, t, span);
+    TD* ho = di.hist_out + ch * span;                       // element i of the last 2N samples of (hist ++ x)
+    for (size_t i = threadIdx.x; i < span; i += kBlock)
+    {
+      const size_t q = a.n + i;
+      ho[i] = (q >= span) ? xs[q - span] : hs[q];
+    }
+    return false;
+  }
+  for (unsigned v = threadIdx.x; v < m; v += kBlock)
+  {
+    FD acc = (FD)0;
+    for (size_t u = v; u < a.chunk_len; u += m)
+    {
+      const FD d = chunk_delta(di, xs, hs, t0 + u, span);
+      dout[t0 + u] = d;
+      acc += d;
+    }
+    x[v] = cmake<FD>(acc, (FD)0);
+  }
+  return true;
+}
+
+template <typename TD, typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsigned log2m, DeltaIn<TD, FD> di)
 {
   extern __shared__ __align__(16) unsigned char fft_lds_raw[];
   cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw);
   const unsigned m = 1u << log2m;                        // 2N
-  const unsigned j = blockIdx.x % (a.chunks - 1);        // chunk 0 .. chunks-2 (full length)
-  const size_t ch = blockIdx.x / (a.chunks - 1);
+  // chunk 0 .. chunks-2 (full length) form partial sums; with fused differences the grid has one more workgroup
+  // per channel, for the last chunk's differences and the delay line
+  const unsigned per_ch = di.x ? a.chunks : a.chunks - 1;
+  const unsigned j = blockIdx.x % per_ch;
+  const size_t ch = blockIdx.x / per_ch;
   const size_t t0 = (size_t)j * a.chunk_len;
   const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
-  const FD* d = a.delta + ch * a.n + t0;
-
-  for (unsigned v = threadIdx.x; v < m; v += kBlock)
-  {
-    FD acc = (FD)0;
-    for (size_t u = v; u < a.chunk_len; u += m) acc += d[u];
-    x[v] = cmake<FD>(acc, (FD)0);
-  }
+  if (!chunk_fold(a, di, x, m, j, ch)) return;
   __syncthreads();
   for (unsigned st = 0; st < log2m; ++st)
   {
@@ -421,24 +484,18 @@ __global__ __launch_bounds__(kBlock) void chunk_fft_kernel(CarryArgs<FD> a, unsi
 // roots taken from the plan's table W[j] = exp(-2*pi*i*j/(2N)).
 struct RadixList { unsigned char count; unsigned char r[15]; };
 
-template <typename FD>
-__global__ __launch_bounds__(kBlock) void chunk_fft_mixed_kernel(CarryArgs<FD> a, unsigned m, RadixList rl)
+template <typename TD, typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_fft_mixed_kernel(CarryArgs<FD> a, unsigned m, RadixList rl, DeltaIn<TD, FD> di)
 {
   extern __shared__ __align__(16) unsigned char fft_lds_raw2[];
   cx<FD>* x = reinterpret_cast<cx<FD>*>(fft_lds_raw2);
   cx<FD>* y = x + m;
-  const unsigned j = blockIdx.x % (a.chunks - 1);        // chunk 0 .. chunks-2 (full length)
-  const size_t ch = blockIdx.x / (a.chunks - 1);
+  const unsigned per_ch = di.x ? a.chunks : a.chunks - 1;    // see chunk_fft_kernel
+  const unsigned j = blockIdx.x % per_ch;
+  const size_t ch = blockIdx.x / per_ch;
   const size_t t0 = (size_t)j * a.chunk_len;
   const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % m);
-  const FD* d = a.delta + ch * a.n + t0;
-
-  for (unsigned v = threadIdx.x; v < m; v += kBlock)
-  {
-    FD acc = (FD)0;
-    for (size_t u = v; u < a.chunk_len; u += m) acc += d[u];
-    x[v] = cmake<FD>(acc, (FD)0);
-  }
+  if (!chunk_fold(a, di, x, m, j, ch)) return;
   __syncthreads();
   unsigned ns = 1;                                       // product of the radices already applied
   for (unsigned st = 0; st < rl.count; ++st)

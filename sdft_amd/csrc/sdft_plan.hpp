@@ -182,6 +182,7 @@ class Plan
   bool chain_attr[3] = {false, false, false};
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
   long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
   DevBuf<unsigned long long> d_chain_stats;
@@ -526,7 +527,15 @@ class Plan
     if ((exact || chunks == 1) && !use_chain && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
     if (use_chain && !ensure_fseed(cL)) return false;
 
-    // K0: differences + delay line
+    // K0: differences + delay line -- unless the FFT form of the chunk-parallel carries forms them itself
+    const size_t span_bytes_k0 = span * sizeof(fdx);
+    const bool pow2_k0 = (span & (span - 1)) == 0 && span >= 2;
+    bool smooth_k0 = false;
+    if (!pow2_k0) { size_t rem = span; for (unsigned f : {4u, 2u, 3u, 5u}) while (rem % f == 0) rem /= f; smooth_k0 = rem == 1; }
+    const bool delta_in_carry = !exact && chunks > 1 && opt_fuse_delta && opt_fft_carry &&
+                                ((pow2_k0 && span_bytes_k0 <= (size_t)64 * 1024) || (smooth_k0 && 2 * span_bytes_k0 <= (size_t)64 * 1024));
+    if (!delta_in_carry)
+    {
     if (!prof_begin(ST_DELTA)) return false;
     {
       const size_t work = std::max(n, span);
@@ -538,9 +547,13 @@ class Plan
                          (const fdx*)acc_p(), (const fdx*)fid_p(), single ? d_carry.p : (fdx*)nullptr, single ? d_seed.p : (fdx*)nullptr,
                          (unsigned)per_ch);
       SDFT_TRY(hipGetLastError());
-      hist_cur ^= 1;
     }
     if (!prof_end(ST_DELTA)) return false;
+    }
+    DeltaIn<TD, FD> din;
+    din.x = delta_in_carry ? x : nullptr; din.x_stride = x_stride;
+    din.hist_in = d_hist[hist_cur].p; din.hist_out = d_hist[hist_cur ^ 1].p; din.delta_out = d_delta.p;
+    hist_cur ^= 1;
 
     // carries
     long segments = 1;
@@ -642,11 +655,11 @@ class Plan
       if (opt_fft_carry && pow2 && span_bytes <= (size_t)64 * 1024)
       {
         unsigned lg = 0; while (((size_t)1 << lg) < span) ++lg;
-        hipLaunchKernelGGL((chunk_fft_kernel<FD>), dim3((unsigned)((chunks - 1) * channels)), dim3(kBlock), span_bytes, stream, ca, lg);
+        hipLaunchKernelGGL((chunk_fft_kernel<TD, FD>), dim3((unsigned)((chunks - (delta_in_carry ? 0 : 1)) * channels)), dim3(kBlock), span_bytes, stream, ca, lg, din);
       }
       else if (opt_fft_carry && rl.count > 0 && 2 * span_bytes <= (size_t)64 * 1024)
-        hipLaunchKernelGGL((chunk_fft_mixed_kernel<FD>), dim3((unsigned)((chunks - 1) * channels)), dim3(kBlock), 2 * span_bytes,
-                           stream, ca, (unsigned)span, rl);
+        hipLaunchKernelGGL((chunk_fft_mixed_kernel<TD, FD>), dim3((unsigned)((chunks - (delta_in_carry ? 0 : 1)) * channels)), dim3(kBlock), 2 * span_bytes,
+                           stream, ca, (unsigned)span, rl, din);
       else
         hipLaunchKernelGGL((chunk_sum_kernel<FD>), dim3((unsigned)((size_t)bin_blocks * (chunks - 1) * channels)), dim3(kBlock), 0, stream, ca);
       SDFT_TRY(hipGetLastError());
