@@ -27,3 +27,25 @@ print("launches", len(vals["WRITE_SIZE"]), "WRITE KiB", W, "FETCH KiB", F, "byte
 print("value", b["value"], "pair", b["analysis_plus_synthesis_msamples_s"], "frac", b["roofline"]["frac"], "avg ms", b["roofline"]["avg_launch_ms"], "| under rocprof", u["value"], u["roofline"]["avg_launch_ms"])
 print("fused", b["fused_process"]["tree_sum_msamples_s"], "n48000", b["north_star_n48000"]["sync"]["frac_of_peak_wall"], b["north_star_n48000"]["async"]["frac_of_peak_wall"])
 print("hop", b["hop100_m1000"])
+
+# the sentences of DESIGN.md and the optimisation log that quote the committed run are regenerated from it
+import re
+ks = next(r for r in csv.DictReader(open(os.path.join(P, "r02_bench_n1e6_m1024_kernel_stats.csv"))) if "forward_rows_kernel" in r["Name"])
+avg_prof = float(ks["AverageNs"]) / 1e6
+ev_prof = u["roofline"]["avg_launch_ms"]
+ev_plain = b["roofline"]["avg_launch_ms"]
+frac = 100.0 * b["roofline"]["frac"]
+def fill(path, tag, text):
+    s = open(path).read()
+    s2, nsub = re.subn(r"<!-- %s -->.*?<!-- /%s -->" % (tag, tag), "<!-- %s -->%s<!-- /%s -->" % (tag, text, tag), s, flags=re.S)
+    assert nsub >= 1, (path, tag)
+    open(path, "w").write(s2)
+fill(os.path.join(R, "DESIGN.md"), "committed-run",
+     "the committed run: rocprofv3 average %.4f ms against %.4f ms from the HIP events in the same process, %.4f ms = %.1f %% unprofiled" % (avg_prof, ev_prof, ev_plain, frac))
+fill(os.path.join(P, "r02_optimization_log.md"), "committed-run",
+     "the committed run: rocprofv3 average %.4f ms over %s launches (`r02_bench_n1e6_m1024_kernel_stats.csv`), HIP events in `bench.py` %.4f ms in the same process "
+     "(`r02_bench_n1e6_m1024_under_rocprof.json`); the unprofiled run of the same box %.4f ms = %.1f %% of peak, `value` %.1f Msamples/s (`r02_bench_n1e6_m1024.json`; "
+     "run-to-run and box-to-box spread of this round: 2.63-2.89 ms = 71-78 %%, `value` 342-374 Msamples/s)." % (avg_prof, ks["Calls"], ev_prof, ev_plain, frac, b["value"]))
+fill(os.path.join(P, "r02_optimization_log.md"), "committed-pmc",
+     "WRITE_SIZE %.0f KiB = %.3f GB per launch, FETCH_SIZE %.0f KiB x2 = %.0f MB" % (W, W * 1024 / 1e9, F, 2 * F * 1024 / 1e6))
+print("documents updated: rocprof avg %.4f, events %.4f / %.4f" % (avg_prof, ev_prof, ev_plain))
