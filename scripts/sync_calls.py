@@ -1,0 +1,18 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from sdft_amd.sdft import SDFT
+from sdft_amd.signals import sine_sweep
+for n in (4096, 12000, 48000):
+    x = torch.from_numpy(sine_sweep(n)).cuda(); y = torch.empty_like(x)
+    out = torch.empty((n, 1024), dtype=torch.complex128, device="cuda")
+    p = SDFT(1024, "hann", 1.0, "f32f64")
+    for what in ("sdft", "process"):
+        f = (lambda: p.sdft(x, out)) if what == "sdft" else (lambda: p.process(x, out=y))
+        for _ in range(5): f()
+        p.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200): f()
+        dt = (time.perf_counter() - t0) / 200
+        print(f"n={n} {what} synchronous: {dt*1e6:.1f} us per call", flush=True)
+    p.close()
