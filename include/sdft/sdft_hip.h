@@ -50,8 +50,8 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
    pays two HBM streams of 16 KiB per sample for it.  sdft_hip_process_n computes
        out[t] = sdft_isdft( op( sdft_sdft(samples[t]) ) )
    with the same arithmetic and the same plan state update as the two calls, but the rows stay
-   inside the workgroup that produced them (calls of 512 samples or more, dftsize up to 1024 double /
-   2048 float bins; other shapes run analysis + synthesis back to back through a bounded workspace).
+   inside the workgroup that produced them (dftsize 8 ... 4096; other shapes, and the reference's summation
+   order beyond 2048 double / 4096 float bins, run analysis + synthesis back to back through a workspace).
      sdft_hip_op_identity  params = NULL
      sdft_hip_op_gain      params = sdft_fd_t gains[dftsize]  (host or device): X'[k] = X[k] * gains[k]
      sdft_hip_op_shift     params = const long* (host): X'[k] = X[k - *params], zero outside the spectrum

@@ -693,7 +693,7 @@ class Plan
       const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
       // fused arithmetic only where the result is not claimed bit-identical: FD double with carries
       // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
-      const bool fused = use_rows && opt_fused && sizeof(FD) == 8 && !use_seed;
+      const bool fused = (use_rows || fuse) && opt_fused && sizeof(FD) == 8 && !use_seed;
       last_fused = fused;
       if (fuse)
       {
@@ -706,6 +706,7 @@ class Plan
         {
           if (!launch_process(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), fused)) return false;
         }
+        else if (!use_rows) { set_error("sdft_hip_process_n", "rows of this length are fused in the folded form only"); return false; }
         else if (!launch_syn(fa, *fuse, (unsigned)(channels * (size_t)(j1 - j0)), (unsigned)(row_waves() * kWave), fused && !exact_order, exact_order))
           return false;
       }
@@ -1404,7 +1405,10 @@ class Plan
       ok = coeff_ready && process_hop(n, xs, n, ys, n);
       flag_wanted = false;
     }
-    else if (fuse_ok() && chunks > 1 && !walk_loses)
+    // the folded form carries up to four bins per lane whatever the bin type is (N <= 4096); the forms that keep the
+    // windowed rows in LDS stop at two slots of the row-group kernel (N <= 2048 double / 4096 float)
+    else if ((fuse_ok() || (!wants_reference_order() && !dfts && opt_fold && nbins >= 8 && nbins <= (size_t)4 * kWave * kRowWavesMax))
+             && chunks > 1 && !walk_loses)
     {
       FuseArgs<TD, FD> fz;
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
