@@ -182,6 +182,8 @@ class Plan
   bool chain_attr[3] = {false, false, false};
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
   long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  long opt_hop_pipe = 1;         // calls of one time chunk, small launches: two waves per tile (forward_hop2_kernel)
+  long last_hop_pipe = 0;
   long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
@@ -739,6 +741,19 @@ class Plan
     }
   }
 
+  template <bool ROWS> void launch_hop2_t(const HopArgs<TD, FD>& ha, unsigned blocks)
+  {
+    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
+    const dim3 g(blocks), b(2 * kWave);
+    switch (window)
+    {
+      case WIN_HANN:     hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_HANN, ROWS>), g, b, 0, stream, ha); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_HAMMING, ROWS>), g, b, 0, stream, ha); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_BLACKMAN, ROWS>), g, b, 0, stream, ha); break;
+      default:           hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_BOXCAR, ROWS>), g, b, 0, stream, ha); break;
+    }
+  }
+
   bool forward_hop(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows)
   {
     const size_t nb = nbins, span = 2 * nbins;
@@ -760,8 +775,16 @@ class Plan
     const unsigned long long blocks = wide ? (ha.total_waves + 3) / 4 : ha.total_waves;
     if (!grid_fits(blocks)) return false;
     ha.done = arm_flag(wide ? 0u : (unsigned)blocks);
+    ha.stamps = nullptr;
+#ifdef SDFT_HOP_STAMPS
+    if (d_partial.reserve(64)) { ha.stamps = reinterpret_cast<unsigned long long*>(d_partial.p); last_partial_elems = 0; hop2_stamps = true; }
+#endif
     if (!prof_begin(ST_FORWARD)) return false;
-    if (rows) { if (wide) launch_hop_t<true, 4>(ha, (unsigned)blocks); else launch_hop_t<true, 1>(ha, (unsigned)blocks); }
+    // small launches of hop-sized calls: two waves per tile (recurrence | window + stores)
+    const bool pipe = !wide && opt_hop_pipe && n <= (size_t)kHopMax;
+    last_hop_pipe = pipe;
+    if (pipe) { if (rows) launch_hop2_t<true>(ha, (unsigned)blocks); else launch_hop2_t<false>(ha, (unsigned)blocks); }
+    else if (rows) { if (wide) launch_hop_t<true, 4>(ha, (unsigned)blocks); else launch_hop_t<true, 1>(ha, (unsigned)blocks); }
     else      { if (wide) launch_hop_t<false, 4>(ha, (unsigned)blocks); else launch_hop_t<false, 1>(ha, (unsigned)blocks); }
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
@@ -1055,10 +1078,20 @@ class Plan
   // synchronous calls: short ones poll the stream (a sleeping hipStreamSynchronize wakes up late --
   // tens of microseconds, more than a whole 100-sample hop takes on the device)
   size_t last_partial_elems = 0;
+  bool hop2_stamps = false;
   bool chain_stats(unsigned long long* out32)
   {
 #ifdef SDFT_HOP_STAMPS
-    // development build: realtime stamps (100 MHz) of the last process_hop_kernel's last workgroup
+    // development build: realtime stamps (100 MHz) of forward_hop2_kernel's workgroup 0 (recurrence wave: 0..2, window wave: 4..6)
+    if (hop2_stamps && d_partial.p)
+    {
+      memset(out32, 0, 32 * sizeof(unsigned long long));
+      SDFT_TRY(hipStreamSynchronize(stream));
+      SDFT_TRY(hipMemcpy(out32, d_partial.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      hop2_stamps = false;
+      return true;
+    }
+    // ... of the last process_hop_kernel's last workgroup
     if (d_partial.p && last_partial_elems)
     {
       memset(out32, 0, 32 * sizeof(unsigned long long));

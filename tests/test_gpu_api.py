@@ -196,7 +196,7 @@ def test_checkpoint_and_resume_on_a_fresh_plan(combo):
 
 
 @pytest.mark.parametrize("combo", O.COMBOS)
-@pytest.mark.parametrize("window", ["hann", "blackman", "boxcar"])
+@pytest.mark.parametrize("window", ["hann", "hamming", "blackman", "boxcar"])
 def test_hop_kernel_matches_reference_and_legacy_single_chunk_path(combo, window):
     """Single-chunk calls run one fused launch (differences formed in the kernel, double-buffered
     state, tiles spread over the CUs).  Hop sizes below and above 2N, across the roll-over, batched
@@ -207,13 +207,19 @@ def test_hop_kernel_matches_reference_and_legacy_single_chunk_path(combo, window
         ch = 2
         xb = np.stack([noise(total, seed=11 + c, dtype=td) for c in range(ch)])
         refs = [O.best(m, window, 0.5, combo) for _ in range(ch)]
-        with make(m, window, 0.5, combo, ch, chunk=1 << 30) as p, make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_kernel=0) as q:
+        with make(m, window, 0.5, combo, ch, chunk=1 << 30) as p, make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_kernel=0) as q, \
+                make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_pipe=0) as r:
             i = 0
             for h in hops:
                 seg = np.ascontiguousarray(xb[:, i:i + h])
                 got = p.sdft(seg)
                 old = q.sdft(seg)
                 assert p.get_option("last_kernel") == 3 and q.get_option("last_kernel") != 3
+                # hop-sized calls: two waves per tile (recurrence | window + stores); the one-wave form must agree
+                assert p.get_option("last_hop_pipe") == (1 if h <= 512 else 0)
+                one_wave = r.sdft(seg)
+                assert r.get_option("last_kernel") == 3 and r.get_option("last_hop_pipe") == 0
+                assert np.array_equal(got, one_wave), (combo, window, m, h)
                 for c in range(ch):
                     want = refs[c].sdft(seg[c])
                     assert np.array_equal(got[c], want), (combo, window, m, h, c)
