@@ -46,6 +46,7 @@ def _stale() -> bool:
 def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
           extra_flags=tuple(os.environ.get("SDFT_HIP_EXTRA_FLAGS", "").split())) -> str:
     """Compile (if stale) and return the path of libsdft_hip.so."""
+    force = force or bool(extra_flags)                    # development flags: never hand back a library built without them
     if not force and not _stale():
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)

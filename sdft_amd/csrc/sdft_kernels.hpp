@@ -299,6 +299,15 @@ template <typename FD> SDFT_D void advance_wrap(BinState<FD>& s, FD delta)
 // chunks.  fid is seeded from the table W[j] = exp(-i*pi*j/N), j = k*cursor mod 2N, and then
 // advanced exactly like the main kernel does, so both see the same rotation sequence.
 // ------------------------------------------------------------------------------------------
+// the same for a workgroup of several waves: every wave waits for its own stores, the workgroup meets, one lane reports
+SDFT_D void signal_done_workgroup(const DoneSignal& d)
+{
+  if (!d.flag) return;                                      // workgroup-uniform
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) signal_done(d);
+}
+
 template <typename FD> struct CarryArgs
 {
   const FD* delta;            // [channels][n]
@@ -1554,6 +1563,7 @@ template <typename FD> struct ForwardArgs
   unsigned chunk_shift;             // chunk j > 0 starts at sample j*chunk_len - chunk_shift (exact carries, ring form; else 0)
   int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
   FD wscale;                  // weight (or weight*0.25 for Hann)
+  DoneSignal done;            // row-group kernels of short synchronous calls: total = workgroups of the launch
 };
 
 // native clang vectors (the nontemporal builtin rejects HIP's struct-wrapped double2/float4)
@@ -2208,12 +2218,7 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
 #endif
   }
   // completion word: both waves' stores are out before one lane reports
-  if (a.done.flag)
-  {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) signal_done(a.done);
-  }
+  signal_done_workgroup(a.done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2677,6 +2682,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           a.fid_state[ch * a.nbins + k] = s[q][b].fid;
         }
   }
+  signal_done_workgroup(a.done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2962,6 +2968,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
         a.fid_state[ch * a.nbins + k] = s[j].fid;
       }
   }
+  signal_done_workgroup(a.done);
 }
 
 // ------------------------------------------------------------------------------------------
