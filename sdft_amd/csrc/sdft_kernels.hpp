@@ -332,19 +332,68 @@ template <typename FD> struct CarryArgs
 // here: this pass only feeds the carry, whose summation order differs from the reference anyway.
 constexpr int kSumBlock = 8;
 
-template <typename FD>
-__global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
+// Differences formed by the carry pass itself (one launch less in front of the forward kernel): when `x` is set the
+// FFT kernels below compute delta[t] = (FD)(x[t] - x[t - 2N]) (sdft.h:564, the subtraction in TD precision) for their
+// chunk, fold it into LDS AND write it to delta_out for the forward kernel; the workgroup of the call's last chunk
+// (which has no partial sum to form) writes its differences and the channel's new delay line.
+template <typename TD, typename FD> struct DeltaIn
+{
+  const TD* x;                // [channels][n], or nullptr: read CarryArgs::delta as before
+  size_t x_stride;
+  const TD* hist_in;          // [channels][2N] delay line in time order
+  TD* hist_out;
+  FD* delta_out;              // [channels][n]
+};
+template <typename TD, typename FD>
+SDFT_D FD chunk_delta(const DeltaIn<TD, FD>& di, const TD* xs, const TD* hs, size_t t, size_t span)
+{
+  const TD cur = xs[t];
+  const TD old = (t < span) ? hs[t] : xs[t - span];
+  const TD dd = cur - old;                                  // TD precision
+  return (FD)dd;
+}
+template <typename TD, typename FD>
+__global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a, DeltaIn<TD, FD> di)
 {
   constexpr int B = kSumBlock;
-  // 1-D grid = bin blocks x (chunks - 1) x channels (grid.y/z stop at 65535)
+  // 1-D grid = bin blocks x (chunks - 1) x channels (grid.y/z stop at 65535); with fused differences one more
+  // chunk per channel: the last one has no partial sum to form, only its differences and the delay line to write
   const unsigned bin_blocks = (a.nbins + kBlock - 1) / kBlock;
-  const unsigned k = (blockIdx.x % bin_blocks) * kBlock + threadIdx.x;
-  const unsigned j = (blockIdx.x / bin_blocks) % (a.chunks - 1);   // chunk 0 .. chunks-2 (all of full length, a multiple of B)
-  const size_t ch = (blockIdx.x / bin_blocks) / (a.chunks - 1);
+  const unsigned per_ch = di.x ? a.chunks : a.chunks - 1;
+  const unsigned bb = blockIdx.x % bin_blocks;
+  const unsigned k = bb * kBlock + threadIdx.x;
+  const unsigned j = (blockIdx.x / bin_blocks) % per_ch;           // chunk 0 .. chunks-2: all of full length, a multiple of B
+  const size_t ch = (blockIdx.x / bin_blocks) / per_ch;
   const unsigned kk = k < a.nbins ? k : a.nbins - 1;
   const unsigned span = 2u * a.nbins;
   const size_t t0 = (size_t)j * a.chunk_len;
   const unsigned c0 = (unsigned)(((size_t)a.cursor0 + t0) % span);
+  const SDFT_CONSTANT TD* xs = nullptr;
+  const SDFT_CONSTANT TD* hs = nullptr;
+  if (di.x)
+  {
+    const TD* xv = di.x + ch * di.x_stride;
+    const TD* hv = di.hist_in + ch * (size_t)span;
+    if (bb == 0)
+    {
+      // the chunk's differences for the forward kernel (one workgroup per chunk writes them)
+      FD* dout = di.delta_out + ch * a.n;
+      const size_t t1 = (t0 + a.chunk_len < a.n) ? t0 + a.chunk_len : a.n;
+      for (size_t t = t0 + threadIdx.x; t < t1; t += kBlock) dout[t] = chunk_delta(di, xv, hv, t, (size_t)span);
+      if (j + 1 == a.chunks)
+      {
+        TD* ho = di.hist_out + ch * (size_t)span;            // element i of the last 2N samples of (hist ++ x)
+        for (size_t i = threadIdx.x; i < span; i += kBlock)
+        {
+          const size_t q = a.n + i;
+          ho[i] = (q >= span) ? xv[q - span] : hv[q];
+        }
+      }
+    }
+    if (j + 1 == a.chunks) return;
+    xs = as_uniform(xv);
+    hs = as_uniform(hv);
+  }
 
   cx<FD> w[B];
 #pragma unroll
@@ -358,8 +407,36 @@ __global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
   for (unsigned blk = 0; blk < blocks; ++blk)
   {
     FD dl[B];
+    if (di.x)
+    {
+      // differences from the input and the delay line (sdft.h:564), the subtraction in TD precision
+      const size_t tt = t0 + (size_t)blk * B;
+      TD cur[B], old[B];
 #pragma unroll
-    for (int b = 0; b < B; ++b) dl[b] = d[(size_t)blk * B + b];
+      for (int b = 0; b < B; ++b) cur[b] = xs[tt + b];
+      if (tt + B <= span)
+      {
+#pragma unroll
+        for (int b = 0; b < B; ++b) old[b] = hs[tt + b];
+      }
+      else if (tt >= span)
+      {
+#pragma unroll
+        for (int b = 0; b < B; ++b) old[b] = xs[tt - span + b];
+      }
+      else
+      {
+#pragma unroll
+        for (int b = 0; b < B; ++b) old[b] = (tt + b < span) ? hs[tt + b] : xs[tt + b - span];
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) { const TD dd = cur[b] - old[b]; dl[b] = (FD)dd; }
+    }
+    else
+    {
+#pragma unroll
+      for (int b = 0; b < B; ++b) dl[b] = d[(size_t)blk * B + b];
+    }
     FD ire = dl[0], iim = (FD)0;              // w[0] == 1
 #pragma unroll
     for (int b = 1; b < B; ++b)
@@ -384,26 +461,6 @@ __global__ __launch_bounds__(kBlock) void chunk_sum_kernel(CarryArgs<FD> a)
 // One workgroup per (chunk, channel): fold the chunk into LDS, radix-2 decimation-in-frequency
 // in place (log2(2N) barriers), read bin k from its bit-reversed slot.  O(N log N) per chunk
 // instead of O(L*N): 149 us -> ~15 us at n = 1e6, N = 1024.
-// Differences formed by the carry pass itself (one launch less in front of the forward kernel): when `x` is set the
-// FFT kernels below compute delta[t] = (FD)(x[t] - x[t - 2N]) (sdft.h:564, the subtraction in TD precision) for their
-// chunk, fold it into LDS AND write it to delta_out for the forward kernel; the workgroup of the call's last chunk
-// (which has no partial sum to form) writes its differences and the channel's new delay line.
-template <typename TD, typename FD> struct DeltaIn
-{
-  const TD* x;                // [channels][n], or nullptr: read CarryArgs::delta as before
-  size_t x_stride;
-  const TD* hist_in;          // [channels][2N] delay line in time order
-  TD* hist_out;
-  FD* delta_out;              // [channels][n]
-};
-template <typename TD, typename FD>
-SDFT_D FD chunk_delta(const DeltaIn<TD, FD>& di, const TD* xs, const TD* hs, size_t t, size_t span)
-{
-  const TD cur = xs[t];
-  const TD old = (t < span) ? hs[t] : xs[t - span];
-  const TD dd = cur - old;                                  // TD precision
-  return (FD)dd;
-}
 // fold one chunk into the 2N LDS cells (cell v = sum of the chunk's samples v, v + 2N, ...); returns false for the
 // workgroup of the last chunk, which has only differences and the delay line to write
 template <typename TD, typename FD>
