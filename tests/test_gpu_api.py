@@ -307,3 +307,46 @@ def test_more_channels_than_a_grid_dimension():
             w = r.sdft(xb[c])
             assert np.abs(dh[i] - w).max() <= 1e-12 * np.abs(w).max(), (opts, c)
             assert np.abs(y[c] - r.isdft(w)).max() <= 1e-6
+
+
+def test_plans_release_everything_they_allocated():
+    """Plans come and go in a long-lived host: after 150 create / use / free cycles that touch every workspace (analysis
+    in one and in many chunks, synthesis, the fused call in its folded, ordered and hop forms with their completion
+    word, exact carries with the seed table) the device has as much free memory as before, and many plans alive at
+    once -- each with its own pinned completion word -- stay independent."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    x_long = torch.from_numpy(sine_sweep(6000)).cuda()
+    x_hop = torch.from_numpy(sine_sweep(100)).cuda()
+    gain = np.linspace(1.0, 0.5, 256)
+
+    def cycle(combo, opts):
+        td = O.combo_types(combo)[0]
+        xl, xh = x_long.to(getattr(torch, np.dtype(td).name)), x_hop.to(getattr(torch, np.dtype(td).name))
+        with SDFT(256, "hann", 1.0, combo) as p:
+            for k, v in opts.items():
+                p.set_option(k, v)
+            d = p.sdft(xl); p.isdft(d)
+            p.process(xl, "gain", gain=gain); p.process(xh); p.sdft(xh); p.isdft(p.sdft(xh))
+
+    variants = (("f32f64", {}), ("f32f32", {"fused_exact": 1}), ("f64f64", {"carry": 1}))
+    for combo, opts in variants:                             # first use loads the kernels (device memory, once)
+        cycle(combo, opts)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()       # (torch's own caching allocator must not blur the picture)
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(150):
+        cycle(*variants[i % 3])
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 8 << 20, (free0, free1)          # nothing accumulates (the allocator may keep a few MiB of slack)
+
+    plans = [SDFT(200, "hann", 1.0, "f32f64") for _ in range(40)]
+    refs = [O.best(200, "hann", 1.0, "f32f64") for _ in range(40)]
+    xs = [noise(100, seed=300 + i) for i in range(40)]
+    for rep in range(3):
+        for i, p in enumerate(plans):                        # interleaved synchronous hop calls on device pointers
+            got = p.process(torch.from_numpy(xs[i]).cuda()).cpu().numpy()
+            want = refs[i].isdft(refs[i].sdft(xs[i]))
+            assert float(np.abs(got - want).max()) <= 1e-6 * max(float(np.abs(want).max()), 1.0), (rep, i)
+    for p in plans:
+        p.close()
