@@ -396,6 +396,16 @@ def main():
             fp[label + "_msamples_s"] = round(count * n / wf / 1e6, 1)
             fp[label + "_ms"] = round(wf * 1e3, 3)
         plan.set_option("fused_exact", -1)
+        # the same call on HOST buffers (what a host of the reference has: malloc'ed samples in, samples out): 4 bytes per
+        # sample each way over PCIe instead of the 16 KiB per sample of the matrix -- PCIe-inclusive, never `value`
+        xh_f = xh if count > 1 else np.ascontiguousarray(xh)
+        yh_f = plan.process(xh_f)
+        th = time.perf_counter()
+        for _ in range(3):
+            plan.process(xh_f, out=yh_f)
+        wh = (time.perf_counter() - th) / 3
+        fp["host_pointers_msamples_s"] = round(count * n / wh / 1e6, 1)
+        fp["host_pointers_ms"] = round(wh * 1e3, 3)
         # folded form (process_rows_kernel, FD double): per bin-sample 6 fused multiply-adds and 3 multiplies
         # (recurrence 6, re X 2, coefficient 1) = 9 vector instructions = 15 flops at 2 per FMA
         folded = bool(plan.get_option("last_fused_fold")) or fp["tree_sum_ms"] < 0.75 * fp["reference_order_ms"]
