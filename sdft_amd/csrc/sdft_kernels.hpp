@@ -3216,6 +3216,170 @@ __global__ __launch_bounds__(kWave) void process_hop_kernel(ProcHopArgs<TD, FD> 
 }
 #undef SDFT_HOP_STAMP
 
+// ------------------------------------------------------------------------------------------
+// K3h, two waves per tile: the lone-wave lesson of forward_hop2_kernel applied to the fused hop.  Wave 0 runs the
+// recurrence and parks (acc, fid) of an 8-sample group in a double-buffered LDS image; wave 1 takes the group one
+// barrier later, forms alpha * re X + beta * im X, transposes and adds its 64 lanes and writes the per-sample sums
+// of the tile.  Ticket, combine and completion word as in process_hop_kernel (the combine by both waves).
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD, bool HASB>
+__global__ __launch_bounds__(2 * kWave) void process_hop2_kernel(ProcHopArgs<TD, FD> a)
+{
+  constexpr int G = kProcGroup;
+  using AT = double;
+  __shared__ cx<FD> image[2][G][2][kWave];                 // [buffer][sample][acc | fid][lane]
+  __shared__ AT tile_lds[G * kProcRow];
+  __shared__ TD diff_lds[kHopMax + G];
+  __shared__ unsigned last_flag;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 recurrence, 1 coefficients + sums
+  const unsigned tile = blockIdx.x % a.tiles;
+  const size_t ch = blockIdx.x / a.tiles;
+  const unsigned span = 2u * a.nbins, maxc = span - 1u;
+  const unsigned k = tile * kWave + (unsigned)lane;
+  const bool live = k < a.nbins;
+  const unsigned kk = live ? k : 0u;
+  const size_t sbase = ch * a.nbins;
+
+  {
+    const TD* xv = a.x + ch * a.x_stride;
+    const TD* hv = a.hist_in + ch * span;
+    TD* ho = a.hist_out + ch * span;
+    // delay line for the next call: element i of the last 2N samples of (hist ++ x)
+    for (size_t i = (size_t)tile * (2 * kWave) + threadIdx.x; i < span; i += (size_t)a.tiles * (2 * kWave))
+    {
+      const size_t j = a.n + i;
+      ho[i] = (j >= span) ? xv[j - span] : hv[j];
+    }
+    // differences of the whole call (sdft.h:564), the subtraction in TD precision
+    for (size_t tt = threadIdx.x; tt < a.n; tt += 2 * kWave)
+    {
+      const TD cur = xv[tt];
+      const TD old = (tt < span) ? hv[tt] : xv[tt - span];
+      diff_lds[tt] = cur - old;
+    }
+  }
+
+  const size_t groups = (a.n + G - 1) / G;
+  if (role == 0)
+  {
+    // ---------------- recurrence (unfused: the state stays the reference's) ----------------
+    BinState<FD> s;
+    s.tw = a.tw[kk]; s.acc = a.acc_in[sbase + kk]; s.fid = a.fid_in[sbase + kk];
+    if (!live) { s.tw = cmake<FD>((FD)0, (FD)0); s.acc = s.tw; s.fid = s.tw; }
+    __syncthreads();                                         // the differences are staged
+    unsigned c = a.cursor0;
+    int buf = 0;
+    for (size_t g = 0; g < groups; ++g)
+    {
+      const size_t t = g * G;
+      const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
+      TD dd[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) dd[u] = diff_lds[t + u];   // broadcast reads
+      if (m == G && c + G <= maxc)
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+        {
+          advance_normal(s, (FD)dd[u]);
+          image[buf][u][0][lane] = s.acc;
+          image[buf][u][1][lane] = s.fid;
+        }
+        c += G;
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+        {
+          if (u < m)
+          {
+            const bool wrap = (c == maxc);                   // wave-uniform
+            if (wrap) advance_wrap(s, (FD)dd[u]); else advance_normal(s, (FD)dd[u]);
+            image[buf][u][0][lane] = s.acc;
+            image[buf][u][1][lane] = s.fid;
+            c = wrap ? 0 : c + 1;
+          }
+        }
+      }
+      __syncthreads();                                       // group g is in the image
+      buf ^= 1;
+    }
+    if (live)
+    {
+      a.acc_out[sbase + k] = s.acc;
+      a.fid_out[sbase + k] = s.fid;
+    }
+  }
+  else
+  {
+    // ---------------- coefficients and the sum over the tile's bins ----------------
+    AT al = a.alpha[kk], be = a.beta[kk];
+    if (!live) { al = (AT)0; be = (AT)0; }
+    double* mine = a.partial + (ch * a.tiles + tile) * a.n;
+    const int ru = lane >> 3, rs = lane & 7;
+    __syncthreads();                                         // (pairs with the barrier after the staging)
+    int buf = 0;
+    for (size_t g = 0; g < groups; ++g)
+    {
+      const size_t t = g * G;
+      const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
+      __syncthreads();                                       // group g is in the image
+      cx<FD> ac[G], fi[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) { ac[u] = image[buf][u][0][lane]; fi[u] = image[buf][u][1][lane]; }   // all reads first
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+      {
+        const AT ar = (AT)ac[u].re, ai = (AT)ac[u].im, fr = (AT)fi[u].re, fm = (AT)fi[u].im;
+        AT vv = al * (ar * fr + ai * fm);
+        if constexpr (HASB) vv += be * (ai * fr - ar * fm);
+        tile_lds[u * kProcRow + lane] = (m == G || u < m) ? vv : (AT)0;        // samples past the call's end hold stale bins
+      }
+      AT sum = tile_lds[ru * kProcRow + rs * 8 + (rs & 7)];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) sum += tile_lds[ru * kProcRow + rs * 8 + ((e + rs) & 7)];
+      sum = sum_of_eight(sum);
+      if (rs == 0 && ru < m) mine[t + ru] = sum;
+      buf ^= 1;
+    }
+  }
+
+  // the channel's last workgroup adds the tiles (release: both waves' stores; acquire: everybody else's)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned ticket = __hip_atomic_fetch_add(a.tickets + ch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (ticket + 1u == a.tiles) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  if (threadIdx.x == 0) __hip_atomic_store(a.tickets + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+  // (only thread 0 has executed the acquire; the other lanes' loads go to the same coherent level explicitly)
+  const double* all = a.partial + ch * a.tiles * a.n;
+  TD* yo = a.y + ch * a.y_stride;
+  for (size_t tb = 0; tb < a.n; tb += 2 * kWave)
+  {
+    const size_t t0 = tb + threadIdx.x;
+    AT p0 = (AT)0;
+    for (unsigned q0 = 0; q0 < a.tiles; q0 += 16)
+    {
+      AT pv0[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        pv0[i] = (q0 + (unsigned)i < a.tiles && t0 < a.n) ? __hip_atomic_load(all + (size_t)(q0 + i) * a.n + t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (AT)0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p0 += pv0[i];
+    }
+    if (t0 < a.n) yo[t0] = (TD)(p0 * (AT)a.sweight);                                    // sdft.h:654-656
+  }
+  signal_done_workgroup(a.done);
+}
+
 // rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
 template <typename FD>
 __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain,

@@ -868,8 +868,14 @@ class Plan
     pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
     pa.done = arm_flag((unsigned)channels);                  // every channel's last workgroup reports
     if (!prof_begin(ST_FORWARD)) return false;
-    if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
-    else                 hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    if (opt_hop_pipe)                                        // two waves per tile (recurrence | coefficients + sums)
+    {
+      if (!coeff_has_beta) hipLaunchKernelGGL((process_hop2_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
+      else                 hipLaunchKernelGGL((process_hop2_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
+    }
+    else if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    else                      hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
+    last_hop_pipe = opt_hop_pipe ? 1 : 0;
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
     hist_cur ^= 1; st_cur ^= 1;

@@ -233,9 +233,9 @@ def test_hop_sized_calls_and_host_pointers(combo):
     x = sine_sweep(12 * hop, dtype=td)
     gain = (1.0 / (1.0 + np.arange(m) / 100.0)).astype(fd)
     for op, shift in OPS:
-        for fused_exact in (1, -1):
+        for fused_exact, hop_pipe in ((1, 1), (-1, 1), (-1, 0)):          # hop_pipe: two waves per tile / one
             ref = O.best(m, "hann", 1.0, combo)
-            with make(m, "hann", 1.0, combo, fused_exact=fused_exact) as p:
+            with make(m, "hann", 1.0, combo, fused_exact=fused_exact, hop_pipe=hop_pipe) as p:
                 gots, wants = [], []
                 for i in range(0, x.size, hop):
                     want, _ = reference(ref, x[i:i + hop], op, gain, shift)
@@ -247,7 +247,7 @@ def test_hop_sized_calls_and_host_pointers(combo):
                         assert np.array_equal(got, want), (combo, op, shift, i)
                     else:
                         assert p.get_option("last_process_path") == 1 and p.get_option("last_fused_fold") == 1
-                        assert p.get_option("last_chunks") == 1
+                        assert p.get_option("last_chunks") == 1 and p.get_option("last_hop_pipe") == hop_pipe
                     gots.append(got); wants.append(want)
                 # (the first hops of a stream are cancellation residue four orders below the signal: the bar is
                 # relative to the stream, not to one hop)
