@@ -376,6 +376,13 @@ def main():
             grp = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 2, m, 8, max(int(plan.get_option("last_chunk_len")), 1), 5)
             torch.cuda.synchronize()
             best_ms = min(v for v in (lin, grp) if v > 0)
+            ld = lib.sdft_hip_load_ceiling(out.data_ptr(), nbytes, 5)
+            torch.cuda.synchronize()
+            if ld > 0 and i_avg > 0:
+                result["roofline"]["load_only_ceiling"] = {
+                    "linear_load_gbs": round(nbytes / (ld * 1e-3) / 1e9, 1),
+                    "synthesis_frac_of_load_only": round((bytes_per_launch / (i_avg * 1e-3)) / (nbytes / (ld * 1e-3)), 4),
+                }
             result["roofline"]["store_only_ceiling"] = {
                 "linear_fill_gbs": round(nbytes / (lin * 1e-3) / 1e9, 1),
                 "row_lockstep_gbs": round(nbytes / (grp * 1e-3) / 1e9, 1),

@@ -34,6 +34,8 @@ int         sdft_hip_selftest(void);         /* 0 = cross-lane primitives behave
    slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave) */
 double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
                                    unsigned chunk_len, int reps);
+/* the same for a load-only kernel (16-byte loads, four in flight per thread) */
+double      sdft_hip_load_ceiling(const void* src, size_t bytes, int reps);
 
 /* ---- batched plans: `channels` independent streams with one launch per call ----------------
    The unit of sharding in the reference is the plan (no shared mutable state, sdft.h:145-182);

@@ -60,6 +60,21 @@ __global__ __launch_bounds__(kBlock) void store_linear_kernel(v2f64* dst, size_t
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) dst[i] = v;
 }
 
+// load-only counterpart: every thread streams 16-byte slots (four in flight), the sum keeps the loads alive
+__global__ __launch_bounds__(kBlock) void load_linear_kernel(const v2f64* src, size_t slots, double* sink)
+{
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  double acc = 0.0;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < slots; i += 4 * stride)
+  {
+    const v2f64 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc += (a.x + b.x) + (c.x + d.x) + (a.y + b.y) + (c.y + d.y);
+  }
+  for (; i < slots; i += stride) { const v2f64 a = src[i]; acc += a.x + a.y; }
+  if (acc == 12345.678) *sink = acc;                        // never true for the buffers measured; defeats dead-code elimination
+}
+
 __global__ __launch_bounds__(kBlock) void store_tiled_kernel(v2f64* dst, size_t rows, unsigned row_slots, unsigned lanes,
                                                             unsigned chunk_len, unsigned tiles, unsigned chunks)
 {
@@ -142,6 +157,27 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)ms / (reps > 0 ? reps : 1);
+}
+
+// average ms of a load-only kernel over `bytes` of device memory (the synthesis kernel's ceiling)
+double sdft_hip_load_ceiling(const void* src, size_t bytes, int reps)
+{
+  using namespace sdfthip;
+  const size_t slots = bytes / 16;
+  hipEvent_t e0, e1;
+  double* sink = nullptr;
+  if (hipMalloc((void**)&sink, 8) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); return -1.0; }
+  auto launch = [&]() { hipLaunchKernelGGL(load_linear_kernel, dim3(256 * 16), dim3(kBlock), 0, 0, (const v2f64*)src, slots, sink); };
+  launch();
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1, 0);
+  float ms = -1.f;
+  if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1); else (void)hipGetLastError();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  return ms < 0.f ? -1.0 : (double)ms / (reps > 0 ? reps : 1);
 }
 
 // NULL when no error has been recorded on this thread since the last clear
