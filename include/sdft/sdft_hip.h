@@ -105,15 +105,21 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        -1 (default) = 1 when the host set carry = 1 at FD double, else 0
    "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
    "fuse_delta"    1 (default) = chunk-parallel calls form the sample differences inside the carry kernel
-   "pointers"      0 = classify each distinct pointer once (cached), 1 = all device, 2 = all host,
-                       3 = query on every call
+   "pointers"      0 = classify each distinct pointer once (the last 8 are cached; sdft_reset, sdft_hip_set_state and
+                       sdft_hip_set_stream forget them), 1 = all device, 2 = all host, 3 = query on every call.
+                       With 0 a host must not free a buffer it has passed to a plan and pass the same address
+                       again as the other kind of memory (host <-> device) without one of those calls in between.
+   "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize a power of two (<= 4096) run as ONE
+                       launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
+                       0 = carries by a pre-pass (two more launches); "self_carry_max" = longest call that takes it
    "stage_bytes"   segment size of the host-pointer staging path
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
    "last_chain", "last_fused_exact", "last_fused_fold", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
-   "cursor", "device". */
+   "last_self", "cursor", "device", "ring_recoveries" (calls re-run with the serial carry pass after a poll loop of
+   the ring form timed out: results stay valid, sdft_hip_last_error() reports it), "flag_fallbacks". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);
 

@@ -917,8 +917,10 @@ template <typename FD> struct ChainArgs
   unsigned L, P;              // block length (divides 2N, multiple of 8), producer waves
   unsigned NB;                // ring form: blocks the LDS ring holds
   unsigned chunk_shift;       // ring form: chunk j > 0 starts at sample j*chunk_len - chunk_shift (0 elsewhere)
-  unsigned debug;             // measurement aid: bit 0 = consumer idles, bit 1 = producers idle (results are garbage)
+  unsigned debug;             // measurement aid: bit 0 = consumer idles, bit 1 = producers idle (results are garbage);
+                              // bit 5 (ring form): test aid, the producers stop publishing after their first block
   unsigned long long* stats;  // measurement aid: per wave of workgroup 0, cycles in {work, tail waits, barrier} (or nullptr)
+  unsigned* status;           // ring form: word in pinned host memory, incremented by every wave whose poll loop ran out
 };
 
 template <typename FD>
@@ -1227,8 +1229,9 @@ __global__ __launch_bounds__(kWave * 8) void carry_chain_kernel(ChainArgs<FD> a)
 //    consumer publishes how many blocks it has left behind.  Both sides poll LDS words; the LDS serves a
 //    wave's instructions in order, so a flag written after the data (producer) or read before it
 //    (consumer) orders them.  Every poll loop is bounded and a time-out is sticky for the workgroup: a
-//    protocol error ends the kernel with wrong carries (the parity tests would catch that) instead of
-//    hanging the GPU;
+//    protocol error (or a wave starved for seconds) ends the kernel instead of hanging the GPU, and the
+//    wave that ran out reports it through ChainArgs::status -- the host then restores the stream state
+//    the call started from and re-runs it with the serial pass (Plan::forward_checked);
 //  * the host shifts the chunk grid so that every chunk but the first starts on a block boundary
 //    (ChainArgs::chunk_shift = cursor0 mod L; the forward kernels use the same grid): the consumer
 //    then walks WHOLE blocks -- one block's products are fetched while the previous block's are added,
@@ -1244,6 +1247,13 @@ constexpr unsigned kRingPollCap = 1u << 20;
 SDFT_D unsigned ring_peek(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SDFT_D void ring_poke(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SDFT_D int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a poll loop ran out: sticky for the workgroup (everybody leaves) and reported to the host, which re-runs the call's
+// carries with the serial pass (Plan::forward_checked); wave-uniform call
+SDFT_D void ring_abort(unsigned* aborted, unsigned* status)
+{
+  ring_poke(aborted, 1u);
+  if (status && (threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <typename FD, int L>
 __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
@@ -1312,7 +1322,8 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
         const unsigned long long mask = __ballot(lane < NB && g < nblocks && flag == (unsigned)(g + 1));
         have = uniform(have + (int)__builtin_ctzll(~mask));  // consecutive published blocks
         if (have >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return have; }
-        if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return -1; }
+        if (ring_peek(&aborted)) return -1;
+        if (++polls > kRingPollCap) { ring_abort(&aborted, a.status); return -1; }
         __builtin_amdgcn_s_sleep(1);
       }
     };
@@ -1449,10 +1460,12 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
         {
           seen_consumed = ring_peek(&consumed_blocks);
           if ((int)seen_consumed >= g - NB + 1) break;
-          if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
+          if (ring_peek(&aborted)) return;
+          if (++polls > kRingPollCap) { ring_abort(&aborted, a.status); return; }
           __builtin_amdgcn_s_sleep(2);
         }
       }
+      if ((a.debug & 32u) && g >= P) return;                 // test aid: a producer that died (the consumer's poll runs out)
       FD* pw = prod + pslot * L;
 #pragma unroll
       for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
@@ -1512,10 +1525,12 @@ __global__ __launch_bounds__(kWave * 8) void carry_ring_kernel(ChainArgs<FD> a)
         {
           seen_consumed = ring_peek(&consumed_blocks);
           if ((int)seen_consumed >= g - NB + 1) break;
-          if (++polls > kRingPollCap || ring_peek(&aborted)) { ring_poke(&aborted, 1u); return; }
+          if (ring_peek(&aborted)) return;
+          if (++polls > kRingPollCap) { ring_abort(&aborted, a.status); return; }
           __builtin_amdgcn_s_sleep(2);
         }
       }
+      if ((a.debug & 32u) && g >= P) return;                 // test aid: a producer that died (the consumer's poll runs out)
       FD* pw = prod + pslot * L;
 #pragma unroll
       for (int s = 0; s < L; s += NV) *reinterpret_cast<vec_t*>(pw + s) = pv[s / NV];
@@ -1622,6 +1637,156 @@ template <typename FD> struct ForwardArgs
   FD wscale;                  // weight (or weight*0.25 for Hann)
   DoneSignal done;            // row-group kernels of short synchronous calls: total = workgroups of the launch
 };
+
+// ------------------------------------------------------------------------------------------
+// Self-carried time chunks (chunk-parallel FD double path, 2N a power of two): ONE launch per call.
+// The carry-in of a chunk is acc(t0) = acc(0) + sum_{t < t0} delta_t * fid(c_t) (sdft.h:583 unrolled), and with
+// fid(c) = W[k*c], W[j] = exp(-2*pi*i*j/(2N)), that sum over ALL earlier samples is one 2N-point DFT of the
+// differences folded by cursor:  cell[v] = sum of delta_t over the t < t0 that arrive at cursor v,
+//     acc_k(t0) = acc_k(0) + sum_v cell[v] * W[k*v].
+// So the workgroup of chunk j folds the call's first t0 samples into 2N LDS cells (one load per sample:
+// the "old" sample of t is the "current" one of t - 2N), runs the FFT in place and has its carry-in -- no
+// partial sums in memory, no scan, no dependency on any other workgroup, no launch in front of the forward
+// kernel.  The differences of its own samples are formed in the time loop from scalar loads of the input and
+// the delay line, as in forward_hop_kernel.  Cost per workgroup: t0 / threads loads + one FFT (a few us);
+// the pre-pass it replaces was two launches, 21 us at n = 48000.  State is double-buffered like in the hop
+// kernels: every workgroup reads acc(0), the last chunk's writes the new state to the other buffer.
+// ------------------------------------------------------------------------------------------
+template <typename TD, typename FD> struct SelfArgs
+{
+  const TD* x;                // [channels][n] the call's samples; nullptr = carries and differences come from a pre-pass
+  size_t x_stride;
+  const TD* hist_in;          // [channels][2N] delay line in time order
+  TD* hist_out;               // the other buffer: written by the workgroup of the call's last chunk
+  const cx<FD>* acc_in;       // [channels][N] accumulator before the call (ForwardArgs::acc_state receives the new one)
+  unsigned log2m;             // 2N = 1 << log2m
+};
+
+// cells[v] = sum of the differences (sdft.h:564, the subtraction in TD precision) of the samples t < t0 whose
+// cursor is v; whole workgroup, no barrier inside
+template <typename TD, typename FD>
+SDFT_D void self_fold(const SelfArgs<TD, FD>& sa, cx<FD>* cells, unsigned m, unsigned cursor0, size_t ch, size_t t0)
+{
+  const TD* xs = sa.x + ch * sa.x_stride;
+  const TD* hs = sa.hist_in + ch * (size_t)m;
+  for (unsigned v = threadIdx.x; v < m; v += blockDim.x)
+  {
+    const size_t tv = (size_t)((v + m - cursor0) & (m - 1));          // first sample that arrives at cursor v (cursor0 < m)
+    FD sum = (FD)0;
+    if (tv < t0)
+    {
+      TD prev = hs[tv];                                               // x[tv - 2N]
+      size_t t = tv;
+      for (; t + 7 * (size_t)m < t0; t += 8 * (size_t)m)               // eight independent loads in flight
+      {
+        TD cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = xs[t + (size_t)q * m];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const TD dd = cur[q] - prev; sum += (FD)dd; prev = cur[q]; }
+      }
+      for (; t < t0; t += m) { const TD cur = xs[t]; const TD dd = cur - prev; sum += (FD)dd; prev = cur; }
+    }
+    cells[v] = cmake<FD>(sum, (FD)0);
+  }
+}
+
+// in-place 2N-point DFT in LDS, decimation in frequency, two radix-2 stages per barrier; bin k ends in cell
+// bitreverse(k); whole workgroup; ends with a barrier.  w[j] = exp(-2*pi*i*j/m), j < m.
+template <typename FD>
+SDFT_D void lds_fft_dif(cx<FD>* x, unsigned log2m, const cx<FD>* __restrict__ w)
+{
+  const unsigned m = 1u << log2m;
+  unsigned st = 0;
+  for (; st + 2 <= log2m; st += 2)
+  {
+    const unsigned half = m >> (st + 1), quarter = half >> 1;         // stage st pairs (p, p + half), stage st + 1 (p, p + quarter)
+    for (unsigned i = threadIdx.x; i < (m >> 2); i += blockDim.x)
+    {
+      const unsigned pos = i & (quarter - 1);
+      const unsigned base = ((i - pos) << 2) + pos;
+      const cx<FD> a0 = x[base], a1 = x[base + quarter], a2 = x[base + half], a3 = x[base + half + quarter];
+      const cx<FD> w1 = w[(size_t)pos << st];                          // stage st, pair (a0, a2)
+      const cx<FD> w2 = w[(size_t)pos << (st + 1)];                    // stage st + 1, both pairs
+      const cx<FD> b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
+      const cx<FD> b1 = cadd(a1, a3), tq = cmul(csub(a1, a3), w1);
+      const cx<FD> b3 = cmake<FD>(tq.im, -tq.re);                      // pair (a1, a3): twiddle index + m/4, i.e. times -i
+      x[base] = cadd(b0, b1);
+      x[base + quarter] = cmul(csub(b0, b1), w2);
+      x[base + half] = cadd(b2, b3);
+      x[base + half + quarter] = cmul(csub(b2, b3), w2);
+    }
+    __syncthreads();
+  }
+  if (st < log2m)                                                      // odd log2m: the last stage pairs neighbours, twiddle 1
+  {
+    for (unsigned i = threadIdx.x; i < (m >> 1); i += blockDim.x)
+    {
+      const cx<FD> p = x[2 * i], q = x[2 * i + 1];
+      x[2 * i] = cadd(p, q);
+      x[2 * i + 1] = csub(p, q);
+    }
+    __syncthreads();
+  }
+}
+
+// the whole prologue of a self-carried chunk: delay line for the next call (last chunk's workgroup), fold, FFT.
+// Returns true when cells[] holds the DFT (chunks that start at sample 0 need none).  Workgroup-uniform.
+template <typename TD, typename FD>
+SDFT_D bool self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<FD>* cells, unsigned chunk, size_t ch, size_t t0)
+{
+  const unsigned m = 1u << sa.log2m;
+  if (chunk + 1 == a.chunks)
+  {
+    const TD* xv = sa.x + ch * sa.x_stride;
+    const TD* hv = sa.hist_in + ch * (size_t)m;
+    TD* ho = sa.hist_out + ch * (size_t)m;                             // element i of the last 2N samples of (hist ++ x)
+    for (size_t i = threadIdx.x; i < m; i += blockDim.x)
+    {
+      const size_t q = a.n + i;
+      ho[i] = (q >= m) ? xv[q - m] : hv[q];
+    }
+  }
+  if (t0 == 0) return false;
+  self_fold(sa, cells, m, a.cursor0, ch, t0);
+  __syncthreads();
+  lds_fft_dif(cells, sa.log2m, a.wtab);
+  return true;
+}
+
+// differences of G consecutive samples from scalar loads of the input and the delay line (wave-uniform)
+template <int G, typename TD, typename FD>
+SDFT_D void self_deltas(FD (&dl)[G], const SDFT_CONSTANT TD* xs, const SDFT_CONSTANT TD* hs, size_t tt, size_t span)
+{
+  TD cur[G], old[G];
+#pragma unroll
+  for (int u = 0; u < G; ++u) cur[u] = xs[tt + u];
+  if (tt + G <= span)
+  {
+#pragma unroll
+    for (int u = 0; u < G; ++u) old[u] = hs[tt + u];
+  }
+  else if (tt >= span)
+  {
+#pragma unroll
+    for (int u = 0; u < G; ++u) old[u] = xs[tt - span + u];
+  }
+  else
+  {
+#pragma unroll
+    for (int u = 0; u < G; ++u) old[u] = (tt + u < span) ? hs[tt + u] : xs[tt + u - span];
+  }
+#pragma unroll
+  for (int u = 0; u < G; ++u) { const TD dd = cur[u] - old[u]; dl[u] = (FD)dd; }     // TD precision (sdft.h:564)
+}
+template <typename TD, typename FD>
+SDFT_D FD self_delta1(const SDFT_CONSTANT TD* xs, const SDFT_CONSTANT TD* hs, size_t tt, size_t span)
+{
+  const TD cur = xs[tt];
+  const TD old = (tt < span) ? hs[tt] : xs[tt - span];
+  const TD dd = cur - old;
+  return (FD)dd;
+}
 
 // native clang vectors (the nontemporal builtin rejects HIP's struct-wrapped double2/float4)
 typedef double sdft_v2f64 __attribute__((ext_vector_type(2)));
@@ -2369,9 +2534,11 @@ constexpr int syn_group(int S, int BPL, int SYN) { return (S == 2 && BPL == 2 &&
 // LDS and summed over bins by a wave-parallel tree, 2 = summed strictly in ascending bin order like the
 // reference (lane u of wave 0 walks sample u's terms: bit-identical to sdft_sdft_n + sdft_isdft_n, at the
 // price of N dependent additions per lockstep group).  The matrix is written only if FuseArgs::store.
-template <typename FD, int BPL, int WIN, bool FUSED, int S, int SYN = 0, bool LAT1 = true, typename TD = float>
-__global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a, FuseArgs<TD, FD> fz)
+// SELF: self-carried chunks (see SelfArgs): no pre-pass, the workgroup derives its carry-in and its differences itself.
+template <typename FD, int BPL, int WIN, bool FUSED, int S, int SYN = 0, bool LAT1 = true, typename TD = float, bool SELF = false>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(ForwardArgs<FD> a, FuseArgs<TD, FD> fz, SelfArgs<TD, FD> sa)
 {
+  static_assert(!SELF || SYN == 0, "the self-carried form shares the dynamic LDS with the terms image");
   constexpr int H = win_halo<WIN>::value;
   // keeps registers roughly constant; the fused synthesis path takes eight samples per group whatever
   // BPL is (its per-group cost is the walk over the bins, shared by as many lanes as there are samples)
@@ -2402,6 +2569,11 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
+  // SELF: carry-in by fold + FFT of everything before this chunk (dynamic LDS: 2N cells)
+  cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
+  bool have_cells = false;
+  if constexpr (SELF) have_cells = self_carry(sa, a, cells, chunk, ch, t0);
+
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
   BinState<FD> s[S][BPL];
   bool keep[S][BPL], flip[S][BPL];
@@ -2423,9 +2595,18 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       const long kk = reflect_bin(k, nbins, flip[q][b]);
       keep[q][b] = k < nbins;
       s[q][b].tw = a.tw[kk];
+      if constexpr (SELF)
+      {
+        s[q][b].acc = sa.acc_in[ch * a.nbins + kk];
+        if (have_cells) s[q][b].acc = cadd(s[q][b].acc, cells[__brev((unsigned)kk) >> (32u - sa.log2m)]);
+        s[q][b].fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+      }
+      else
+      {
       s[q][b].acc = a.carry[cbase + kk];
       s[q][b].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, kk, c, s[q][b].tw)
                   : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+      }
 
       pub[q][b] = &edgeL[0][0][0][0];
       pubflip[q][b] = false; has_role[q][b] = false;
@@ -2471,6 +2652,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   constexpr size_t kSlabBuf = (size_t)G * kSlabU;         // elements between the two buffers
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+  const SDFT_CONSTANT TD* xin = SELF ? as_uniform(sa.x + ch * sa.x_stride) : nullptr;
+  const SDFT_CONSTANT TD* hin = SELF ? as_uniform(sa.hist_in + ch * (size_t)span) : nullptr;
   const FD w = a.wscale;
   cx<FD>* row = a.out + ch * a.out_stride + t0 * (size_t)a.nbins;     // wave-uniform row base
   // lane-constant 32-bit element offsets into a row: the stores then use the scalar-base form
@@ -2666,8 +2849,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     if (m == G && c + G <= maxc)
     {
       FD dl[G];
+      if constexpr (SELF) self_deltas<G>(dl, xin, hin, t, (size_t)span);
+      else
+      {
 #pragma unroll
-      for (int u = 0; u < G; ++u) dl[u] = d[t + u];
+        for (int u = 0; u < G; ++u) dl[u] = d[t + u];
+      }
 #pragma unroll
       for (int u = 0; u < G; ++u)
       {
@@ -2686,7 +2873,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       {
         if (u < m)
         {
-          const FD dl = d[t + u];
+          const FD dl = SELF ? self_delta1<TD, FD>(xin, hin, t + u, (size_t)span) : d[t + u];
           const bool wrap = (c == maxc);
 #pragma unroll
           for (int q = 0; q < S; ++q)
@@ -2852,8 +3039,8 @@ constexpr int kProcRow = 72;             // row stride of the transpose tile: 64
 constexpr int kProcRing = SDFT_PROC_RING;             // groups whose per-wave sums are in flight (a ring of tables)
 constexpr int kProcSync = SDFT_PROC_RING / 2;         // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
 
-template <typename TD, typename FD, int J, bool FUSED, bool HASB>
-__global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz)
+template <typename TD, typename FD, int J, bool FUSED, bool HASB, bool SELF = false>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz, SelfArgs<TD, FD> sa)
 {
   constexpr int G = kProcGroup;
   constexpr int R = kProcRing, K = kProcSync;
@@ -2875,6 +3062,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
 
   for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (AT)0;   // waves that do not exist add 0
 
+  // SELF: carry-in by fold + FFT of everything before this chunk; the 2N cells borrow the transpose tiles, which
+  // the time loop does not touch before the barrier below
+  static_assert(!SELF || sizeof(tile) >= (size_t)4096 * sizeof(cx<FD>), "2N <= 4096 cells must fit the transpose tiles");
+  cx<FD>* cells = reinterpret_cast<cx<FD>*>(&tile[0][0]);
+  bool have_cells = false;
+  if constexpr (SELF) have_cells = self_carry(sa, a, cells, chunk, ch, t0);
+
   BinState<FD> s[J];
   AT al[J], be[J];
   bool live[J];
@@ -2886,9 +3080,18 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     live[j] = k < a.nbins;
     const unsigned kk = live[j] ? k : 0u;
     s[j].tw = a.tw[kk];
+    if constexpr (SELF)
+    {
+      s[j].acc = sa.acc_in[ch * a.nbins + kk];
+      if (have_cells) s[j].acc = cadd(s[j].acc, cells[__brev(kk) >> (32u - sa.log2m)]);
+      s[j].fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+    }
+    else
+    {
     s[j].acc = a.carry[cbase + kk];
     s[j].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, (long)kk, c, s[j].tw)
              : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+    }
     al[j] = pz.alpha[kk];
     be[j] = pz.beta[kk];
     if (!live[j])
@@ -2943,6 +3146,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   };
 
   const SDFT_CONSTANT FD* d = as_uniform(a.delta + ch * a.n);
+  const SDFT_CONSTANT TD* xin = SELF ? as_uniform(sa.x + ch * sa.x_stride) : nullptr;
+  const SDFT_CONSTANT TD* hin = SELF ? as_uniform(sa.hist_in + ch * (size_t)span) : nullptr;
   TD* yo = pz.y + ch * pz.y_stride;
   AT* my = tile[wave];
   const int ru = lane >> 3, rs = lane & 7;                 // transposed role: sample of the group, segment of the row
@@ -2968,8 +3173,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     if (m == G && c + G <= maxc)
     {
       FD dl[G];
+      if constexpr (SELF) self_deltas<G>(dl, xin, hin, t, (size_t)span);
+      else
+      {
 #pragma unroll
-      for (int u = 0; u < G; ++u) dl[u] = d[t + u];
+        for (int u = 0; u < G; ++u) dl[u] = d[t + u];
+      }
 #pragma unroll
       for (int u = 0; u < G; ++u) v[u] = step_all(dl[u], false);
       c += G;
@@ -2982,7 +3191,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
         v[u] = (AT)0;
         if (u < m)
         {
-          const FD dl = d[t + u];
+          const FD dl = SELF ? self_delta1<TD, FD>(xin, hin, t + u, (size_t)span) : d[t + u];
           const bool wrap = (c == maxc);
           v[u] = step_all(dl, wrap);
           c = wrap ? 0 : c + 1;

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,9 @@ class Plan
                                  // -1 = in order exactly when the host asked for exact carries at FD double (carry = 1)
   long last_fused_exact = 0, last_fused_fold = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
+  long opt_self = 1;             // chunk-parallel FD double calls, 2N a power of two: self-carried chunks (no pre-pass launches)
+  long opt_self_max = (long)1 << 20;   // ... for calls of up to this many samples per channel (the fold of a chunk's past grows with n)
+  long last_self = 0;
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
 
@@ -245,6 +249,7 @@ class Plan
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
+    if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
     d_done_count.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
@@ -267,6 +272,7 @@ class Plan
   bool reset()
   {
     cursor = 0; hist_cur = 0; st_cur = 0; fid_canonical = true;
+    forget_pointers();
     if (nbins == 0) return true;
     if (!bind()) return false;
     const size_t nb = nbins, span = 2 * nbins;
@@ -282,11 +288,26 @@ class Plan
   {
     if (stream) SDFT_TRY(hipStreamSynchronize(stream));
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+    forget_pointers();
     stream = s; own_stream = false;
     return true;
   }
 
-  bool synchronize() { SDFT_TRY(hipStreamSynchronize(stream)); return collect_profile(); }
+  bool synchronize()
+  {
+    SDFT_TRY(hipStreamSynchronize(stream));
+    if (status_armed)
+    {
+      if (aux) SDFT_TRY(hipStreamSynchronize(aux));
+      if (ring_gave_up())
+      {
+        set_error("carry_ring_kernel", "a poll loop timed out in an asynchronous call: its output and the stream state are invalid (reset the plan or restore a state)");
+        (void)collect_profile();
+        return false;
+      }
+    }
+    return collect_profile();
+  }
 
   // ---- profiling ---------------------------------------------------------------------------
   bool prof_on(int st) const { return profile == 1 || (profile == 2 && (st == ST_FORWARD || st == ST_INVERSE)); }
@@ -489,7 +510,62 @@ class Plan
   // ---- forward on device-resident buffers ------------------------------------------------
   // x: [channels] x n with stride x_stride; out: rows at out + ch*out_stride + t*N, or the row
   // pointer table `rows` (device array of channels*n device pointers)
+  // Checked form (what every entry point calls).  The ring form of the exact carries ends its poll loops after a bounded
+  // number of tries instead of hanging the GPU; a wave that ran out says so in a word of pinned host memory
+  // (ChainArgs::status).  The state a call starts from stays intact until the next call (acc, fid and the delay line are
+  // double-buffered, the cursor lives on the host), so a synchronous call that finds the word changed restores that
+  // state and runs again with the serial pass: the outputs are the reference's bits either way, and
+  // sdft_hip_last_error() tells the host that it happened.  Asynchronous calls are checked in synchronize(), which can
+  // only report (the caller's buffers may have moved on).
+  unsigned* h_status = nullptr;
+  unsigned* d_status = nullptr;
+  unsigned status_seen = 0;
+  bool status_armed = false;       // a ring launch is in flight or unchecked
+  long ring_recoveries = 0;
+  bool ensure_status()
+  {
+    if (h_status) return true;
+    if (hipHostMalloc((void**)&h_status, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); h_status = nullptr; return false; }
+    *h_status = 0;
+    if (hipHostGetDevicePointer((void**)&d_status, h_status, 0) != hipSuccess)
+    {
+      (void)hipGetLastError(); (void)hipHostFree(h_status); h_status = nullptr; return false;
+    }
+    return true;
+  }
+  // after the stream has drained: did a ring launch give up since the last look?
+  bool ring_gave_up()
+  {
+    if (!status_armed || !h_status) return false;
+    status_armed = false;
+    const unsigned now = *(volatile unsigned*)h_status;
+    if (now == status_seen) return false;
+    status_seen = now;
+    return true;
+  }
   bool forward_device(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows,
+                      const FuseArgs<TD, FD>* fuse = nullptr)
+  {
+    const size_t cursor0 = cursor;
+    const int st0 = st_cur, hist0 = hist_cur;
+    const bool canon0 = fid_canonical;
+    if (!forward_launch(n, x, x_stride, out, out_stride, rows, fuse)) return false;
+    if (last_chain != 2 || async) return true;
+    SDFT_TRY(hipStreamSynchronize(stream));
+    if (aux) SDFT_TRY(hipStreamSynchronize(aux));
+    if (!ring_gave_up()) return true;
+    cursor = cursor0; st_cur = st0; hist_cur = hist0; fid_canonical = canon0;
+    const long saved = opt_chain;
+    opt_chain = 0;
+    const bool ok = forward_launch(n, x, x_stride, out, out_stride, rows, fuse) && (hipStreamSynchronize(stream) == hipSuccess);
+    opt_chain = saved;
+    ++ring_recoveries;
+    set_error("carry_ring_kernel", ok ? "a poll loop timed out; the call was re-run with the serial carry pass (results are valid)"
+                                      : "a poll loop timed out and the re-run with the serial carry pass failed");
+    return ok;
+  }
+
+  bool forward_launch(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows,
                       const FuseArgs<TD, FD>* fuse = nullptr)
   {
     if (n == 0 || nbins == 0) return true;
@@ -503,10 +579,22 @@ class Plan
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
-    last_segments = 1; last_fused = 0;
+    last_segments = 1; last_fused = 0; last_self = 0; last_chain = 0;
     if (chunks == 1 && opt_hop_kernel && nbins >= 2 && !fuse) return forward_hop(n, x, x_stride, out, out_stride, rows);
 
     const bool exact = (carry_mode == CARRY_EXACT);
+    // self-carried chunks: every workgroup derives its carry-in from the raw samples (fold + one FFT in LDS) and forms
+    // its own differences -- the call is ONE launch.  Kernels that have the form: the row-group forward kernel and the
+    // folded fused kernel, FD double, 2N a power of two of at most 4096 cells.
+    const bool folded_fuse = fuse && !wants_reference_order() && !fuse->store && opt_fold && coeff_ready;
+    // (the fold of a chunk's past costs t0 / threads loads: hidden behind the other workgroups' row stores in the
+    // analysis, which is bound by HBM -- n = 1e6: 2.885 -> 2.853 ms -- but not in the fused call, which is bound by
+    // instruction issue: n = 48000: 45.9 -> 42.3 us, n = 131072: 99 -> 117 us)
+    const size_t self_max = fuse ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
+    const bool self = sizeof(FD) == 8 && !exact && chunks > 1 && opt_self && (span & (span - 1)) == 0 && span >= 16 && span <= 4096 &&
+                      n <= self_max && (fuse ? folded_fuse : use_rows);
+    last_self = self;
+    if (self) return forward_self(n, x, x_stride, out, out_stride, chunks, len, fuse);
     // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
     // leave most SIMDs idle; the plain serial pass when bins x channels already fill the chip
     unsigned cL = 0, cP = 0;
@@ -624,8 +712,10 @@ class Plan
         cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
         cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
         cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
-        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 15u; cc.stats = nullptr;
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 47u; cc.stats = nullptr;
         if (opt_chain_debug & 16) { if (!d_chain_stats.reserve(64)) return false; cc.stats = d_chain_stats.p; }
+        cc.status = (use_ring && ensure_status()) ? d_status : nullptr;
+        if (cc.status) status_armed = true;
         const unsigned cblocks = eblocks * (unsigned)channels;
         bool ok = true;
         if (use_ring)
@@ -689,7 +779,8 @@ class Plan
     fa.seed = (use_seed && !use_chain) ? d_seed.p : nullptr;
     fa.fseed = use_chain ? d_fseed.p : nullptr; fa.fseed_L = use_chain ? cL : 0;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = rows;
-    fa.acc_state = acc_p(); fa.fid_state = fid_p(); fa.n = n;
+    // the new state goes to the other buffer set (the one a call started from survives it, see forward_device)
+    fa.acc_state = d_accs[st_cur ^ 1].p; fa.fid_state = d_fids[st_cur ^ 1].p; fa.n = n;
     fa.total_waves = (unsigned long long)channels * (unsigned long long)chunks * (unsigned long long)ntiles;
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)ntiles;
     fa.interior_lanes = (unsigned)inter; fa.cursor0 = (unsigned)cursor; fa.chunk_shift = shift;
@@ -740,7 +831,84 @@ class Plan
     if (!use_seed) fid_canonical = false;
     else if (cursor + n >= span) fid_canonical = true;
     cursor = (cursor + n) % span;
+    st_cur ^= 1;
     return true;
+  }
+
+  // ---- self-carried chunks: the whole chunk-parallel call in one launch (SelfArgs in sdft_kernels.hpp) ----
+  bool forward_self(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, long chunks, long len,
+                    const FuseArgs<TD, FD>* fuse)
+  {
+    const size_t nb = nbins, span = 2 * nbins;
+    SelfArgs<TD, FD> sa;
+    sa.x = x; sa.x_stride = x_stride;
+    sa.hist_in = d_hist[hist_cur].p; sa.hist_out = d_hist[hist_cur ^ 1].p;
+    sa.acc_in = d_accs[st_cur].p;
+    sa.log2m = 0; while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
+    ForwardArgs<FD> fa;
+    fa.delta = nullptr; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = nullptr; fa.seed = nullptr; fa.fseed = nullptr; fa.fseed_L = 0;
+    fa.out = out; fa.out_stride = out_stride; fa.out_rows = nullptr;
+    fa.acc_state = d_accs[st_cur ^ 1].p; fa.fid_state = d_fids[st_cur ^ 1].p; fa.n = n;
+    fa.total_waves = 0;
+    fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)tiles();
+    fa.interior_lanes = (unsigned)interior_lanes(); fa.cursor0 = (unsigned)cursor; fa.chunk_shift = 0;
+    fa.chunk0 = 0; fa.launch_chunks = (unsigned)chunks;
+    fa.vec_store = 0;
+    fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
+    fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
+    if (!grid_fits(channels * (size_t)chunks)) return false;
+    if (channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)1 << 24)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
+    const unsigned blocks = (unsigned)(channels * (size_t)chunks);
+    const bool fused = opt_fused != 0;
+    last_fused = fused; last_segments = 1; last_chain = 0;
+    if (!prof_begin(ST_FORWARD)) return false;
+    if constexpr (sizeof(FD) == 8)
+    {
+      if (fuse)
+      {
+        last_fused_exact = 0; last_fused_fold = 1;
+        if (!launch_process(fa, *fuse, blocks, fused, &sa)) return false;
+      }
+      else if (!launch_forward_rows_self(fa, sa, blocks, (unsigned)(row_waves() * kWave), fused)) return false;
+    }
+    SDFT_TRY(hipGetLastError());
+    if (!prof_end(ST_FORWARD)) return false;
+    hist_cur ^= 1; st_cur ^= 1;
+    fid_canonical = false;                                   // chunks seeded fid from the closed-form table
+    cursor = (cursor + n) % span;
+    return true;
+  }
+  template <int WIN, bool FUSED, int S>
+  bool launch_forward_rows_self_ws(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads)
+  {
+    auto kern = forward_rows_kernel<FD, 1, WIN, FUSED, S, 0, true, TD, true>;
+    const size_t lds = ((size_t)1 << sa.log2m) * sizeof(fdx);
+    static thread_local int raised_on = -1;                  // static + dynamic LDS beyond 64 KiB has to be asked for (per device)
+    if (raised_on != device)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      raised_on = device;
+    }
+    const FuseArgs<TD, FD> none{};
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, fa, none, sa);
+    SDFT_TRY(hipGetLastError());
+    return true;
+  }
+  template <bool FUSED>
+  bool launch_forward_rows_self_t(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads)
+  {
+    const bool two = row_slots() != 1;
+    switch (window)
+    {
+      case WIN_HANN:     return two ? launch_forward_rows_self_ws<WIN_HANN, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_HANN, FUSED, 1>(fa, sa, blocks, threads);
+      case WIN_HAMMING:  return two ? launch_forward_rows_self_ws<WIN_HAMMING, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_HAMMING, FUSED, 1>(fa, sa, blocks, threads);
+      case WIN_BLACKMAN: return two ? launch_forward_rows_self_ws<WIN_BLACKMAN, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_BLACKMAN, FUSED, 1>(fa, sa, blocks, threads);
+      default:           return two ? launch_forward_rows_self_ws<WIN_BOXCAR, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_BOXCAR, FUSED, 1>(fa, sa, blocks, threads);
+    }
+  }
+  bool launch_forward_rows_self(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads, bool fused)
+  {
+    return fused ? launch_forward_rows_self_t<true>(fa, sa, blocks, threads) : launch_forward_rows_self_t<false>(fa, sa, blocks, threads);
   }
 
   // ---- single-chunk calls (hop-wise streaming): one fused launch, tiles spread over the CUs ----
@@ -827,7 +995,7 @@ class Plan
     if (h_done_flag) return true;
     if (!d_done_count.reserve(2)) return false;
     if (hipMemsetAsync(d_done_count.p, 0, 2 * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipHostMalloc((void**)&h_done_flag, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_done_flag = nullptr; return false; }
+    if (hipHostMalloc((void**)&h_done_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); h_done_flag = nullptr; return false; }
     *h_done_flag = 0;
     if (hipHostGetDevicePointer((void**)&d_done_flag, h_done_flag, 0) != hipSuccess)
     {
@@ -891,12 +1059,13 @@ class Plan
     constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
     const dim3 g(blocks), b(threads);
     const FuseArgs<TD, FD> none{};
+    const SelfArgs<TD, FD> noself{};
     switch (window)
     {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
-      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none); break;
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
+      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
     }
   }
   template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
@@ -938,7 +1107,7 @@ class Plan
       SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
       raised_on = device;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(SYN), stream, fa, fz);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(SYN), stream, fa, fz, SelfArgs<TD, FD>{});
     SDFT_TRY(hipGetLastError());
     return true;
   }
@@ -991,18 +1160,22 @@ class Plan
     return true;
   }
   template <int J, bool FUSED, bool HASB>
-  void launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads)
+  void launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, const SelfArgs<TD, FD>* self)
   {
-    hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB>), dim3(blocks), dim3(threads), 0, stream, fa, pz);
+    if constexpr (sizeof(FD) == 8 && J <= 2)
+    {
+      if (self) { hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB, true>), dim3(blocks), dim3(threads), 0, stream, fa, pz, *self); return; }
+    }
+    hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB>), dim3(blocks), dim3(threads), 0, stream, fa, pz, SelfArgs<TD, FD>{});
   }
   template <bool FUSED, bool HASB>
-  void launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots)
+  void launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots, const SelfArgs<TD, FD>* self)
   {
-    if (slots <= 1) launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads);
-    else if (slots == 2) launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads);
-    else launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads);
+    if (slots <= 1) launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads, self);
+    else if (slots == 2) launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads, self);
+    else launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads, self);
   }
-  bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused)
+  bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused, const SelfArgs<TD, FD>* self = nullptr)
   {
     ProcArgs<TD, FD> pz;
     pz.y = fz.y; pz.y_stride = fz.y_stride; pz.alpha = d_alpha.p; pz.beta = d_beta.p; pz.sweight = fz.sweight;
@@ -1012,9 +1185,9 @@ class Plan
     const bool hasb = coeff_has_beta;
     if constexpr (sizeof(FD) == 8)
     {
-      if (fused) { if (hasb) launch_process_t<true, true>(fa, pz, blocks, threads, slots); else launch_process_t<true, false>(fa, pz, blocks, threads, slots); SDFT_TRY(hipGetLastError()); return true; }
+      if (fused) { if (hasb) launch_process_t<true, true>(fa, pz, blocks, threads, slots, self); else launch_process_t<true, false>(fa, pz, blocks, threads, slots, self); SDFT_TRY(hipGetLastError()); return true; }
     }
-    if (hasb) launch_process_t<false, true>(fa, pz, blocks, threads, slots); else launch_process_t<false, false>(fa, pz, blocks, threads, slots);
+    if (hasb) launch_process_t<false, true>(fa, pz, blocks, threads, slots, self); else launch_process_t<false, false>(fa, pz, blocks, threads, slots, self);
     SDFT_TRY(hipGetLastError());
     return true;
   }
@@ -1127,25 +1300,47 @@ class Plan
     return true;
   }
 
+  // Synchronous calls do not sleep on the stream (a sleeping hipStreamSynchronize wakes up tens of microseconds late):
+  // they poll -- the completion word where the call's last kernel sets one, the stream otherwise -- for a bounded
+  // wall-clock time (about twice what the call can take at HBM speed, at most 5 ms; 50 ms for the word) and only then
+  // block.  flag_fallbacks counts completion words that never became visible (get_option "flag_fallbacks").
+  long flag_fallbacks = 0;
   bool finish(size_t work = 0)
   {
     if (async) return true;
+    using clock = std::chrono::steady_clock;
     if (flag_pending)
     {
       // the kernel's completion word: visible ~6 us before the stream reports the kernel done
       flag_pending = false;
       volatile unsigned* f = h_done_flag;
-      for (int spins = 0; spins < 4000000; ++spins)
-        if (*f == flag_seq) return true;
+      const clock::time_point t0 = clock::now();
+      for (unsigned spins = 1;; ++spins)
+      {
+        if (*f == flag_seq)
+        {
+          // the word says nothing about faults: ask the stream once (not ready yet is the normal answer)
+          const hipError_t e = hipStreamQuery(stream);
+          if (e != hipSuccess && e != hipErrorNotReady) { set_error("hipStreamQuery", hipGetErrorString(e)); return false; }
+          if (e == hipErrorNotReady) (void)hipGetLastError();
+          return true;
+        }
+        if ((spins & 1023u) == 0 && clock::now() - t0 > std::chrono::milliseconds(50)) break;
+      }
+      ++flag_fallbacks;
       return synchronize();                                  // never seen: fall back to the stream
     }
-    if (opt_spin && work && work <= ((size_t)1 << 24))
+    if (opt_spin && work)
     {
-      for (int spins = 0; spins < 20000; ++spins)
+      const double est_us = (double)work * (double)sizeof(fdx) / 5.0e6;      // at 5 TB/s
+      const auto budget = std::chrono::microseconds((long long)std::min(5000.0, 100.0 + 2.0 * est_us));
+      const clock::time_point t0 = clock::now();
+      for (unsigned spins = 1;; ++spins)
       {
         const hipError_t e = hipStreamQuery(stream);
         if (e == hipSuccess) return collect_profile();
         if (e != hipErrorNotReady) { set_error("hipStreamQuery", hipGetErrorString(e)); return false; }
+        if ((spins & 15u) == 0 && clock::now() - t0 > budget) break;
       }
       (void)hipGetLastError();
     }
@@ -1156,9 +1351,13 @@ class Plan
   // buffers call after call pay hipPointerGetAttributes once per buffer.  (A cached answer would
   // be stale only if a device allocation were freed and the very same address handed out again as
   // host memory; option "pointers" = 3 queries on every call, 1 / 2 declare all device / all host.)
+  // The hazard that remains with the default: an address classified once, freed by the host and handed out again as
+  // the other kind of memory between two calls on the same plan.  reset(), set_state() and set_stream() forget the
+  // cache; a host that recycles buffers between calls sets option "pointers" to 3 (or declares them with 1 / 2).
   struct PtrClass { const void* p; bool dev; };
   PtrClass ptr_cache[8] = {};
   unsigned ptr_cache_next = 0;
+  void forget_pointers() { for (PtrClass& e : ptr_cache) e = PtrClass{nullptr, false}; ptr_cache_next = 0; }
   bool on_device(const void* p)
   {
     if (opt_pointers == 1) return true;
@@ -1531,6 +1730,7 @@ class Plan
   {
     if (!bind()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
+    forget_pointers();
     if (nbins)
     {
       if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }

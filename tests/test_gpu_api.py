@@ -350,3 +350,47 @@ def test_plans_release_everything_they_allocated():
             assert float(np.abs(got - want).max()) <= 1e-6 * max(float(np.abs(want).max()), 1.0), (rep, i)
     for p in plans:
         p.close()
+
+
+def test_ring_timeout_is_reported_and_the_call_recovers():
+    """The ring form of the exact carries bounds its poll loops; a time-out used to end the kernel with wrong carries and
+    rc = 0.  Now the wave that ran out reports it through a word of pinned host memory: a synchronous call restores the
+    state it started from, runs again with the serial pass (bit-identical output and state) and records an error string;
+    an asynchronous call is reported by sdft_hip_synchronize.  chain_debug bit 5 makes the producers stop publishing."""
+    import ctypes as C
+    import torch
+    m, n = 256, 40000
+    x = noise(n, seed=5)
+    ref = O.best(m, "hann", 1.0, "f32f32")
+    want = ref.sdft(x)
+    from sdft_amd.sdft import SDFT
+    with SDFT(m, "hann", 1.0, "f32f32") as p:
+        p.set_option("chain_debug", 32)
+        out = np.empty((n, m), dtype=np.complex64)
+        p.api.lib.sdft_hip_clear_error()
+        p.api.sdft_n(p._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data))
+        err = p.api.last_error()
+        p.api.lib.sdft_hip_clear_error()
+        assert err and "re-run" in err and "valid" in err, err
+        assert p.get_option("ring_recoveries") == 1
+        assert np.array_equal(out, want)
+        p.set_option("chain_debug", 0)
+        x2 = noise(9000, seed=6)
+        assert np.array_equal(p.sdft(x2), ref.sdft(x2))          # the state after the recovery is the reference's
+        assert p.get_option("last_chain") == 2 and p.get_option("ring_recoveries") == 1
+        # device pointers, synchronous: same recovery
+        p.set_option("chain_debug", 32)
+        x3 = noise(30000, seed=7)
+        got3 = torch.empty((x3.size, m), dtype=torch.complex64, device="cuda")
+        p.api.sdft_n(p._p, x3.size, C.c_void_p(torch.from_numpy(x3).cuda().data_ptr()), C.c_void_p(got3.data_ptr()))
+        err = p.api.last_error(); p.api.lib.sdft_hip_clear_error()
+        assert err and "re-run" in err
+        assert np.array_equal(got3.cpu().numpy(), ref.sdft(x3)) and p.get_option("ring_recoveries") == 2
+        # asynchronous: nothing to re-run with, synchronize() reports
+        p.set_option("async", 1)
+        x4 = torch.from_numpy(noise(30000, seed=8)).cuda()
+        p.api.sdft_n(p._p, 30000, C.c_void_p(x4.data_ptr()), C.c_void_p(got3.data_ptr()))
+        assert p.api.last_error() is None
+        assert p.api.synchronize(p._p) != 0
+        err = p.api.last_error(); p.api.lib.sdft_hip_clear_error()
+        assert err and "asynchronous" in err, err

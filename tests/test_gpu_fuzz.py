@@ -66,6 +66,7 @@ def test_random_geometry_parity(seed):
             "row_slots_max": int(rng.integers(1, 3)),
             "segments": int(rng.choice([0, 1, 2, 5])),
             "fft_carry": int(rng.integers(0, 2)),
+            "self_carry": int(rng.integers(0, 2)),
             "fused": int(rng.integers(0, 2)),
         }
         x1 = noise(n1, seed=seed * 100 + case, dtype=td)

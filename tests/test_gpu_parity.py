@@ -291,9 +291,9 @@ def test_fft_carry_equals_direct_sums(m, chunk):
     want2 = ref.sdft(x2)
     outs = {}
     for fft in (1, 0):
-        with make(m, "hann", 1.0, "f32f64", chunk=chunk, carry=0, fft_carry=fft) as p:
+        with make(m, "hann", 1.0, "f32f64", chunk=chunk, carry=0, fft_carry=fft, self_carry=0) as p:     # the pre-pass forms
             outs[fft] = (p.sdft(x), p.sdft(x2))
-            assert p.get_option("last_chunks") > 1
+            assert p.get_option("last_chunks") > 1 and p.get_option("last_self") == 0
     for fft in (1, 0):
         assert rel_err(outs[fft][0], want) <= 1e-11, (fft, rel_err(outs[fft][0], want))
         assert rel_err(outs[fft][1], want2) <= 1e-11, (fft, rel_err(outs[fft][1], want2))
@@ -374,3 +374,73 @@ def test_very_large_dftsize(combo, m, n):
     else:
         assert rel_err(got, want) <= 1e-11
     assert np.array_equal(y, ref.isdft(got))
+
+
+# ---------------------------------------------------------------------------------------------
+# self-carried chunks: the chunk-parallel FD double call as ONE launch (round 3)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combo,m,chunk", [("f32f64", 1024, 192), ("f32f64", 1024, 3000), ("f32f64", 8, 64), ("f32f64", 64, 128),
+                                           ("f32f64", 256, 600), ("f32f64", 512, 5000), ("f32f64", 2048, 512), ("f64f64", 1024, 512),
+                                           ("f64f64", 128, 1000), ("f32f64", 16, 8), ("f32f64", 1024, 0)])
+@pytest.mark.parametrize("window", ["hann", "blackman"])
+def test_self_carried_chunks(combo, m, chunk, window):
+    """Every workgroup derives its carry-in from the raw samples (fold by cursor + one 2N-point FFT in LDS) and forms its
+    own differences: no pre-pass launch.  Against the oracle, against the pre-pass form, over calls that start at
+    cursor 0, mid-period and right before the roll-over, followed by a hop that reads the state the call left."""
+    td, fd, fdx = O.combo_types(combo)
+    ref = O.best(m, window, 1.0, combo)
+    calls = [noise(20000, seed=31, dtype=td), sine_sweep(7001, dtype=td), noise(2 * m - 1 + 4096, seed=32, dtype=td), noise(3 * m + 700, seed=33, dtype=td)]
+    with make(m, window, 1.0, combo, chunk=chunk, carry=0) as p, make(m, window, 1.0, combo, chunk=chunk, carry=0, self_carry=0) as q:
+        for x in calls:
+            want = ref.sdft(x)
+            got = p.sdft(x)
+            several = p.get_option("last_chunks") > 1
+            assert p.get_option("last_self") == (1 if several else 0)
+            old = q.sdft(x)
+            assert q.get_option("last_self") == 0 and (q.get_option("last_chunks") > 1) == several
+            assert rel_err(got, want) <= 1e-11, rel_err(got, want)
+            assert rel_err(got, old) <= 1e-12, rel_err(got, old)
+            hop = noise(100, seed=34, dtype=td)
+            assert rel_err(p.sdft(hop), ref.sdft(hop)) <= 1e-11
+            q.sdft(hop)
+            acc, fid, hist, cur = p.state()
+            racc, rfid, rhist, rcur = ref.state()
+            assert cur == rcur and np.array_equal(hist, rhist)
+            assert rel_err(acc, racc) <= 1e-11 and rel_err(fid, rfid) <= 1e-11
+
+
+def test_self_carried_chunks_batched_and_fused():
+    """Batched plans (channels ride on the grid) and the fused call (folded form) in the self-carried form."""
+    import torch
+    m, n, C = 1024, 12000, 3
+    x = sweep_batch(C, n)
+    refs = [O.best(m, "hann", 1.0, "f32f64") for _ in range(C)]
+    want = [r.sdft(x[c]) for c, r in enumerate(refs)]
+    with make(m, "hann", 1.0, "f32f64", channels=C) as p:
+        xd = torch.from_numpy(x).cuda()
+        d = p.sdft(xd)
+        assert p.get_option("last_self") == 1
+        got = d.cpu().numpy()
+        for c in range(C):
+            assert rel_err(got[c], want[c]) <= 1e-11
+        x2 = sweep_batch(C, 5000)[:, ::-1].copy()
+        got2 = p.sdft(torch.from_numpy(x2).cuda()).cpu().numpy()
+        for c in range(C):
+            assert rel_err(got2[c], refs[c].sdft(x2[c])) <= 1e-11
+    for mm, lat in ((1024, 1.0), (2048, 1.0), (256, 0.5)):
+        ref = O.best(mm, "hamming", lat, "f32f64")
+        xs = noise(30000, seed=41)
+        gain = np.linspace(1.0, 0.25, mm)
+        with make(mm, "hamming", lat, "f32f64") as p:
+            for part in (xs[:17000], xs[17000:]):
+                dd = ref.sdft(part)
+                want_y = ref.isdft((dd * gain[None, :]).astype(dd.dtype))
+                got_y = p.process(torch.from_numpy(part).cuda(), "gain", gain=gain).cpu().numpy()
+                assert p.get_option("last_self") == 1 and p.get_option("last_process_path") == 1
+                assert rel_err(got_y, want_y) <= 1e-6, rel_err(got_y, want_y)
+            p.set_option("self_carry", 0)
+            p.reset(); ref.reset()
+            dd = ref.sdft(xs)
+            want_y = ref.isdft((dd * gain[None, :]).astype(dd.dtype))
+            assert rel_err(p.process(xs, "gain", gain=gain), want_y) <= 1e-6
+            assert p.get_option("last_self") == 0
