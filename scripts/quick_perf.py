@@ -27,7 +27,7 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
     byts = channels * n * (m * esz + x.element_size())
     f = pr["forward"][0] / pr["forward"][1]; i = pr["inverse"][0] / pr["inverse"][1]
     c = pr["carry"][0] / max(pr["carry"][1], 1); d = pr["delta"][0] / pr["delta"][1]
-    print(f"n={n} m={m} {window} {combo} ch={channels} opts={opts} chunks={p.get_option('last_chunks')} len={p.get_option('last_chunk_len')}: "
+    print(f"n={n} m={m} {window} {combo} ch={channels} opts={opts} chunks={p.get_option('last_chunks')} len={p.get_option('last_chunk_len')} chain={p.get_option('last_chain')} flow={p.get_option('last_flow')}: "
           f"fwd {f:.3f} ms ({byts/f/1e9:.0f} GB/s, {channels*n/f/1e3:.1f} Msamp/s) carry {c:.3f} delta {d:.3f} inv {i:.3f} ms ({byts/i/1e9:.0f} GB/s) wall/iter {wall*1e3:.3f} ms", flush=True)
     p.close(); del out
 
@@ -114,6 +114,14 @@ if __name__ == "__main__":
                       f"process async {res[('async','process')]*1e6:.1f} us sync {res[('sync','process')]*1e6:.1f} us", flush=True)
                 pl.close()
             del out
+    if which == "relay":
+        # exact carries: relay form against the ring form, alone (profile events) and inside the call
+        for shape in ((262144, 4096, "blackman", "f32f32"), (262144, 1024, "hann", "f32f32"), (1000000, 1024, "hann", "f32f64")):
+            n, m, win, combo = shape
+            extra = {"carry": 1} if combo == "f32f64" else {}
+            for opts in ({"chain_relay": 0}, {}, {"relay_waves": 6}, {"relay_waves": 7}, {"relay_flow": 0}, {"relay_flow": 0, "segments": 4},
+                         {"segments": 1}, {"segments": 1, "chain_relay": 0}):
+                run(n, m, win, combo, **extra, **opts)
     if which == "mid":
         # calls between a hop and the north star's 48000 samples: chunk length against wall time per call
         for combo in ("f32f64", "f32f32"):

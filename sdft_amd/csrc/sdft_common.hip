@@ -20,6 +20,8 @@ __global__ void lane_selftest_kernel(int* out)
   const int lane = threadIdx.x;
   out[lane] = lane_from_below(lane + 100);
   out[64 + lane] = lane_from_above(lane + 100);
+  // row broadcast (carry_relay_kernel): every lane of a row of 16 receives the row's lane 3
+  out[128 + lane] = __builtin_amdgcn_update_dpp(0, lane + 100, 0x153 /*row_newbcast:3*/, 0xf, 0xf, true);
 }
 
 // Verifies on the device that the DPP wave shifts move data the way the kernels assume
@@ -31,15 +33,16 @@ bool lane_selftest()
   std::lock_guard<std::mutex> lock(mu);
   if (state != 0) { if (state < 0) set_error("lane_selftest", "DPP wave shift semantics mismatch"); return state > 0; }
   int* d = nullptr;
-  SDFT_TRY(hipMalloc((void**)&d, 128 * sizeof(int)));
+  SDFT_TRY(hipMalloc((void**)&d, 192 * sizeof(int)));
   hipLaunchKernelGGL(lane_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
-  int h[128];
+  int h[192];
   hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) { set_error("lane_selftest", hipGetErrorString(e)); return false; }
   bool ok = true;
   for (int l = 1; l < 64; ++l) ok = ok && (h[l] == l - 1 + 100);
   for (int l = 0; l < 63; ++l) ok = ok && (h[64 + l] == l + 1 + 100);
+  for (int l = 0; l < 64; ++l) ok = ok && (h[128 + l] == (l & ~15) + 3 + 100);
   state = ok ? 1 : -1;
   if (!ok) set_error("lane_selftest", "DPP wave shift semantics mismatch");
   return ok;

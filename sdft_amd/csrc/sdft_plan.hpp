@@ -191,6 +191,8 @@ class Plan
   long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
+  long opt_chain_relay = 1;      // exact carries: relay form (identical waves pass acc on as a token; products stay in registers)
+  long opt_relay_waves = 0;      // waves per workgroup of the relay form (0 = default)
   DevBuf<unsigned long long> d_chain_stats;
   long last_chain = 0;
 
@@ -250,6 +252,8 @@ class Plan
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
     if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
+    if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
+    d_ready.release();
     d_done_count.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
@@ -407,6 +411,7 @@ class Plan
       {
         len = ((len + 31) / 32) * 32;                        // whole trips of the exact pass's inner loop
         if (mid && len > 32) len = ((len + 63) / 64) * 64;   // whole blocks of the ring form at FD float
+        if (!mid && len > 64) len = ((len + 127) / 128) * 128;   // whole blocks of the relay form
       }
       len = std::max(1L, std::min(len, (long)n));
       chunks = (long)((n + len - 1) / len);
@@ -496,6 +501,74 @@ class Plan
     SDFT_TRY(hipGetLastError());
     return true;
   }
+  // relay form: block length = seed distance: divides 2N and the chunk length; L products live in L registers per lane
+  unsigned relay_block(long len) const
+  {
+    const size_t span = 2 * nbins;
+    const unsigned top = sizeof(FD) == 4 ? 128u : 64u;
+    for (unsigned cand : {128u, 64u, 32u, 16u, 8u})
+    {
+      if (cand > top) continue;
+      if (opt_chain_L > 0 && (unsigned)opt_chain_L != cand) continue;
+      if (span % cand == 0 && (size_t)len % cand == 0 && ((span / cand) * nbins * sizeof(fdx)) <= ((size_t)256 << 20)) return cand;
+    }
+    return 0;
+  }
+  // flow mode of the relay form (see forward_launch)
+  long opt_relay_flow = 1, last_flow = 0;
+  DevBuf<unsigned> d_ready;
+  unsigned ready_seq = 0;
+  unsigned* d_started = nullptr;      // signal memory
+  unsigned started_target = 0;
+  int wait_value_state = 0;           // 0 unknown, 1 usable, -1 not
+  bool wait_value_ok()
+  {
+    if (wait_value_state == 0)
+    {
+      int can = 0;
+      wait_value_state = -1;
+      if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
+          hipExtMallocWithFlags((void**)&d_started, 8, hipMallocSignalMemory) == hipSuccess)
+      {
+        if (hipMemset(d_started, 0, 8) == hipSuccess) wait_value_state = 1;
+        else { (void)hipFree(d_started); d_started = nullptr; }
+      }
+      (void)hipGetLastError();
+      started_target = 0;
+    }
+    return wait_value_state > 0;
+  }
+  // relays (32 bins of a channel each), waves per relay; two relays may share a workgroup (FD float, option relay_groups;
+  // measured slower: 12 waves of products and two chains on one CU contend for issue -- config 3 shape, 1.5 against 1.05 ms)
+  long opt_relay_groups = 1;     // relays per workgroup
+  static unsigned relay_waves_default() { return 8u; }
+  unsigned relay_waves() const
+  {
+    const long mx = relay_limits<FD>::waves;
+    return (unsigned)std::max(1L, std::min(mx, opt_relay_waves > 0 ? opt_relay_waves : (long)relay_waves_default()));
+  }
+  unsigned relay_groups(unsigned relays) const
+  {
+    const unsigned fit = (unsigned)relay_limits<FD>::waves / relay_waves();
+    unsigned g = opt_relay_groups > 0 ? (unsigned)opt_relay_groups : (unsigned)relay_limits<FD>::groups;
+    g = std::max(1u, std::min({g, fit, (unsigned)relay_limits<FD>::groups}));
+    return relays >= 2 ? g : 1u;
+  }
+  template <int L> bool launch_relay(ChainArgs<FD> cc, unsigned relays, hipStream_t on)
+  {
+    const unsigned waves = relay_waves(), groups = relay_groups(relays);
+    const unsigned blocks = (relays + groups - 1) / groups;
+    cc.P = waves; cc.chunks_channels = (unsigned)channels;
+    if constexpr (L * sizeof(FD) == 512)
+    {
+      // the longest block also exists as a measurement build
+      if (cc.stats) { hipLaunchKernelGGL((carry_relay_kernel<FD, L, true>), dim3(blocks), dim3(kWave * waves * groups), 0, on, cc); SDFT_TRY(hipGetLastError()); return true; }
+    }
+    if constexpr (L * sizeof(FD) <= 512)
+      hipLaunchKernelGGL((carry_relay_kernel<FD, L>), dim3(blocks), dim3(kWave * waves * groups), 0, on, cc);
+    SDFT_TRY(hipGetLastError());
+    return true;
+  }
   bool ensure_fseed(unsigned L)
   {
     if (fseed_L == L && d_fseed.p) return true;
@@ -550,7 +623,7 @@ class Plan
     const int st0 = st_cur, hist0 = hist_cur;
     const bool canon0 = fid_canonical;
     if (!forward_launch(n, x, x_stride, out, out_stride, rows, fuse)) return false;
-    if (last_chain != 2 || async) return true;
+    if (last_chain < 2 || async) return true;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (aux) SDFT_TRY(hipStreamSynchronize(aux));
     if (!ring_gave_up()) return true;
@@ -599,21 +672,25 @@ class Plan
     // leave most SIMDs idle; the plain serial pass when bins x channels already fill the chip
     unsigned cL = 0, cP = 0;
     const size_t serial_waves = ((nb + kWave / 2 - 1) / (kWave / 2)) * channels;
-    const bool use_chain = exact && chunks > 1 && opt_chain && fid_canonical && chain_geometry(cL, cP) &&
-                           (opt_chain >= 2 || serial_waves <= 1024);
+    const bool chain_ok = exact && chunks > 1 && opt_chain && fid_canonical && (opt_chain >= 2 || serial_waves <= 1024);
+    // relay form (default): identical waves, the block's products in registers; same shifted chunk grid as the ring form
+    const unsigned yL = (chain_ok && opt_chain_relay && !(opt_chain_debug & 19) && n < ((size_t)1 << 31)) ? relay_block(len) : 0u;
+    const bool use_relay = yL != 0;
+    const bool use_chain = use_relay || (chain_ok && chain_geometry(cL, cP));
     // ring form: the chunk grid is shifted so that every chunk but the first starts on a block boundary
     // of the cursor (chunk j starts at sample j*len - shift); one more chunk may be needed for the tail
-    const bool use_ring = use_chain && opt_chain_ring && !(opt_chain_debug & 19) && (len % (long)cL) == 0 && n < ((size_t)1 << 31);
+    const bool use_ring = use_relay || (use_chain && opt_chain_ring && !(opt_chain_debug & 19) && (len % (long)cL) == 0 && n < ((size_t)1 << 31));
     // the ring form's cost per block (flag, slot, chunk counter) is paid half as often with blocks twice as long
     unsigned rL = cL;
     if (use_ring && opt_chain_L <= 0 && cL == (sizeof(FD) == 4 ? 32u : 16u) && span % (2 * cL) == 0 && len % (long)(2 * cL) == 0) rL = 2 * cL;
+    if (use_relay) rL = yL;
     if (use_ring) cL = rL;
     const unsigned shift = use_ring ? (unsigned)(cursor % cL) : 0u;
     if (shift) { chunks = (long)((n + shift + (size_t)len - 1) / (size_t)len); last_chunks = chunks; }
 
     if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
-    last_chain = use_chain ? (use_ring ? 2 : 1) : 0;
+    last_chain = use_chain ? (use_relay ? 3 : (use_ring ? 2 : 1)) : 0;
     if ((exact || chunks == 1) && !use_chain && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
     if (use_chain && !ensure_fseed(cL)) return false;
 
@@ -662,6 +739,7 @@ class Plan
 
     // carries
     long segments = 1;
+    bool flow = false;
     if (exact && chunks > 1)
     {
       // time segments: the serial pass of segment s+1 (few waves, latency-bound) runs on `aux`
@@ -669,8 +747,18 @@ class Plan
       // up to 8 segments, each forward launch still filling the chip (>= 256 workgroups)
       const long launch_blocks = use_rows ? (long)channels * chunks : (long)channels * chunks * ntiles / kWavesPerBlock;
       segments = opt_segments > 0 ? opt_segments : std::max(1L, std::min(8L, launch_blocks / 256));
+      // Relay form, flow mode: ONE relay launch for the whole call on `aux` and ONE forward launch whose workgroups wait
+      // for their chunk's carries themselves (ForwardArgs::ready).  With segments and events the two passes barely overlap:
+      // a 16-wave forward workgroup fills a CU's registers, so the relays of segment s+1 wait until the forward launch of
+      // segment s has drained (config 3: chain 0.71 ms alone + forward 1.55 ms alone = 2.2 ms together).  Here the relays
+      // hold their CUs from the start, the forward workgroups take whatever is free, in time order, and the whole chip
+      // once the relays are through.  The forward launch is held back (hipStreamWaitValue32 on a word every relay workgroup
+      // bumps at its start) until the relays are resident: a forward workgroup that waits for a relay which cannot start
+      // would be a deadlock -- every wait in the kernels is bounded all the same, and a time-out re-runs the call (forward_device).
+      flow = use_relay && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && wait_value_ok();
+      if (flow) segments = 1;
       segments = std::max(1L, std::min(segments, chunks));
-      if (segments > 1)
+      if (segments > 1 || flow)
       {
         if (!aux) SDFT_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
         if (!ev_delta) SDFT_TRY(hipEventCreateWithFlags(&ev_delta, hipEventDisableTiming));
@@ -686,7 +774,7 @@ class Plan
       }
     }
     // the stage's events go where its kernels go (the overlapped exact pass runs on `aux`)
-    hipStream_t carry_stream = segments > 1 ? aux : stream;
+    hipStream_t carry_stream = (segments > 1 || flow) ? aux : stream;
     if (!prof_begin(ST_CARRY, carry_stream)) return false;
     CarryArgs<FD> ca;
     ca.acc_next = nullptr; ca.fid_next = nullptr; ca.chunk0 = 0; ca.launch_chunks = (unsigned)chunks;
@@ -707,18 +795,43 @@ class Plan
       for (long sg = 0; sg < segments && use_chain; ++sg)
       {
         const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
-        ChainArgs<FD> cc;
+        ChainArgs<FD> cc{};
         cc.delta = d_delta.p; cc.tw = d_tw.p; cc.fseed = d_fseed.p; cc.carry = d_carry.p;
         cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
         cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
         cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
-        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & 47u; cc.stats = nullptr;
-        if (opt_chain_debug & 16) { if (!d_chain_stats.reserve(64)) return false; cc.stats = d_chain_stats.p; }
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & (47u | 128u); cc.stats = nullptr;
+        if (opt_chain_debug & (16 | 64 | 128)) { if (!d_chain_stats.reserve(64 + 3 * 1024)) return false; cc.stats = d_chain_stats.p; }
         cc.status = (use_ring && ensure_status()) ? d_status : nullptr;
         if (cc.status) status_armed = true;
+        cc.ready = nullptr; cc.ready_seq = 0; cc.started = nullptr; cc.chunks_channels = (unsigned)channels;
+        if (flow)
+        {
+          const size_t relays_per_channel = (nb + kWave / 2 - 1) / (kWave / 2);
+          const size_t words = channels * (size_t)chunks * relays_per_channel;
+          if (d_ready.cap < words)
+          {
+            if (!d_ready.reserve(words)) return false;
+            SDFT_TRY(hipMemsetAsync(d_ready.p, 0, d_ready.cap * sizeof(unsigned), carry_stream));
+            ready_seq = 0;
+          }
+          if (++ready_seq == 0) { SDFT_TRY(hipMemsetAsync(d_ready.p, 0, d_ready.cap * sizeof(unsigned), carry_stream)); ready_seq = 1; }
+          cc.ready = d_ready.p; cc.ready_seq = ready_seq; cc.started = d_started;
+        }
         const unsigned cblocks = eblocks * (unsigned)channels;
         bool ok = true;
-        if (use_ring)
+        if (use_relay)
+        {
+          switch (rL)
+          {
+            case 128: ok = launch_relay<128>(cc, cblocks, carry_stream); break;
+            case 64:  ok = launch_relay<64>(cc, cblocks, carry_stream); break;
+            case 32:  ok = launch_relay<32>(cc, cblocks, carry_stream); break;
+            case 16:  ok = launch_relay<16>(cc, cblocks, carry_stream); break;
+            default:  ok = launch_relay<8>(cc, cblocks, carry_stream); break;
+          }
+        }
+        else if (use_ring)
         {
           // ring form: blocks of 64 (FD float) / 32 (FD double) steps where the geometry allows
           if (rL == 64) { if constexpr (sizeof(FD) == 4) ok = launch_ring<64>(cc, cblocks, carry_stream); }
@@ -730,7 +843,14 @@ class Plan
         else if (cL == 16) ok = launch_chain<16>(cc, cblocks, carry_stream);
         else ok = launch_chain<8>(cc, cblocks, carry_stream);
         if (!ok) return false;
-        if (segments > 1) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
+        if (segments > 1 || flow) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
+        if (flow)
+        {
+          // the forward launch may go once every relay workgroup of this launch is resident
+          const unsigned relays = cblocks, groups = relay_groups(relays);
+          started_target += (relays + groups - 1) / groups;
+          SDFT_TRY(hipStreamWaitValue32(stream, d_started, started_target, hipStreamWaitValueGte, 0xffffffffu));
+        }
       }
       for (long sg = 0; sg < segments && !use_chain; ++sg)
       {
@@ -774,7 +894,7 @@ class Plan
 
     // K1
     if (!prof_begin(ST_FORWARD)) return false;
-    ForwardArgs<FD> fa;
+    ForwardArgs<FD> fa{};
     fa.delta = d_delta.p; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = d_carry.p;
     fa.seed = (use_seed && !use_chain) ? d_seed.p : nullptr;
     fa.fseed = use_chain ? d_fseed.p : nullptr; fa.fseed_L = use_chain ? cL : 0;
@@ -787,6 +907,14 @@ class Plan
     fa.vec_store = (bins_per_lane() == 2 && (nb % 2 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride % 2 == 0) && !rows) ? 1 : 0;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
+    fa.ready = nullptr; fa.ready_seq = 0; fa.ready_n = 0; fa.ready_channels = (unsigned)channels; fa.ready_status = nullptr; fa.ready_status_seen = 0;
+    if (flow)
+    {
+      fa.ready = d_ready.p; fa.ready_seq = ready_seq; fa.ready_n = (unsigned)((nb + kWave / 2 - 1) / (kWave / 2));
+      fa.ready_status = ensure_status() ? d_status : nullptr;
+      fa.ready_status_seen = fa.ready_status ? *(volatile unsigned*)h_status : 0u;
+      if (fa.ready_status) status_armed = true;
+    }
     // short synchronous calls: the row-group kernels report their own completion (a word in pinned host memory
     // reaches the host before the stream does).  Worth it while the kernel has little to write back: n = 4096,
     // N = 1024: 49.7 -> 46.7 us per sdft_sdft_n, 40.4 -> 35.8 us per fused call; nothing at n = 48000.
@@ -798,7 +926,7 @@ class Plan
       const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
       fa.chunk0 = (unsigned)j0; fa.launch_chunks = (unsigned)(j1 - j0);
       fa.total_waves = (unsigned long long)channels * (unsigned long long)(j1 - j0) * (unsigned long long)ntiles;
-      if (segments > 1) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[sg], 0));
+      if (segments > 1) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[sg], 0));      // (flow mode: the kernel waits chunk by chunk)
       const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
       // fused arithmetic only where the result is not claimed bit-identical: FD double with carries
       // from the chunk-parallel pass (use_seed == false <=> fast mode, more than one chunk)
@@ -824,6 +952,8 @@ class Plan
       SDFT_TRY(hipGetLastError());
     }
     SDFT_TRY(hipGetLastError());
+    if (flow) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[0], 0));          // the call ends when both launches have
+    last_flow = flow;
     if (!prof_end(ST_FORWARD)) return false;
 
     // fid stays on the canonical rotation sequence unless this call seeded chunks from the closed-form
@@ -845,7 +975,7 @@ class Plan
     sa.hist_in = d_hist[hist_cur].p; sa.hist_out = d_hist[hist_cur ^ 1].p;
     sa.acc_in = d_accs[st_cur].p;
     sa.log2m = 0; while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
-    ForwardArgs<FD> fa;
+    ForwardArgs<FD> fa{};
     fa.delta = nullptr; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = nullptr; fa.seed = nullptr; fa.fseed = nullptr; fa.fseed_L = 0;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = nullptr;
     fa.acc_state = d_accs[st_cur ^ 1].p; fa.fid_state = d_fids[st_cur ^ 1].p; fa.n = n;
@@ -1297,6 +1427,15 @@ class Plan
 #endif
     if (!d_chain_stats.p) return false;
     SDFT_TRY(hipMemcpy(out32, d_chain_stats.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return true;
+  }
+  // development aid: the relay form's stamps (option chain_debug bit 7), 3 per turn of workgroup 0
+  bool relay_stamps(unsigned long long* out, size_t count)
+  {
+    if (!d_chain_stats.p || d_chain_stats.cap < 64 + count) return false;
+    SDFT_TRY(hipStreamSynchronize(stream));
+    if (aux) SDFT_TRY(hipStreamSynchronize(aux));
+    SDFT_TRY(hipMemcpy(out, d_chain_stats.p + 64, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return true;
   }
 

@@ -377,7 +377,7 @@ def test_ring_timeout_is_reported_and_the_call_recovers():
         p.set_option("chain_debug", 0)
         x2 = noise(9000, seed=6)
         assert np.array_equal(p.sdft(x2), ref.sdft(x2))          # the state after the recovery is the reference's
-        assert p.get_option("last_chain") == 2 and p.get_option("ring_recoveries") == 1
+        assert p.get_option("last_chain") >= 2 and p.get_option("ring_recoveries") == 1
         # device pointers, synchronous: same recovery
         p.set_option("chain_debug", 32)
         x3 = noise(30000, seed=7)

@@ -109,15 +109,16 @@ def test_exact_carry_chain_form_bit_exact(combo, m, block):
     ch = 2
     lens = (3 * m + 5, 4 * m + 8 * 37, 555)                      # cursors at arbitrary offsets
     xb = np.stack([noise(sum(lens), seed=3 + c, dtype=td) for c in range(ch)])
-    for segments, ring in ((1, 1), (3, 1), (1, 0), (3, 0)):  # products through the LDS ring / in rounds with a barrier each
+    # products through the LDS ring / in rounds with a barrier each / relay form (products stay in registers, acc is a token)
+    for segments, ring, relay in ((1, 1, 0), (3, 1, 0), (1, 0, 0), (3, 0, 0), (1, 1, 1), (3, 1, 1)):
         refs = [O.best(m, "blackman", 1.0, combo) for _ in range(ch)]
-        with make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=2, segments=segments, chain_ring=ring) as p, \
+        with make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=2, segments=segments, chain_ring=ring, chain_relay=relay) as p, \
              make(m, "blackman", 1.0, combo, ch, chunk=64, carry=1, chain=0, segments=segments) as q:
             i = 0
             for n in lens:
                 seg = np.ascontiguousarray(xb[:, i:i + n])
                 got, old = p.sdft(seg), q.sdft(seg)
-                assert p.get_option("last_chain") == ((2 if ring else 1) if block else 0) and q.get_option("last_chain") == 0
+                assert p.get_option("last_chain") == ((3 if relay else 2 if ring else 1) if block else 0) and q.get_option("last_chain") == 0
                 assert p.get_option("last_chunks") > 2 or m == 7
                 for c in range(ch):
                     want = refs[c].sdft(seg[c])
@@ -134,10 +135,48 @@ def test_exact_carry_chain_form_bit_exact(combo, m, block):
         want = O.best(m, "hann", 1.0, combo).sdft(x)
         for L, P, ring in ((8, 1, 1), (8, 7, 1), (8, 1, 0), (8, 7, 0), (block if block < 32 or combo.endswith("f32") else 16, 2, 1),
                            (block if block < 32 or combo.endswith("f32") else 16, 2, 0)):
-            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, chain_producers=P, chain_ring=ring) as p:
+            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, chain_producers=P, chain_ring=ring, chain_relay=0) as p:
                 got = p.sdft(x)
                 assert p.get_option("last_chain") == (2 if ring else 1)
                 assert np.array_equal(got, want), (combo, m, L, P, ring)
+        for L, W in ((8, 1), (8, 8), (8, 3), (block if block < 32 else 32, 2)):
+            with make(m, "hann", 1.0, combo, chunk=96, carry=1, chain=2, chain_block=L, relay_waves=W) as p:
+                got = p.sdft(x)
+                assert p.get_option("last_chain") == 3
+                assert np.array_equal(got, want), (combo, m, L, W, "relay")
+
+
+@pytest.mark.parametrize("combo,m,chunk,want_l", [("f32f32", 4096, 1024, 128), ("f32f32", 1024, 0, 128), ("f64f32", 512, 192, 64),
+                                                  ("f32f64", 1024, 512, 64), ("f64f64", 256, 96, 32), ("f32f32", 2048, 128, 128)])
+def test_exact_carry_relay_form_long_blocks(combo, m, chunk, want_l):
+    """Relay form at the block lengths the big shapes use (128 products in 128 registers per lane at FD float, 64 at FD
+    double): calls that start at cursor 0, mid-block (the ragged first block adds nothing for the steps before the call)
+    and just before the roll-over; batched; in overlap segments; state and the hop that follows bit-identical."""
+    td, fd, fdx = O.combo_types(combo)
+    ref = O.best(m, "blackman", 1.0, combo)
+    lens = (9000 + 37, 2 * m + 4096 + 5, 6 * 1024, 4096 + 63)
+    with make(m, "blackman", 1.0, combo, chunk=chunk, carry=1, chain=2) as p:
+        for i, n in enumerate(lens):
+            x = noise(n, seed=50 + i, dtype=td)
+            want = ref.sdft(x)
+            got = p.sdft(x)
+            assert p.get_option("last_chain") == 3, (p.get_option("last_chain"), p.get_option("last_chunk_len"))
+            assert np.array_equal(got, want), (combo, m, n, rel_err(got, want))
+            hop = noise(77, seed=60 + i, dtype=td)
+            assert np.array_equal(p.sdft(hop), ref.sdft(hop))
+        acc, fid, hist, cur = p.state()
+        racc, rfid, rhist, rcur = ref.state()
+        assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid) and np.array_equal(hist, rhist)
+    # batched, segments on the auxiliary stream, odd wave counts
+    C = 3
+    xb = np.stack([noise(20000, seed=70 + c, dtype=td) for c in range(C)])
+    wants = [O.best(m, "hann", 1.0, combo).sdft(xb[c]) for c in range(C)]
+    for waves, segments in ((0, 0), (2, 3), (5, 1), (8, 4)):
+        with make(m, "hann", 1.0, combo, C, chunk=chunk, carry=1, chain=2, relay_waves=waves, segments=segments) as p:
+            got = p.sdft(xb)
+            assert p.get_option("last_chain") == 3
+            for c in range(C):
+                assert np.array_equal(got[c], wants[c]), (combo, m, waves, segments, c)
 
 
 def test_exact_chain_falls_back_while_fid_is_off_the_canonical_sequence():
@@ -444,3 +483,38 @@ def test_self_carried_chunks_batched_and_fused():
             want_y = ref.isdft((dd * gain[None, :]).astype(dd.dtype))
             assert rel_err(p.process(xs, "gain", gain=gain), want_y) <= 1e-6
             assert p.get_option("last_self") == 0
+
+
+def test_exact_carry_relay_flow_mode():
+    """Flow mode (default with the relay form): one relay launch on the auxiliary stream, one forward launch whose
+    workgroups wait for their chunk's carries (time-major numbering for batched plans), against the segmented form and
+    the oracle; the fused call takes it too."""
+    import torch
+    for combo, m, C, n in (("f32f32", 1024, 1, 60000), ("f32f32", 256, 3, 20000), ("f32f64", 512, 2, 30000), ("f32f32", 4096, 1, 20000)):
+        td, fd, fdx = O.combo_types(combo)
+        xb = np.stack([noise(n, seed=90 + c, dtype=td) for c in range(C)])
+        x2 = np.stack([noise(5000 + 77, seed=95 + c, dtype=td) for c in range(C)])
+        refs = [O.best(m, "hamming", 1.0, combo) for _ in range(C)]
+        want = [r.sdft(xb[c]) for c, r in enumerate(refs)]
+        want2 = [r.sdft(x2[c]) for c, r in enumerate(refs)]
+        for flow in (1, 0):
+            with make(m, "hamming", 1.0, combo, C, carry=1, chain=2, relay_flow=flow) as p:
+                got = p.sdft(torch.from_numpy(xb if C > 1 else xb[0]).cuda()).cpu().numpy()
+                assert p.get_option("last_chain") == 3 and p.get_option("last_flow") == flow, (combo, m, p.get_option("last_chain"), p.get_option("last_flow"))
+                got2 = p.sdft(x2 if C > 1 else x2[0])            # second call: mid-block start, host pointers
+                assert p.get_option("last_flow") == flow
+                for c in range(C):
+                    assert np.array_equal(got[c] if C > 1 else got, want[c]), (combo, m, flow, c)
+                    assert np.array_equal(got2[c] if C > 1 else got2, want2[c]), (combo, m, flow, c)
+    # the fused call (exact carries at FD float: folded form on top of the relay's carries)
+    m, n = 1024, 40000
+    x = noise(n, seed=99)
+    ref = O.best(m, "hann", 1.0, "f32f32")
+    d = ref.sdft(x)
+    with make(m, "hann", 1.0, "f32f32") as p:
+        y = p.process(torch.from_numpy(x).cuda(), "identity").cpu().numpy()
+        assert p.get_option("last_flow") == 1 and p.get_option("last_chain") == 3
+        assert rel_err(y, ref.isdft(d)) <= 1e-4
+        acc, fid, hist, cur = p.state()
+        racc, rfid, rhist, rcur = ref.state()
+        assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid)
