@@ -58,6 +58,17 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
      sdft_hip_op_gain      params = sdft_fd_t gains[dftsize]  (host or device): X'[k] = X[k] * gains[k]
      sdft_hip_op_shift     params = const long* (host): X'[k] = X[k - *params], zero outside the spectrum
      sdft_hip_op_cgain     params = sdft_fdx_t gains[dftsize] (host or device): X'[k] = X[k] * gains[k], complex
+     sdft_hip_op_gain_rows / sdft_hip_op_cgain_rows   gains that change with time -- what a host of the reference does when
+                           its loop over the matrix recomputes the mask every hop: params = const sdft_hip_gain_rows_t*
+                           { gains[rows][dftsize] (real / complex; host or device), rows, hop }: vector r applies to the
+                           call's samples [r*hop, (r+1)*hop), the last vector to everything after it.  Still one launch:
+                           the folded coefficients of all vectors are formed by one small launch in front of it.
+     sdft_hip_op_gate      params = sdft_fd_t[2] {threshold, floor} (host): X'[k] = X[k] if |X[k]| >= threshold, else
+                           X[k] * floor (a spectral gate; floor = 0 removes the bin)
+     sdft_hip_op_power     params = sdft_fd_t[2] {exponent, scale} (host): X'[k] = X[k] * scale * |X[k]|^(exponent-1), i.e.
+                           |X'[k]| = scale * |X[k]|^exponent with the phase kept (spectral compression / expansion)
+                           (gate and power are not linear in the spectrum: they run on the windowed rows inside the
+                           row-group kernel, dftsize <= 2048 double / 4096 float, two passes beyond)
    dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
    (not with the shift).  Batched plans: samples / out [channels][nsamples].
    Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the path's bar (1e-6
@@ -65,7 +76,9 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
    "fused_exact" = 1) wherever the analysis is: calls shorter than 512 samples, FD float, FD double with
    carry = 1.  The stream state a call leaves behind is the one the two calls leave.  Returns 0, or -1
    with sdft_hip_last_error() set. */
-enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2, sdft_hip_op_cgain = 3 };
+enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2, sdft_hip_op_cgain = 3,
+                   sdft_hip_op_gain_rows = 4, sdft_hip_op_cgain_rows = 5, sdft_hip_op_gate = 6, sdft_hip_op_power = 7 };
+typedef struct { const void* gains; size_t rows; size_t hop; } sdft_hip_gain_rows_t;
 int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t* samples, sdft_td_t* const out,
                        const int op, const void* params, sdft_fdx_t* dfts) SDFT_HIP_SYMBOL(process_n);
 

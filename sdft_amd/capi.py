@@ -14,7 +14,7 @@ from . import build as _build
 COMBOS = _build.COMBOS
 WINDOWS = {"boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3}   # sdft.h:127-133 of the reference
 STAGES = ("delta", "carry", "forward", "inverse")
-OPS = {"identity": 0, "gain": 1, "shift": 2, "cgain": 3}                      # enum sdft_hip_op (sdft_hip.h)
+OPS = {"identity": 0, "gain": 1, "shift": 2, "cgain": 3, "gain_rows": 4, "cgain_rows": 5, "gate": 6, "power": 7}   # enum sdft_hip_op (sdft_hip.h)
 
 # every typed entry point exported per (td, fd) combination:  name -> (restype, argtypes)
 _TD = {"f32": C.c_float, "f64": C.c_double}

@@ -2919,27 +2919,84 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
 // output bins in ascending order; a shift keeps source bins in the same order, and the bins it
 // empties add +-0, which never changes a running sum that started at +0.
 // ------------------------------------------------------------------------------------------
-enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2, OP_CGAIN = 3 };
+//   gate  (thr, floor)  X'_k = X_k if |X_k| >= thr, else X_k * floor            (not linear: windowed rows only)
+//   power (p, scale)    X'_k = X_k * scale * |X_k|^(p-1), i.e. |X'_k| = scale * |X_k|^p with the phase kept
+// Gains may change with time: `rows` gain vectors, row r for the call's samples [r*hop, (r+1)*hop), the last one for
+// everything after it (what a host does when it recomputes its mask every hop; README.md:42-47 leaves that loop to it).
+enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2, OP_CGAIN = 3, OP_GATE = 4, OP_POWER = 5 };
 template <typename FD> struct SpectralOp
 {
   int kind;
-  const FD* gain;             // OP_GAIN: [N] real factors; OP_CGAIN: [N] complex factors (re, im interleaved)
+  const FD* gain;             // OP_GAIN: [rows][N] real factors; OP_CGAIN: [rows][N] complex factors (re, im interleaved)
   long shift;                 // OP_SHIFT
+  unsigned rows;              // gain vectors (<= 1: one for the whole call)
+  size_t hop;                 // samples per gain vector
+  size_t t0;                  // index, within the host's call, of the first row a launch sees (two-pass segments)
+  FD p0, p1;                  // OP_GATE: threshold, floor; OP_POWER: exponent, scale
 };
+template <typename FD> SDFT_HD bool op_is_linear(int kind) { return kind <= OP_CGAIN; }
+// the gain vector of row t of the launch
+template <typename FD> SDFT_D const FD* gain_row(const SpectralOp<FD>& op, size_t t, unsigned nbins)
+{
+  if (op.rows <= 1 || !op.gain) return op.gain;
+  size_t r = (op.t0 + t) / op.hop;
+  if (r >= op.rows) r = op.rows - 1;
+  return op.gain + r * (size_t)nbins * (op.kind == OP_CGAIN ? 2u : 1u);
+}
+// ... walked forward in time (the row-group kernels): one division at the start, additions afterwards
+template <typename FD> struct GainCursor
+{
+  const FD* g; size_t next, hop, stride; unsigned left;     // next: launch-relative time at which the next vector starts
+  SDFT_D void start(const SpectralOp<FD>& op, size_t t, unsigned nbins)
+  {
+    g = op.gain; next = ~(size_t)0; hop = op.hop; left = 0; stride = (size_t)nbins * (op.kind == OP_CGAIN ? 2u : 1u);
+    if (op.rows <= 1 || !op.gain || (op.kind != OP_GAIN && op.kind != OP_CGAIN)) return;
+    size_t r = (op.t0 + t) / op.hop;
+    if (r >= op.rows) r = op.rows - 1;
+    g = op.gain + r * stride;
+    left = op.rows - 1 - (unsigned)r;
+    if (left) next = (r + 1) * op.hop - op.t0;
+  }
+  SDFT_D void seek(size_t t)                               // t never decreases
+  {
+    while (left && t >= next) { g += stride; --left; next = left ? next + hop : ~(size_t)0; }
+  }
+};
+// the operations that are not linear in the spectrum, on one windowed bin
+template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>& op)
+{
+  if (op.kind == OP_GATE)
+  {
+    const FD mag2 = v.re * v.re + v.im * v.im;
+    return (mag2 < op.p0 * op.p0) ? cscale(v, op.p1) : v;
+  }
+  if (op.kind == OP_POWER)
+  {
+    const FD mag2 = v.re * v.re + v.im * v.im;
+    if (!(mag2 > (FD)0)) return cmake<FD>((FD)0, (FD)0);
+    FD f;
+    if constexpr (sizeof(FD) == 8) f = op.p1 * pow(mag2, (op.p0 - (FD)1) * (FD)0.5);
+    else f = op.p1 * powf(mag2, (op.p0 - (FD)1) * (FD)0.5);
+    return cscale(v, f);
+  }
+  return v;
+}
 
+// grow: the gain vector of the row v belongs to (gain_row / GainCursor); unused by the other operations
 template <typename FD, bool LAT1, bool OPS>
-SDFT_D FD synth_term(cx<FD> v, unsigned k, const SpectralOp<FD>& op, const cx<FD>* syn, unsigned nbins)
+SDFT_D FD synth_term(cx<FD> v, unsigned k, const SpectralOp<FD>& op, const cx<FD>* syn, unsigned nbins, const FD* grow = nullptr)
 {
   long ko = (long)k;                                       // output bin whose sign / twiddle applies
   if constexpr (OPS)                                       // (plain sdft_isdft_n instantiates without the checks)
   {
-    if (op.kind == OP_GAIN) v = cscale(v, op.gain[k < nbins ? k : 0]);
-    else if (op.kind == OP_CGAIN) v = cmul(v, reinterpret_cast<const cx<FD>*>(op.gain)[k < nbins ? k : 0]);
+    if (op.kind == OP_GAIN) v = cscale(v, grow[k < nbins ? k : 0]);
+    else if (op.kind == OP_CGAIN) v = cmul(v, reinterpret_cast<const cx<FD>*>(grow)[k < nbins ? k : 0]);
     else if (op.kind == OP_SHIFT)
     {
       ko += op.shift;
       if (ko < 0 || ko >= (long)nbins) return (FD)0;
     }
+    else if (op.kind >= OP_GATE) v = op_pointwise(v, op);
   }
   if constexpr (LAT1) return v.re * ((ko & 1) ? (FD)(-1) : (FD)(+1));               // sdft.h:643
   else { const cx<FD> sy = syn[ko < (long)nbins ? ko : 0]; return v.re * sy.re - v.im * sy.im; }   // re of :650
@@ -3135,6 +3192,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // SYN: padded row length of the terms image (bins of all waves + one 16-byte vector)
   const unsigned term_bins = (unsigned)(nv * kWave * BPL);
   const unsigned term_stride = term_bins + 16u / (unsigned)sizeof(FD);
+  GainCursor<FD> gcur;                                     // SYN: the gain vector of the sample being finished
+  if constexpr (SYN != 0) gcur.start(fz.op, t0, a.nbins); else gcur.g = nullptr;
+  size_t gtime = t0;                                       // time of the next sample finish() sees
 
   auto publish = [&](const cx<FD> (&x)[S][BPL], int buf, int u)
   {
@@ -3157,6 +3217,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   auto finish = [&](const cx<FD> (&xin)[S][BPL], int buf, int u)
   {
+    if constexpr (SYN != 0) { gcur.seek(gtime); ++gtime; }
 #pragma unroll
     for (int q = 0; q < S; ++q)
     {
@@ -3208,10 +3269,11 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         for (int b = 0; b < BPL; ++b)
         {
           const unsigned k = off_elems[q] + (unsigned)b;
-          if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], fz.op.gain[keep[q][b] ? k : 0]);
-          else if (fz.op.kind == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(fz.op.gain)[keep[q][b] ? k : 0]);
-          SpectralOp<FD> shift_only; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
-          shift_only.gain = nullptr; shift_only.shift = fz.op.shift;
+          if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], gcur.g[keep[q][b] ? k : 0]);
+          else if (fz.op.kind == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(gcur.g)[keep[q][b] ? k : 0]);
+          else if (fz.op.kind >= OP_GATE) y[b] = op_pointwise(y[b], fz.op);
+          SpectralOp<FD> shift_only = fz.op; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
+          shift_only.gain = nullptr;
           const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
           terms[((size_t)buf * G + (size_t)u) * term_stride + k] = keep[q][b] ? term : (FD)0;
         }
@@ -3450,9 +3512,11 @@ template <typename TD, typename FD> struct ProcArgs
 {
   TD* y;                      // [channels][n]
   size_t y_stride;
-  const double* alpha;        // [N]
-  const double* beta;         // [N]
+  const double* alpha;        // [rows][N]
+  const double* beta;         // [rows][N]
   FD sweight;
+  unsigned rows;              // coefficient vectors (time-varying gains; <= 1: one for the call)
+  size_t hop;                 // samples per vector: vector r for the call's samples [r*hop, (r+1)*hop), the last for the rest
 };
 
 // alpha / beta for source bin r: every virtual position m whose mirror image is r (m = r, and m = -r or
@@ -3464,6 +3528,9 @@ __global__ __launch_bounds__(kBlock) void fold_coeff_kernel(double* alpha, doubl
 {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x, N = (long)nbins;
   if (r >= N) return;
+  // one coefficient vector per gain vector (blockIdx.y): alpha / beta [rows][N]
+  if (op.rows > 1 && op.gain) op.gain += (size_t)blockIdx.y * (size_t)nbins * (op.kind == OP_CGAIN ? 2u : 1u);
+  alpha += (size_t)blockIdx.y * nbins; beta += (size_t)blockIdx.y * nbins;
   const double h[5] = {(double)h2, (double)h1, (double)h0, (double)h1, (double)h2};
   double al = 0.0, be = 0.0;
   auto add_position = [&](long m, bool flip)
@@ -3559,14 +3626,27 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
     s[j].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, (long)kk, c, s[j].tw)
              : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
     }
-    al[j] = pz.alpha[kk];
-    be[j] = pz.beta[kk];
-    if (!live[j])
-    {
-      s[j].tw = cmake<FD>((FD)0, (FD)0); s[j].acc = s[j].tw; s[j].fid = s[j].tw;
-      al[j] = (AT)0; be[j] = (AT)0;
-    }
+    if (!live[j]) { s[j].tw = cmake<FD>((FD)0, (FD)0); s[j].acc = s[j].tw; s[j].fid = s[j].tw; }
   }
+  // coefficients: one vector for the call, or (time-varying gains) vector r for the samples [r*hop, (r+1)*hop)
+  size_t coeff_row = 0, coeff_next = ~(size_t)0;
+  if (pz.rows > 1)
+  {
+    coeff_row = t0 / pz.hop;
+    if (coeff_row >= pz.rows) coeff_row = pz.rows - 1;
+    if (coeff_row + 1 < pz.rows) coeff_next = (coeff_row + 1) * pz.hop;
+  }
+  auto load_coeff = [&]()
+  {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+    {
+      const unsigned k = (unsigned)((j * nwaves + wave) * kWave + lane);
+      al[j] = live[j] ? pz.alpha[coeff_row * a.nbins + k] : (AT)0;
+      be[j] = live[j] ? pz.beta[coeff_row * a.nbins + k] : (AT)0;
+    }
+  };
+  load_coeff();
   __syncthreads();
 
   // one sample: the recurrence (sdft.h:566-587) for this lane's bins, then their share of the output sample
@@ -3637,7 +3717,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   {
     const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
     AT v[G];
-    if (m == G && c + G <= maxc)
+    if (m == G && c + G <= maxc && t + G <= coeff_next)
     {
       FD dl[G];
       if constexpr (SELF) self_deltas<G>(dl, xin, hin, t, (size_t)span);
@@ -3658,6 +3738,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
         v[u] = (AT)0;
         if (u < m)
         {
+          if (t + u == coeff_next)                          // the next gain vector takes over (workgroup-uniform)
+          {
+            ++coeff_row;
+            coeff_next = (coeff_row + 1 < pz.rows) ? coeff_next + pz.hop : ~(size_t)0;
+            load_coeff();
+          }
           const FD dl = SELF ? self_delta1<TD, FD>(xin, hin, t + u, (size_t)span) : d[t + u];
           const bool wrap = (c == maxc);
           v[u] = step_all(dl, wrap);
@@ -4056,17 +4142,21 @@ __global__ __launch_bounds__(2 * kWave) void process_hop2_kernel(ProcHopArgs<TD,
   signal_done_workgroup(a.done);
 }
 
-// rows[ch][t][k] *= gain[k] (the processed copy of the spectrum on the two-pass path of sdft_hip_process_n)
+// rows[ch][t][k] = op(rows[ch][t][k]) for the operations that change a bin in place (the processed copy of the spectrum
+// on the two-pass path of sdft_hip_process_n)
 template <typename FD>
-__global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, const FD* gain,
-                                                            int complex_gain)
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, SpectralOp<FD> op)
 {
   const size_t per = rows * nbins, total = per * channels;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
   {
     const size_t ch = i / per, r = i - ch * per;
+    const size_t t = r / nbins, k = r - t * nbins;
     cx<FD>* p = mat + ch * stride + r;
-    *p = complex_gain ? cmul(*p, reinterpret_cast<const cx<FD>*>(gain)[r % nbins]) : cscale(*p, gain[r % nbins]);
+    const FD* g = gain_row(op, t, nbins);
+    if (op.kind == OP_GAIN) *p = cscale(*p, g[k]);
+    else if (op.kind == OP_CGAIN) *p = cmul(*p, reinterpret_cast<const cx<FD>*>(g)[k]);
+    else if (op.kind >= OP_GATE) *p = op_pointwise(*p, op);
   }
 }
 
@@ -4101,10 +4191,11 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
     const size_t ch = r / a.n, t = r - ch * a.n;
     const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
     FD part = (FD)0;
+    const FD* grow = OPS ? gain_row(a.op, t, a.nbins) : nullptr;
 #pragma unroll 4
     for (unsigned k = lane; k < a.nbins; k += kWave)
     {
-      part += synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins);
+      part += synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins, grow);
     }
     const FD sum = wave_sum(part);
     if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);
@@ -4149,6 +4240,9 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
     const size_t ch = g / ngroups_per_ch;
     const size_t r0 = (g - ch * ngroups_per_ch) * RW;
     const cx<FD>* base = a.in + ch * a.in_stride;
+    const FD* grow[NI];                                    // OPS: the gain vector of each row this lane stages
+#pragma unroll
+    for (int i = 0; i < NI; ++i) grow[i] = OPS ? gain_row(a.op, r0 + (size_t)(RPI * i + sub), a.nbins) : nullptr;
 
     auto fetch = [&](unsigned k0, cx<FD> (&v)[NI][BPL])
     {
@@ -4185,7 +4279,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
         for (int b = 0; b < BPL; ++b)
         {
           const unsigned k = k0 + (unsigned)seg * BPL + b;
-          tile[wib][RPI * i + sub][seg * BPL + b] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins);
+          tile[wib][RPI * i + sub][seg * BPL + b] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins, grow[i]);
         }
     };
 
@@ -4248,6 +4342,7 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
   const size_t r = (size_t)gridDim.x - 1 - blockIdx.x;       // last rows first (what the analysis wrote last is still in cache)
   const size_t ch = r / a.n, t = r - ch * a.n;
   const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
+  const FD* grow = OPS ? gain_row(a.op, t, a.nbins) : nullptr;
   const bool vec_ok = (BPL == 1) || ((a.nbins % 2 == 0) && (((uintptr_t)row & 15) == 0));
 
   FD sum = (FD)0;
@@ -4283,7 +4378,7 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
       {
         const unsigned kl = (unsigned)(i * kWave + lane) * BPL + b;
         const unsigned k = k0 + kl;
-        terms[kl] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins);
+        terms[kl] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins, grow);
       }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1267,22 +1267,27 @@ class Plan
   // synthesis tables and the call's operation, then one launch per overlap segment
   DevBuf<double> d_alpha, d_beta;
   bool coeff_ready = false, coeff_has_beta = false;
+  unsigned coeff_rows = 1;
   int coeff_kind = -1; long coeff_shift = 0;
   bool fold_coefficients(const SpectralOp<FD>& op)
   {
     coeff_ready = false;
     if (!opt_fold || nbins < 8) return true;
     // identity and shift depend on the plan only: folded once; a gain array may change between calls
+    if (!op_is_linear<FD>(op.kind)) return true;                                   // gate, power: the windowed rows are needed
     const bool has_array = op.kind == OP_GAIN || op.kind == OP_CGAIN;
+    const unsigned rows = has_array && op.rows > 1 ? op.rows : 1u;
+    if (rows > 65535u) return true;                                                // (grid.y) -- more gain vectors than that: two passes
     coeff_has_beta = !(latency == 1) || op.kind == OP_CGAIN;                     // im X enters through the synthesis twiddle or a complex gain
+    coeff_rows = rows;
     if (!has_array && coeff_kind == op.kind && coeff_shift == op.shift && d_alpha.p) { coeff_ready = true; return true; }
-    if (!d_alpha.reserve(nbins) || !d_beta.reserve(nbins)) return false;
+    if (!d_alpha.reserve((size_t)rows * nbins) || !d_beta.reserve((size_t)rows * nbins)) return false;
     const FD w = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // as ForwardArgs::wscale
     FD h0 = w, h1 = (FD)0, h2 = (FD)0;                                                   // taps of window_tap()
     if (window == WIN_HANN) { h0 = w + w; h1 = -w; }
     else if (window == WIN_HAMMING) { h0 = (FD)(0.54) * w; h1 = -((FD)(0.23) * w); }
     else if (window == WIN_BLACKMAN) { h0 = (FD)(0.42) * w; h1 = -((FD)(0.25) * w); h2 = (FD)(0.04) * w; }
-    hipLaunchKernelGGL((fold_coeff_kernel<FD>), dim3((unsigned)((nbins + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((fold_coeff_kernel<FD>), dim3((unsigned)((nbins + kBlock - 1) / kBlock), rows), dim3(kBlock), 0, stream,
                        d_alpha.p, d_beta.p, op, (const fdx*)d_syn.p, (unsigned)nbins, latency == 1 ? 1 : 0, h0, h1, h2);
     SDFT_TRY(hipGetLastError());
     coeff_kind = op.kind; coeff_shift = op.shift;
@@ -1309,6 +1314,7 @@ class Plan
   {
     ProcArgs<TD, FD> pz;
     pz.y = fz.y; pz.y_stride = fz.y_stride; pz.alpha = d_alpha.p; pz.beta = d_beta.p; pz.sweight = fz.sweight;
+    pz.rows = coeff_rows; pz.hop = fz.op.hop;
     const long waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
     const long slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
     const unsigned threads = (unsigned)(waves * kWave);
@@ -1387,7 +1393,7 @@ class Plan
     InverseArgs<TD, FD> ia;
     ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
     ia.n = n; ia.nbins = (unsigned)nbins; ia.channels = (unsigned)channels; ia.sweight = tab.sweight;
-    ia.op.kind = OP_IDENTITY; ia.op.gain = nullptr; ia.op.shift = 0;
+    ia.op = SpectralOp<FD>{}; ia.op.kind = OP_IDENTITY; ia.op.rows = 1;
     ia.done.flag = nullptr; ia.done.count = nullptr; ia.done.seq = 0; ia.done.total = 0;
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;
@@ -1743,8 +1749,11 @@ class Plan
   {
     if (n == 0) return true;
     if (!bind()) return false;
-    if (op_kind < OP_IDENTITY || op_kind > OP_CGAIN) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
-    if ((op_kind != OP_IDENTITY) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
+    // public operation numbers (enum sdft_hip_op): 0 identity, 1 gain, 2 shift, 3 cgain, 4 gain_rows, 5 cgain_rows, 6 gate, 7 power
+    const int op_public = op_kind;
+    if (op_public < 0 || op_public > 7) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
+    if ((op_public != 0) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
+    op_kind = op_public == 4 ? OP_GAIN : op_public == 5 ? OP_CGAIN : op_public == 6 ? OP_GATE : op_public == 7 ? OP_POWER : op_public;
     if (op_kind == OP_SHIFT && dfts) { set_error("sdft_hip_process_n", "a copy of the spectrum is not available with the shift operation"); return false; }
     const bool yd = on_device(y);
     if (nbins == 0)
@@ -1753,20 +1762,33 @@ class Plan
       return finish();
     }
     if (dfts && !on_device(dfts)) { set_error("sdft_hip_process_n", "dfts must be device memory (or NULL)"); return false; }
-    SpectralOp<FD> op; op.kind = op_kind; op.gain = nullptr; op.shift = 0;
+    SpectralOp<FD> op{}; op.kind = op_kind; op.gain = nullptr; op.shift = 0; op.rows = 1; op.hop = 0; op.t0 = 0;
     if (op_kind == OP_GAIN || op_kind == OP_CGAIN)
     {
       const FD* g = static_cast<const FD*>(params);
+      size_t rows = 1;
+      if (op_public >= 4)
+      {
+        // time-varying gains: { gains, rows, hop } (sdft_hip_gain_rows_t)
+        struct table_t { const void* gains; size_t rows, hop; };
+        const table_t* tb = static_cast<const table_t*>(params);
+        if (!tb->gains || tb->rows == 0 || (tb->rows > 1 && tb->hop == 0)) { set_error("sdft_hip_process_n", "gain table: gains, rows >= 1 and hop >= 1 are required"); return false; }
+        if (tb->rows > 0xffffffffull) { set_error("sdft_hip_process_n", "gain table: too many rows"); return false; }
+        g = static_cast<const FD*>(tb->gains); rows = tb->rows; op.rows = (unsigned)rows; op.hop = tb->hop;
+      }
       const size_t per_bin = op_kind == OP_CGAIN ? 2 : 1;          // real factors, or (re, im) pairs
       if (!on_device(g))
       {
-        if (!d_gain.reserve(nbins * 2)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, nbins * per_bin * sizeof(FD), hipMemcpyHostToDevice, stream));
+        if (!d_gain.reserve(rows * nbins * 2)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, rows * nbins * per_bin * sizeof(FD), hipMemcpyHostToDevice, stream));
         g = d_gain.p;
       }
       op.gain = g;
     }
     else if (op_kind == OP_SHIFT) op.shift = *static_cast<const long*>(params);
+    else if (op_kind == OP_GATE || op_kind == OP_POWER) { const FD* q = static_cast<const FD*>(params); op.p0 = q[0]; op.p1 = q[1]; }   // host memory
+    const bool linear = op_is_linear<FD>(op_kind);
+    const bool one_vector = op.rows <= 1;
 
     // samples: device pointers as they are, host pointers staged (4 bytes per sample each way)
     const bool xd = on_device(x);
@@ -1789,7 +1811,8 @@ class Plan
     const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
     // calls of one time chunk: the folded form in one launch (process_hop_kernel) unless the reference's order
     // is wanted -- then the hop kernel + row synthesis pair below, which is bit-identical
-    const bool one_chunk_folded = chunks == 1 && n <= (size_t)kHopMax && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel;
+    const bool one_chunk_folded = chunks == 1 && n <= (size_t)kHopMax && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel &&
+                                  linear && one_vector;
     if (one_chunk_folded)
     {
       if (!fold_coefficients(op)) return false;
@@ -1800,8 +1823,8 @@ class Plan
     }
     // the folded form carries up to four bins per lane whatever the bin type is (N <= 4096); the forms that keep the
     // windowed rows in LDS stop at two slots of the row-group kernel (N <= 2048 double / 4096 float)
-    else if ((fuse_ok() || (!wants_reference_order() && !dfts && opt_fold && nbins >= 8 && nbins <= (size_t)4 * kWave * kRowWavesMax))
-             && chunks > 1 && !walk_loses)
+    else if ((fuse_ok() || (linear && op.rows <= 65535u && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && nbins <= (size_t)4 * kWave * kRowWavesMax))
+             && (chunks > 1 || n > (size_t)kHopMax) && !walk_loses)       // (many channels: one chunk per channel, however long)
     {
       FuseArgs<TD, FD> fz;
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
@@ -1831,17 +1854,19 @@ class Plan
           (void)hipGetLastError();
         }
       }
-      if (channels > 1 && !dfts) seg = n;                    // batched layout: channel stride = n rows (workspace holds the call)
+      // (batched plans take segments too: the workspace's channel stride is the segment, mstride below)
       if (!dfts && !d_stage_fdx.reserve(row_elems * seg)) return false;
       last_process_path = (chunks == 1) ? 2 : 3;
+      last_fused_exact = 0; last_fused_fold = 0;
       ok = true;
       for (size_t t = 0; t < n && ok; t += seg)
       {
         const size_t m = std::min(seg, n - t);
         fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
         const size_t mstride = dfts ? n * nbins : m * nbins;
-        ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &op);
-        if (ok && (op_kind == OP_GAIN || op_kind == OP_CGAIN) && dfts) ok = scale_rows(mat, mstride, m, op.gain, op_kind == OP_CGAIN);
+        SpectralOp<FD> ops = op; ops.t0 = t;                  // gain vectors count from the start of the call
+        ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &ops);
+        if (ok && (op_kind == OP_GAIN || op_kind == OP_CGAIN || op_kind >= OP_GATE) && dfts) ok = scale_rows(mat, mstride, m, ops);
       }
     }
     if (!ok) return false;
@@ -1854,11 +1879,11 @@ class Plan
   }
 
   // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)
-  bool scale_rows(fdx* mat, size_t stride, size_t rows, const FD* gain, bool complex_gain)
+  bool scale_rows(fdx* mat, size_t stride, size_t rows, const SpectralOp<FD>& op)
   {
     const size_t total = channels * rows * nbins;
     const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
-    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, gain, complex_gain ? 1 : 0);
+    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, op);
     SDFT_TRY(hipGetLastError());
     return true;
   }

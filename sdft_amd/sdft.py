@@ -201,18 +201,40 @@ class SDFT:
         return out
 
 
-    def process(self, x, op="identity", gain=None, shift=0, out=None, dfts=None):
+    def process(self, x, op="identity", gain=None, shift=0, out=None, dfts=None, hop=0, threshold=0.0, floor=0.0,
+                exponent=1.0, scale=1.0):
         """Fused analysis -> spectral operation -> synthesis (``sdft_hip_process_n``): returns the
         processed samples; the DFT matrix is not materialised unless ``dfts`` (a CUDA tensor of shape
         (n, dftsize) [(channels, n, dftsize)]) asks for a copy of the processed spectrum.
 
-        ``op``: "identity", "gain" (``gain`` = real array of dftsize factors), "cgain" (``gain`` = complex array)
-        or "shift" (``shift`` bins).
+        ``op``: "identity", "gain" (``gain`` = real array of dftsize factors), "cgain" (``gain`` = complex array),
+        "shift" (``shift`` bins), "gain_rows" / "cgain_rows" (``gain`` = (rows, dftsize) array, row r for the call's samples
+        [r*hop, (r+1)*hop), the last row for the rest), "gate" (``threshold``, ``floor``) or "power" (``exponent``, ``scale``).
         """
         kind = OPS[op] if isinstance(op, str) else int(op)
         params = None
         keep = None
-        if kind in (OPS["gain"], OPS["cgain"]):
+        if kind in (OPS["gain_rows"], OPS["cgain_rows"]):
+            gdt = self.fd if kind == OPS["gain_rows"] else self.fdx
+            if _is_tensor(gain):
+                assert gain.dim() == 2 and gain.shape[1] == self.dftsize
+                self._check_tensor(gain, "gain", gdt)
+                gptr, rows = gain.data_ptr(), int(gain.shape[0])
+                keep_rows = gain
+            else:
+                keep_rows = np.ascontiguousarray(gain, dtype=gdt)
+                assert keep_rows.ndim == 2 and keep_rows.shape[1] == self.dftsize
+                gptr, rows = keep_rows.ctypes.data, int(keep_rows.shape[0])
+
+            class _Table(C.Structure):
+                _fields_ = [("gains", C.c_void_p), ("rows", C.c_size_t), ("hop", C.c_size_t)]
+            keep = (_Table(gptr, rows, int(hop)), keep_rows)
+            params = C.cast(C.byref(keep[0]), C.c_void_p)
+        elif kind in (OPS["gate"], OPS["power"]):
+            vals = (threshold, floor) if kind == OPS["gate"] else (exponent, scale)
+            keep = np.asarray(vals, dtype=self.fd)
+            params = C.c_void_p(keep.ctypes.data)
+        elif kind in (OPS["gain"], OPS["cgain"]):
             gdt = self.fd if kind == OPS["gain"] else self.fdx
             if _is_tensor(gain):
                 self._check_tensor(gain, "gain", gdt, (self.dftsize,))

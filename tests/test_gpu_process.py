@@ -290,3 +290,141 @@ def test_process_argument_errors():
     assert float(y.min()) == 7.0                                  # outputs untouched
     assert api.process_n(plan, 0, None, None, 0, None, None) == 0
     api.free(plan)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: gains that change with time, and operations that are not linear in the spectrum
+# ---------------------------------------------------------------------------------------------
+def rows_reference(ref, x, gains, hop, complex_gain):
+    d = ref.sdft(x)
+    r = np.minimum(np.arange(d.shape[0]) // hop, gains.shape[0] - 1)
+    out = np.empty_like(d)
+    if complex_gain:
+        g = gains[r]
+        out.real = d.real * g.real - d.imag * g.imag
+        out.imag = d.real * g.imag + d.imag * g.real
+    else:
+        out = (d * gains[r].astype(d.real.dtype)).astype(d.dtype)
+    return ref.isdft(out), out
+
+
+@pytest.mark.parametrize("combo,m,n,hop", [("f32f64", 1024, 20000, 512), ("f32f64", 256, 9000, 100), ("f32f32", 512, 12000, 1000),
+                                           ("f64f64", 128, 6000, 37), ("f32f64", 2048, 9000, 4096), ("f32f64", 3000, 7000, 1024)])
+@pytest.mark.parametrize("op", ["gain_rows", "cgain_rows"])
+def test_gains_that_change_with_time(combo, m, n, hop, op):
+    """A host of the reference that recomputes its mask every hop (README.md:42-47 leaves the loop over the matrix to it):
+    gains[rows][N], row r for the samples [r*hop, (r+1)*hop), the last row for the rest -- through the folded kernel
+    (coefficient vectors reloaded at the row changes), the reference's summation order, the copy of the spectrum,
+    the two-pass path, a call of one time chunk, a second call (rows count from the start of each call)."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    rng = np.random.default_rng(7)
+    rows = (n + hop - 1) // hop - 1                                  # one row short: the last row serves the tail
+    gains = rng.uniform(0.2, 1.5, size=(max(rows, 1), m)).astype(fd)
+    if op == "cgain_rows":
+        gains = (gains * np.exp(1j * rng.uniform(-1, 1, size=gains.shape))).astype(fdx)
+    x = noise(n, seed=3, dtype=td)
+    x2 = noise(300, seed=4, dtype=td)
+    tol = TOL[combo[3:]]
+    for opts in ({}, {"fused_exact": 1}, {"fold": 0}, {"rows_kernel": 0, "fold": 0}):
+        if m > 2048 and opts.get("fused_exact"):
+            continue
+        ref = O.best(m, "hann", 1.0, combo)
+        want, dwant = rows_reference(ref, x, gains, hop, op == "cgain_rows")
+        with make(m, "hann", 1.0, combo, **opts) as p:
+            got = p.process(torch.from_numpy(x).cuda(), op, gain=torch.from_numpy(gains).cuda(), hop=hop).cpu().numpy()
+            assert rel_err(got, want) <= tol, (combo, m, hop, opts, rel_err(got, want))
+            if opts.get("fused_exact") and combo.endswith("f32"):
+                assert np.array_equal(got, want)
+            # a call of one time chunk with three rows of 100 samples
+            want2, _ = rows_reference(ref, x2, gains[:3], 100, op == "cgain_rows")
+            got2 = p.process(x2, op, gain=gains[:3], hop=100)
+            assert rel_err(got2, want2) <= tol, (combo, m, hop, opts, "hop-sized", rel_err(got2, want2))
+    # copy of the processed spectrum
+    if m <= 2048:
+        ref = O.best(m, "hann", 1.0, combo)
+        want, dwant = rows_reference(ref, x, gains, hop, op == "cgain_rows")
+        with make(m, "hann", 1.0, combo) as p:
+            dd = torch.empty((n, m), dtype=getattr(torch, np.dtype(fdx).name), device="cuda")
+            got = p.process(torch.from_numpy(x).cuda(), op, gain=gains, hop=hop, dfts=dd).cpu().numpy()
+            assert rel_err(got, want) <= tol and rel_err(dd.cpu().numpy(), dwant) <= tol
+
+
+def rel_err(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    scale = float(np.abs(b).max())
+    return float(np.abs(a - b).max()) / scale if scale else float(np.abs(a).max())
+
+
+def nonlinear_reference(ref, x, op, p0, p1):
+    d = ref.sdft(x)
+    fd = d.real.dtype
+    mag2 = d.real * d.real + d.imag * d.imag                      # FD arithmetic, as the kernels do it
+    if op == "gate":
+        thr2 = fd.type(p0) * fd.type(p0)
+        f = np.where(mag2 < thr2, fd.type(p1), fd.type(1))
+        out = (d * f).astype(d.dtype)
+        out = np.where(mag2 < thr2, out, d)
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = fd.type(p1) * np.power(mag2, (fd.type(p0) - fd.type(1)) * fd.type(0.5))
+        f = np.where(mag2 > 0, f, 0).astype(fd)
+        out = (d * f).astype(d.dtype)
+    return ref.isdft(out), out
+
+
+@pytest.mark.parametrize("combo,m", [("f32f64", 1024), ("f32f32", 512), ("f32f64", 2048), ("f64f64", 100), ("f32f32", 4096), ("f32f64", 2500)])
+@pytest.mark.parametrize("op,p0,p1", [("gate", 0.02, 0.0), ("gate", 0.05, 0.25), ("power", 0.6, 1.3), ("power", 1.5, 0.8)])
+def test_operations_that_are_not_linear(combo, m, op, p0, p1):
+    """Spectral gate (|X| < threshold -> X * floor) and magnitude power law (|X'| = scale * |X|^p, phase kept) on the
+    windowed spectrum inside the row-group kernel; two passes where the row does not fit; copy of the spectrum."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    n = 12000 if m <= 2048 else 6000
+    x = (noise(n, seed=11, dtype=td) * 0.5 + sine_sweep(n, dtype=td) * 0.5).astype(td)
+    tol = TOL[combo[3:]]
+    kw = dict(threshold=p0, floor=p1) if op == "gate" else dict(exponent=p0, scale=p1)
+    for opts in ({}, {"fused_exact": 1}):
+        ref = O.best(m, "hamming", 1.0, combo)
+        want, dwant = nonlinear_reference(ref, x, op, p0, p1)
+        with make(m, "hamming", 1.0, combo, **opts) as p:
+            got = p.process(torch.from_numpy(x).cuda(), op, **kw).cpu().numpy()
+            assert p.get_option("last_fused_fold") == 0
+            assert rel_err(got, want) <= tol, (combo, m, op, opts, rel_err(got, want))
+            if op == "gate" and opts.get("fused_exact") and combo.endswith("f32") and m <= 4096:
+                assert np.array_equal(got, want)                  # same bins gated, same sums
+            hop = x[:200] * 0.7
+            wh, _ = nonlinear_reference(ref, hop, op, p0, p1)
+            assert rel_err(p.process(hop, op, **kw), wh) <= tol
+    if m <= 2048:
+        ref = O.best(m, "hamming", 1.0, combo)
+        want, dwant = nonlinear_reference(ref, x, op, p0, p1)
+        with make(m, "hamming", 1.0, combo) as p:
+            dd = torch.empty((n, m), dtype=getattr(torch, np.dtype(fdx).name), device="cuda")
+            got = p.process(torch.from_numpy(x).cuda(), op, dfts=dd, **kw).cpu().numpy()
+            assert rel_err(got, want) <= tol and rel_err(dd.cpu().numpy(), dwant) <= tol
+
+
+def test_many_channels_long_call_takes_the_fused_kernel():
+    """512 channels leave one time chunk per channel however long the call is: still the fused kernel,
+    never the (channels, n, N) workspace."""
+    import torch
+    C, m, n = 512, 64, 1500
+    x = np.stack([noise(n, seed=200 + c) for c in range(C)])
+    gain = np.linspace(1.0, 0.3, m)
+    with make(m, "hann", 1.0, "f32f64", C) as p:
+        got = p.process(torch.from_numpy(x).cuda(), "gain", gain=gain).cpu().numpy()
+        assert p.get_option("last_process_path") == 1 and p.get_option("last_chunks") == 1
+        for c in (0, 17, 255, 511):
+            ref = O.best(m, "hann", 1.0, "f32f64")
+            want, _ = reference(ref, x[c], "gain", gain, 0)
+            assert rel_err(got[c], want) <= 1e-6
+    # batched plans on the two-pass path run in segments of the workspace
+    C, m, n = 3, 96, 5000
+    x = np.stack([noise(n, seed=300 + c) for c in range(C)])
+    with make(m, "hann", 1.0, "f32f64", C, fold=0, rows_kernel=0, stage_bytes=C * m * 16 * 700) as p:
+        got = p.process(x, "identity")
+        assert p.get_option("last_process_path") == 3
+        for c in range(C):
+            ref = O.best(m, "hann", 1.0, "f32f64")
+            assert rel_err(got[c], ref.isdft(ref.sdft(x[c]))) <= 1e-6
