@@ -188,7 +188,46 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
     res["forward_kernel_us"] = round(pr["forward"][0] / max(pr["forward"][1], 1) * 1e3, 1)
     res["inverse_kernel_us"] = round(pr["inverse"][0] / max(pr["inverse"][1], 1) * 1e3, 1)
     p.close()
+    # the literal drop-in: malloc'ed x, buffer, y exactly as test.c:62-64 has them (numpy arrays = pageable host memory):
+    # default (copies through the runtime's pageable path) and with option host_register = 1 (the library maps the
+    # caller's buffers once and the kernels work on them over PCIe; for hosts that keep their buffers, like test.c)
+    xh = sine_sweep(total, dtype=td)
+    yh = np.zeros(total, dtype=td)
+    dh = np.zeros((hop, m), dtype=np.complex128 if combo[3:] == "f64" else np.complex64)
+    for label, reg in (("us_per_hop_host_pointers", 0), ("us_per_hop_host_pointers_registered", 1)):
+        p = SDFT(m, "hann", 1.0, combo, device=device)
+        p.set_option("host_register", reg)
+        w = 0.0
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for i in range(0, total, hop):
+                p.api.sdft_n(p._p, hop, C.c_void_p(xh.ctypes.data + i * isz), C.c_void_p(dh.ctypes.data))
+                p.api.isdft_n(p._p, hop, C.c_void_p(dh.ctypes.data), C.c_void_p(yh.ctypes.data + i * isz))
+            w = (time.perf_counter() - t0) / (total // hop)
+        res[label] = round(w * 1e6, 1)
+        p.close()
+    res["host_pointers_pcie_floor_us"] = round(2 * hop * m * dh.itemsize / 55e9 * 1e6, 1)      # the matrix out and back in at 55 GB/s
     return res
+
+
+def cpu_hop_baseline(np, sine_sweep, combo, td, m=1000, hop=100, total=2000):
+    """The reference's own driver loop (test/test.c:69-83) on one host core: microseconds per hop."""
+    from oracle import oracle as O
+    if not O.have_port(combo):
+        O.build(ref=True)
+    td_, fd, fdx = O.combo_types(combo)
+    plan = O.best(m, "hann", 1.0, combo)
+    x = sine_sweep(total, dtype=td)
+    buf = np.zeros((hop, m), dtype=fdx)
+    best = float("inf")
+    for rep in range(2):
+        plan.reset()
+        t0 = time.perf_counter()
+        for i in range(0, total, hop):
+            plan.sdft(x[i:i + hop], buf)
+            plan.isdft(buf)
+        best = min(best, (time.perf_counter() - t0) / (total // hop))
+    return {"us_per_hop": round(best * 1e6, 1), "kind": plan.kind, "cores": 1, "sample": f"{total // hop} hops of {hop} samples, dftsize {m}, hann, {combo}"}
 
 
 def main():
@@ -429,6 +468,8 @@ def main():
         if workload == "single" and out.numel() >= 48000 * m:
             result["north_star_n48000"] = north_star_shape(torch, np, SDFT, sine_sweep, out, m, window, combo, esz, td, local_rank)
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)
+        if not args.no_cpu_baseline:
+            result["hop100_m1000"]["cpu_reference"] = cpu_hop_baseline(np, sine_sweep, combo, td)
 
         # PCIe-inclusive host-pointer path (never `value`)
         npci = min(n, 65536)

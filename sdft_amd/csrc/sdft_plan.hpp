@@ -252,6 +252,7 @@ class Plan
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
     if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
+    forget_host_buffers();
     if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
     d_ready.release();
     d_done_count.release();
@@ -1464,10 +1465,11 @@ class Plan
       {
         if (*f == flag_seq)
         {
-          // the word says nothing about faults: ask the stream once (not ready yet is the normal answer)
-          const hipError_t e = hipStreamQuery(stream);
-          if (e != hipSuccess && e != hipErrorNotReady) { set_error("hipStreamQuery", hipGetErrorString(e)); return false; }
-          if (e == hipErrorNotReady) (void)hipGetLastError();
+          // (the word says nothing about faults; a query of the stream here costs 5 us per hop -- measured 35 -> 46 us
+          // for the two reference calls -- so a fault surfaces at the next call that touches the stream, as it does
+          // for asynchronous calls)
+          const hipError_t e = hipPeekAtLastError();
+          if (e != hipSuccess) { set_error("completion word", hipGetErrorString(e)); (void)hipGetLastError(); return false; }
           return true;
         }
         if ((spins & 1023u) == 0 && clock::now() - t0 > std::chrono::milliseconds(50)) break;
@@ -1514,6 +1516,67 @@ class Plan
     return dev;
   }
 
+  // ---- host buffers, mapped in place --------------------------------------------------------------------------
+  // A host of the reference hands malloc'ed buffers to every call and reuses them hop after hop
+  // (/root/reference/test/test.c:62-83).  Copying through the runtime's pageable path costs such a hop-sized call more
+  // than its kernels (round 1: 191 us for a 1.6 MB hop); registering the caller's buffer once (hipHostRegister: the
+  // pages are pinned and mapped, the driver follows the mapping with MMU notifiers) lets the kernels read and write it
+  // over PCIe directly -- no staging copy, one synchronisation.  Buffers of 1 MiB and more only (smaller ones share
+  // pages with their heap neighbours), whole pages, at most 8 ranges that never overlap; anything the runtime refuses
+  // falls back to the staged path.  Option "host_register" = 1 turns it on, "host_register_max" bounds the
+  // bytes of one buffer (default 256 MiB: longer calls run at PCIe speed through the staged path anyway).
+  static constexpr size_t kSmallHostBytes = (size_t)64 << 10;
+  static constexpr size_t kHostRegisterMin = (size_t)1 << 20;       // smaller buffers share pages with their heap neighbours: staged
+  // OFF by default: a registration dies with the mapping it was made on.  A host that frees a buffer and gets the same
+  // address back from its allocator (numpy does, every call) would make a remembered registration fault the GPU
+  // (measured: "Memory access fault" on the second call) -- the driver does not re-attach it.  A C host that allocates
+  // its buffers once, like the reference's driver, sets option "host_register" = 1.
+  long opt_host_register = 0;
+  size_t opt_host_register_max = (size_t)256 << 20;
+  // registered page ranges [lo, hi) never overlap each other: a buffer inside a registered range uses that registration
+  // (two registrations sharing a page would lose it when the first of them is dropped)
+  struct HostReg { uintptr_t lo, hi; char* dev; unsigned long long used; bool owned; };
+  HostReg host_regs[8] = {};
+  unsigned long long host_reg_clock = 0;
+  long host_reg_hits = 0, host_reg_misses = 0;
+  void drop_host(HostReg& e)
+  {
+    if (e.hi && e.owned) { (void)hipHostUnregister(reinterpret_cast<void*>(e.lo)); (void)hipGetLastError(); }
+    e = HostReg{};
+  }
+  void forget_host_buffers() { for (HostReg& e : host_regs) drop_host(e); }
+  // device-side address of a host buffer of `bytes` bytes, or nullptr (not used / not possible: take the staged path)
+  void* map_host(const void* p, size_t bytes)
+  {
+    if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > opt_host_register_max) return nullptr;
+    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p);
+    const uintptr_t lo = a & ~(page - 1), hi = (a + bytes + page - 1) & ~(page - 1);
+    for (HostReg& e : host_regs)
+      if (e.hi && lo >= e.lo && hi <= e.hi) { e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.lo); }
+    // anything that overlaps without covering goes first (its pages would be shared)
+    for (HostReg& e : host_regs)
+      if (e.hi && lo < e.hi && e.lo < hi) drop_host(e);
+    HostReg* slot = &host_regs[0];
+    for (HostReg& e : host_regs) { if (!e.hi) { slot = &e; break; } if (e.used < slot->used) slot = &e; }
+    drop_host(*slot);
+    ++host_reg_misses;
+    void* dev = nullptr;
+    // memory the host pinned itself (hipHostMalloc, its own hipHostRegister) is mapped already
+    if (hipHostGetDevicePointer(&dev, const_cast<void*>(p), 0) == hipSuccess && dev)
+    {
+      *slot = HostReg{a, a + bytes, static_cast<char*>(dev), ++host_reg_clock, false};
+      return dev;
+    }
+    (void)hipGetLastError();
+    if (hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(&dev, reinterpret_cast<void*>(lo), 0) != hipSuccess || !dev)
+    {
+      (void)hipGetLastError(); (void)hipHostUnregister(reinterpret_cast<void*>(lo)); (void)hipGetLastError(); return nullptr;
+    }
+    *slot = HostReg{lo, hi, static_cast<char*>(dev), ++host_reg_clock, true};
+    return static_cast<char*>(dev) + (a - lo);
+  }
+
   // one strip per channel; per-channel async copies (no pitch limits, works for any size)
   bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, hipMemcpyKind kind)
   {
@@ -1539,6 +1602,28 @@ class Plan
       return ok && finish(channels * n * nbins);
     }
 
+    // host buffers mapped in place (see map_host): the kernels work on the caller's memory
+    {
+      // (a hop's samples are a different slice of the host's signal every call: a few hundred bytes go through the
+      // staging buffer, only buffers beyond 64 KiB are worth a registration)
+      const bool small_x = channels * n * sizeof(TD) <= kSmallHostBytes;
+      fdx* om = od ? dfts : static_cast<fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
+      const TD* xm = xd ? x : ((x_class == 0 || small_x) ? nullptr : static_cast<const TD*>(map_host(x, channels * n * sizeof(TD))));
+      if (om && !xm && !xd && small_x)
+      {
+        if (!d_stage_td.reserve(channels * n)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, channels * n * sizeof(TD), hipMemcpyHostToDevice, stream));
+        xm = d_stage_td.p;
+      }
+      if (xm && om)
+      {
+        const bool ok = forward_device(n, xm, n, om, n * nbins, nullptr);
+        const bool saved = async; async = false;           // host memory: complete on return, through the stream
+        const bool done = ok && finish(channels * n * nbins);
+        async = saved;
+        return done;
+      }
+    }
     // staged path (host pointers): time segments so that the staging matrix stays bounded;
     // the stream state carries over from segment to segment exactly like hop-wise calls do
     const size_t row_bytes = channels * nbins * sizeof(fdx);
@@ -1640,6 +1725,25 @@ class Plan
       const bool ok = inverse_device(n, dfts, n * nbins, nullptr, y, n);
       flag_wanted = false;
       return ok && finish(channels * n * nbins);
+    }
+    {
+      const bool small_y = channels * n * sizeof(TD) <= kSmallHostBytes;
+      const fdx* im = id ? dfts : static_cast<const fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
+      TD* ym = yd ? y : (small_y ? nullptr : static_cast<TD*>(map_host(y, channels * n * sizeof(TD))));
+      if (im && !ym && !yd && small_y) { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; }
+      if (im && ym)
+      {
+        bool ok = inverse_device(n, im, n * nbins, nullptr, ym, n);
+        if (ok && ym == d_stage_td.p && !yd)
+        {
+          const hipError_t e = hipMemcpyAsync(y, ym, channels * n * sizeof(TD), hipMemcpyDeviceToHost, stream);
+          if (e != hipSuccess) { set_error("hipMemcpyAsync", hipGetErrorString(e)); ok = false; }
+        }
+        const bool saved = async; async = false;
+        const bool done = ok && finish(channels * n * nbins);
+        async = saved;
+        return done;
+      }
     }
     const size_t row_bytes = channels * nbins * sizeof(fdx);
     size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));

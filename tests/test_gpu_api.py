@@ -394,3 +394,53 @@ def test_ring_timeout_is_reported_and_the_call_recovers():
         assert p.api.synchronize(p._p) != 0
         err = p.api.last_error(); p.api.lib.sdft_hip_clear_error()
         assert err and "asynchronous" in err, err
+
+
+def test_host_buffers_mapped_in_place():
+    """The reference's driver hands malloc'ed buffers to every call and reuses them hop after hop (test/test.c:62-83): the
+    library registers such a buffer once and lets the kernels work on it over PCIe (option host_register = 1; off by
+    default because a registration does not survive the host freeing the buffer and getting the address back).
+    Same bits as the staged path; larger buffers, small ones (staged), memory pinned by the host itself."""
+    import ctypes as C
+    import torch
+    m, hop, total = 1000, 100, 2000                               # 1.6 MB per hop: the reference's own test shape
+    x = noise(total, seed=21)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    from sdft_amd.sdft import SDFT
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        assert p.get_option("host_register") == 0
+        p.set_option("host_register", 1)
+        buf = np.zeros((hop, m), dtype=np.complex128)            # one buffer for every hop, as the reference's driver has it
+        y = np.zeros(total, dtype=np.float32)
+        for i in range(0, total, hop):
+            p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 4 * i), C.c_void_p(buf.ctypes.data))
+            want = ref.sdft(x[i:i + hop])
+            assert np.array_equal(buf, want)
+            buf *= 0.5                                          # the host's own loop over the matrix
+            p.api.isdft_n(p._p, hop, C.c_void_p(buf.ctypes.data), C.c_void_p(y.ctypes.data + 4 * i))
+            assert np.array_equal(y[i:i + hop], ref.isdft(buf))
+        assert p.get_option("host_register_misses") == 1 and p.get_option("host_register_hits") >= 2 * (total // hop) - 1
+        # a longer call on a new, larger buffer; then the first buffer again
+        x2 = noise(3000, seed=22)
+        big = np.zeros((x2.size, m), dtype=np.complex128)
+        p.api.sdft_n(p._p, x2.size, C.c_void_p(x2.ctypes.data), C.c_void_p(big.ctypes.data))
+        assert rel(big, ref.sdft(x2)) <= 1e-11
+        y2 = np.zeros(x2.size, dtype=np.float32)
+        p.api.isdft_n(p._p, x2.size, C.c_void_p(big.ctypes.data), C.c_void_p(y2.ctypes.data))
+        assert np.array_equal(y2, ref.isdft(big))
+        # memory the host pinned itself
+        small = np.zeros((7, m), dtype=np.complex128)              # below 1 MiB: staged (heap neighbours share pages)
+        p.api.sdft_n(p._p, 7, C.c_void_p(x.ctypes.data), C.c_void_p(small.ctypes.data))
+        assert rel(small, ref.sdft(x[:7])) <= 1e-11               # (the 3000-sample call was chunk-parallel: no longer bit for bit)
+        pinned = torch.empty((hop, m), dtype=torch.complex128).pin_memory()
+        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data), C.c_void_p(pinned.data_ptr()))
+        assert rel(pinned.numpy(), ref.sdft(x[:hop])) <= 1e-11
+        # off: the staged path, same bits
+        p.set_option("host_register", 0)
+        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 400), C.c_void_p(buf.ctypes.data))
+        assert rel(buf, ref.sdft(x[100:200])) <= 1e-11
+        assert p.api.last_error() is None
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(float(np.abs(b).max()), 1e-300))
