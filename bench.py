@@ -100,14 +100,41 @@ def cpu_baseline(m, window, combo, n_cpu):
         os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
     except Exception:
         pass
-    return {
+    res = {
         "value": round(n_cpu / best / 1e6, 4),
         "unit": "Msamples/s",
         "cores": 1,
         "kind": plan.kind,
         "sample": f"sdft_sdft_n forward, n={n_cpu} of the sine sweep, m={m}, {window}, {combo}, 1 thread"
                   f"{' pinned' if pinned else ''}, output pre-touched, best of 5; host has {os.cpu_count()} cores",
+        "flags": "gcc -std=gnu99 -O2 -ffp-contract=off (the canonical oracle build, SURVEY.md 8c)",
     }
+    # second figure: the same code with -O3 -march=native, compiled on this machine: the genuine header
+    # when SDFT_REF_DIR points at a checkout of the reference, else the bit-identical restatement (the GPU box has none)
+    if combo == "f32f64":
+        try:
+            path, kind = O.build_native(combo)
+            nat = (O.Reference if kind == "reference" else O.Port)(m, window, 1.0, combo, lib_path=path)
+            try:
+                os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+            except Exception:
+                pass
+            nbest = float("inf")
+            for _ in range(3):
+                nat.reset()
+                t0 = time.perf_counter()
+                nat.sdft(x, out)
+                nbest = min(nbest, time.perf_counter() - t0)
+            try:
+                os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+            except Exception:
+                pass
+            res["o3_march_native"] = {"value": round(n_cpu / nbest / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                                      "flags": "gcc -std=gnu99 -O3 -march=native -ffp-contract=off, built on this host",
+                                      "note": None if kind == "reference" else "reference sources are not on this machine (SDFT_REF_DIR unset): the restatement stands in"}
+        except Exception as e:                                   # no compiler on the host: say so
+            res["o3_march_native"] = {"value": None, "note": f"not built: {e}"[:200]}
+    return res
 
 
 def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz, td, device):
@@ -141,6 +168,8 @@ def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz
             k48 = pr["forward"][0] / max(pr["forward"][1], 1) * 1e-3
             res["forward_kernel_gbs"] = round(b48 / k48 / 1e9, 1)
             res["prepass_us"] = round((pr["delta"][0] + pr["carry"][0]) / max(pr["forward"][1], 1) * 1e3, 1)
+            res["launches_per_call"] = 1 if p.get_option("last_self") == 1 else 3
+            res["self_carried_chunks"] = bool(p.get_option("last_self") == 1)
         p.close()
     res["path"] = "default: pointers classified by the library (cached per buffer), no options set"
     res["note"] = "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache"
@@ -228,6 +257,34 @@ def cpu_hop_baseline(np, sine_sweep, combo, td, m=1000, hop=100, total=2000):
             plan.isdft(buf)
         best = min(best, (time.perf_counter() - t0) / (total // hop))
     return {"us_per_hop": round(best * 1e6, 1), "kind": plan.kind, "cores": 1, "sample": f"{total // hop} hops of {hop} samples, dftsize {m}, hann, {combo}"}
+
+
+def reference_bench_shape(torch, np, SDFT, device, with_cpu=True):
+    """/root/reference/cpp/examples/bench.cpp:15-48 (rust/examples/bench.rs): dftsize 1000, 44100 zero samples, TD = FD =
+    double, Hann, 10 runs, microseconds per sdft / isdft call -- on device pointers, and the reference on one host core."""
+    m, n, runs = 1000, 44100, 10
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d = torch.empty((n, m), dtype=torch.complex128, device="cuda")
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    p = SDFT(m, "hann", 1.0, "f64f64", device=device)
+    fw, iv = [], []
+    for r in range(runs + 2):
+        t0 = time.perf_counter(); p.sdft(x, d); t1 = time.perf_counter(); p.isdft(d, y); t2 = time.perf_counter()
+        if r >= 2:
+            fw.append(t1 - t0); iv.append(t2 - t1)
+    p.close()
+    res = {"shape": "dftsize 1000, 44100 samples of zeros, TD = FD = double, hann, 10 runs (cpp/examples/bench.cpp:15-48)",
+           "gpu_sdft_us": round(float(np.median(fw)) * 1e6, 1), "gpu_isdft_us": round(float(np.median(iv)) * 1e6, 1)}
+    if with_cpu:
+        from oracle import oracle as O
+        if not O.have_port("f64f64"):
+            O.build(ref=True)
+        ref = O.best(m, "hann", 1.0, "f64f64")
+        xh = np.zeros(n); dh = np.zeros((n, m), dtype=np.complex128); yh = np.zeros(n)
+        t0 = time.perf_counter(); ref.sdft(xh, dh); t1 = time.perf_counter(); ref.isdft(dh, yh); t2 = time.perf_counter()
+        res.update({"cpu_sdft_us": round((t1 - t0) * 1e6, 1), "cpu_isdft_us": round((t2 - t1) * 1e6, 1), "cpu_kind": ref.kind, "cpu_cores": 1,
+                    "cpu_runs": 1})
+    return res
 
 
 def main():
@@ -321,6 +378,19 @@ def main():
     units = float(count * n * args.steps)
     rate, secs = shard.job_throughput(units, elapsed, local_rank)
 
+    # the same step one at a time (SURVEY.md 8d asks for a median): wall clock around one synchronised call each, and the
+    # kernel's own HIP events launch by launch; outside the contract's timed region above
+    step_ms, kern_ms = [], []
+    for _ in range(min(args.steps, 20)):
+        sync()
+        ts = time.perf_counter()
+        plan.sdft(x, out)
+        sync()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        pf = plan.profile()["forward"]
+        if pf[1]:
+            kern_ms.append(pf[0] / pf[1])
+
     # second bracketed region, every rank: analysis + synthesis pairs (the metric string names both)
     y = plan.isdft(out)
     sync(); plan.profile()
@@ -349,8 +419,9 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
             t = json.load(fh)
-        if t.get("workload") == workload and t.get("n") == n and t.get("m") == m and t.get("channels") == count:
-            traffic = t.get("bytes_per_launch")
+        for entry in (t if isinstance(t, list) else [t]):
+            if entry.get("workload") == workload and entry.get("n") == n and entry.get("m") == m and entry.get("channels") == count:
+                traffic = entry.get("bytes_per_launch")
     except Exception:
         pass
 
@@ -366,6 +437,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(secs / args.steps * 1e3, 4),
+        "ms_per_step_median_one_at_a_time": round(float(np.median(step_ms)), 4) if step_ms else None,
         "ms_per_step_analysis_plus_synthesis": round(secs_rt / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
@@ -394,6 +466,7 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(f_avg_ms, 4),
+            "median_launch_ms": round(float(np.median(kern_ms)), 4) if kern_ms else None,
             "launches": f_calls,
             "prepass_ms_per_step": round(prepass_ms, 4),
             "synthesis_read_gbs": round(bytes_per_launch / (i_avg * 1e-3) / 1e9, 1) if i_avg > 0 else None,
@@ -442,6 +515,21 @@ def main():
             fp[label + "_msamples_s"] = round(count * n / wf / 1e6, 1)
             fp[label + "_ms"] = round(wf * 1e3, 3)
         plan.set_option("fused_exact", -1)
+        # round 3: gains that change every 512 samples (one launch: the folded coefficients of all gain vectors come from one
+        # small launch in front), and a spectral gate (not linear: the windowed rows in LDS, tree sum)
+        if count == 1:
+            rows_g = torch.rand(((n + 511) // 512, m), dtype=torch.float64 if esz == 16 else torch.float32, device="cuda") + 0.5
+            for label, kw in (("gain_rows_hop512", dict(op="gain_rows", gain=rows_g, hop=512)), ("gate", dict(op="gate", threshold=1e-3, floor=0.0))):
+                yf = plan.process(x, **kw)
+                sync()
+                tf = time.perf_counter()
+                for _ in range(5):
+                    plan.process(x, out=yf, **kw)
+                sync()
+                wf = (time.perf_counter() - tf) / 5
+                fp[label + "_msamples_s"] = round(count * n / wf / 1e6, 1)
+                fp[label + "_ms"] = round(wf * 1e3, 3)
+            del rows_g
         # the same call on HOST buffers (what a host of the reference has: malloc'ed samples in, samples out): 4 bytes per
         # sample each way over PCIe instead of the 16 KiB per sample of the matrix -- PCIe-inclusive, never `value`
         xh_f = xh if count > 1 else np.ascontiguousarray(xh)
@@ -470,6 +558,7 @@ def main():
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)
         if not args.no_cpu_baseline:
             result["hop100_m1000"]["cpu_reference"] = cpu_hop_baseline(np, sine_sweep, combo, td)
+        result["reference_bench_shape"] = reference_bench_shape(torch, np, SDFT, local_rank, with_cpu=not args.no_cpu_baseline)
 
         # PCIe-inclusive host-pointer path (never `value`)
         npci = min(n, 65536)

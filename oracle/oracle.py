@@ -53,6 +53,18 @@ def ref_path(combo: str) -> str:
     return os.path.join(HERE, "_ref", f"libsdft_ref_{combo}.so")
 
 
+def build_native(combo: str = "f32f64"):
+    """-O3 -march=native builds for bench.py's second CPU figure, made on the machine that runs it (the code does not
+    travel).  -> (path, kind) of the strongest one: the reference header when SDFT_REF_DIR points at a checkout, else the port."""
+    assert combo == "f32f64"
+    ref_dir = os.environ.get("SDFT_REF_DIR")
+    if ref_dir and os.path.exists(ref_dir + "/c/src/sdft/sdft.h"):
+        subprocess.run(["make", "-C", HERE, "-B", "native-ref"], check=True, capture_output=True)
+        return os.path.join(HERE, "_ref", f"libsdft_ref_native_{combo}.so"), "reference"
+    subprocess.run(["make", "-C", HERE, "-B", "native"], check=True, capture_output=True)
+    return os.path.join(HERE, "_build", f"liboracle_native_{combo}.so"), "port"
+
+
 def have_port(combo: str = "f32f64") -> bool:
     return os.path.exists(port_path(combo))
 
@@ -93,9 +105,9 @@ class Port(_Base):
 
     kind = "port"
 
-    def __init__(self, dftsize, window="hann", latency=1.0, combo="f32f64"):
+    def __init__(self, dftsize, window="hann", latency=1.0, combo="f32f64", lib_path=None):
         self._setup(combo, dftsize, window, latency)
-        lib = C.CDLL(port_path(combo))
+        lib = C.CDLL(lib_path or port_path(combo))
         lib.oracle_new.restype = C.c_void_p
         lib.oracle_new.argtypes = [C.c_size_t, C.c_int, C.c_double]
         for name in ("oracle_free", "oracle_reset"):
@@ -171,9 +183,9 @@ class Reference(_Base):
 
     kind = "reference"
 
-    def __init__(self, dftsize, window="hann", latency=1.0, combo="f32f64"):
+    def __init__(self, dftsize, window="hann", latency=1.0, combo="f32f64", lib_path=None):
         self._setup(combo, dftsize, window, latency)
-        lib = C.CDLL(ref_path(combo))
+        lib = C.CDLL(lib_path or ref_path(combo))
         lib.sdft_alloc_custom.restype = C.c_void_p
         lib.sdft_alloc_custom.argtypes = [C.c_size_t, C.c_int, C.c_double]
         for name in ("sdft_free", "sdft_reset"):

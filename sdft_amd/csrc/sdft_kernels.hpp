@@ -2129,30 +2129,54 @@ template <typename TD, typename FD> struct SelfArgs
 
 // cells[v] = sum of the differences (sdft.h:564, the subtraction in TD precision) of the samples t < t0 whose
 // cursor is v; whole workgroup, no barrier inside
-template <typename TD, typename FD>
+template <int CP, int QB, typename TD, typename FD>
 SDFT_D void self_fold(const SelfArgs<TD, FD>& sa, cx<FD>* cells, unsigned m, unsigned cursor0, size_t ch, size_t t0)
 {
+  // A thread owns up to CP cells (cursor values v, v + threads, ...); cell v collects the samples tv, tv + 2N, ... < t0.
+  // QB rows of all its cells are requested before the first is used -- CP*QB independent loads in flight, every one of
+  // them unconditional (an index past the fold is clamped, its value ignored): the compiler can count them and wait once.
+  // (CP*QB registers: 4 x 8 in the forward kernel, 2 x 4 in the fused one, which lives on 64 registers per lane)
   const TD* xs = sa.x + ch * sa.x_stride;
   const TD* hs = sa.hist_in + ch * (size_t)m;
-  for (unsigned v = threadIdx.x; v < m; v += blockDim.x)
+  const unsigned nthr = blockDim.x;
+  const size_t rows = (t0 + m - 1) / m;                    // t0 >= 1
+  for (unsigned v0 = threadIdx.x; v0 < m; v0 += CP * nthr)
   {
-    const size_t tv = (size_t)((v + m - cursor0) & (m - 1));          // first sample that arrives at cursor v (cursor0 < m)
-    FD sum = (FD)0;
-    if (tv < t0)
+    size_t tv[CP]; FD sum[CP]; TD prev[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
     {
-      TD prev = hs[tv];                                               // x[tv - 2N]
-      size_t t = tv;
-      for (; t + 7 * (size_t)m < t0; t += 8 * (size_t)m)               // eight independent loads in flight
-      {
-        TD cur[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = xs[t + (size_t)q * m];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const TD dd = cur[q] - prev; sum += (FD)dd; prev = cur[q]; }
-      }
-      for (; t < t0; t += m) { const TD cur = xs[t]; const TD dd = cur - prev; sum += (FD)dd; prev = cur; }
+      const unsigned v = v0 + (unsigned)c * nthr;
+      tv[c] = (size_t)(((v < m ? v : v0) + m - cursor0) & (m - 1));      // first sample that arrives at cursor v (cursor0 < m)
+      sum[c] = (FD)0;
+      prev[c] = hs[tv[c]];                                 // x[tv - 2N]
     }
-    cells[v] = cmake<FD>(sum, (FD)0);
+    for (size_t q = 0; q < rows; q += QB)
+    {
+      TD cur[CP][QB];
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+        {
+          const size_t t = tv[c] + (q + qq) * (size_t)m;
+          cur[c][qq] = xs[t < t0 ? t : t0 - 1];
+        }
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+        {
+          const size_t t = tv[c] + (q + qq) * (size_t)m;
+          if (t < t0) { const TD dd = cur[c][qq] - prev[c]; sum[c] += (FD)dd; prev[c] = cur[c][qq]; }   // TD precision (sdft.h:564)
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+    {
+      const unsigned v = v0 + (unsigned)c * nthr;
+      if (v < m) cells[v] = cmake<FD>(sum[c], (FD)0);
+    }
   }
 }
 
@@ -2197,7 +2221,7 @@ SDFT_D void lds_fft_dif(cx<FD>* x, unsigned log2m, const cx<FD>* __restrict__ w)
 
 // the whole prologue of a self-carried chunk: delay line for the next call (last chunk's workgroup), fold, FFT.
 // Returns true when cells[] holds the DFT (chunks that start at sample 0 need none).  Workgroup-uniform.
-template <typename TD, typename FD>
+template <int CP, int QB, typename TD, typename FD>
 SDFT_D bool self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<FD>* cells, unsigned chunk, size_t ch, size_t t0)
 {
   const unsigned m = 1u << sa.log2m;
@@ -2213,7 +2237,7 @@ SDFT_D bool self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<
     }
   }
   if (t0 == 0) return false;
-  self_fold(sa, cells, m, a.cursor0, ch, t0);
+  self_fold<CP, QB>(sa, cells, m, a.cursor0, ch, t0);
   __syncthreads();
   lds_fft_dif(cells, sa.log2m, a.wtab);
   return true;
@@ -3095,7 +3119,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // SELF: carry-in by fold + FFT of everything before this chunk (dynamic LDS: 2N cells)
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
   bool have_cells = false;
-  if constexpr (SELF) have_cells = self_carry(sa, a, cells, chunk, ch, t0);
+  if constexpr (SELF) have_cells = self_carry<4, 8>(sa, a, cells, chunk, ch, t0);
 
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
   BinState<FD> s[S][BPL];
@@ -3572,8 +3596,9 @@ constexpr int kProcRow = 72;             // row stride of the transpose tile: 64
 constexpr int kProcRing = SDFT_PROC_RING;             // groups whose per-wave sums are in flight (a ring of tables)
 constexpr int kProcSync = SDFT_PROC_RING / 2;         // groups per workgroup barrier (kProcRing >= 2 * kProcSync)
 
+// (one bin per lane: two 16-wave workgroups share a CU -- 64 registers per lane, asked for by name)
 template <typename TD, typename FD, int J, bool FUSED, bool HASB, bool SELF = false>
-__global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz, SelfArgs<TD, FD> sa)
+__global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_rows_kernel(ForwardArgs<FD> a, ProcArgs<TD, FD> pz, SelfArgs<TD, FD> sa)
 {
   constexpr int G = kProcGroup;
   constexpr int R = kProcRing, K = kProcSync;
@@ -3601,7 +3626,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void process_rows_kernel(Forw
   static_assert(!SELF || sizeof(tile) >= (size_t)4096 * sizeof(cx<FD>), "2N <= 4096 cells must fit the transpose tiles");
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(&tile[0][0]);
   bool have_cells = false;
-  if constexpr (SELF) have_cells = self_carry(sa, a, cells, chunk, ch, t0);
+  if constexpr (SELF) have_cells = self_carry<1, 8>(sa, a, cells, chunk, ch, t0);
 
   BinState<FD> s[J];
   AT al[J], be[J];

@@ -406,6 +406,8 @@ class Plan
       // (measured, N = 1024 f64: n = 1024 77 -> 31 us, 4096 77 -> 36, 12000 79 -> 53, 24000 95 -> 91)
       if (mid) want = std::max(1L, std::min((190L + (long)channels - 1) / (long)channels, (long)(n / 32)));
       else want = std::max(1L, std::min(want, (long)(n / (carry_mode == CARRY_EXACT ? 128 : 192))));
+      // (n = 48000: 250 chunks of 192 rows leave 6 CUs idle; 256 chunks of 188 rows were measured the same, 137.3 against
+      // 137.9 us per call, and 128 chunks of 376 rows 145 us: the call is bound by HBM, not by the CUs that feed it)
       len = (long)((n + want - 1) / want);
       len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
       if (carry_mode == CARRY_EXACT)
@@ -649,6 +651,9 @@ class Plan
 
     const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
+    // (the folded fused kernel and the row-group forward kernel have the self-carried form)
+    const bool folded_fuse = fuse && !wants_reference_order() && !fuse->store && opt_fold && coeff_ready;
+    const bool self_form = self_eligible(n, fuse != nullptr) && (fuse ? folded_fuse : use_rows);
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
@@ -660,13 +665,10 @@ class Plan
     // self-carried chunks: every workgroup derives its carry-in from the raw samples (fold + one FFT in LDS) and forms
     // its own differences -- the call is ONE launch.  Kernels that have the form: the row-group forward kernel and the
     // folded fused kernel, FD double, 2N a power of two of at most 4096 cells.
-    const bool folded_fuse = fuse && !wants_reference_order() && !fuse->store && opt_fold && coeff_ready;
     // (the fold of a chunk's past costs t0 / threads loads: hidden behind the other workgroups' row stores in the
     // analysis, which is bound by HBM -- n = 1e6: 2.885 -> 2.853 ms -- but not in the fused call, which is bound by
-    // instruction issue: n = 48000: 45.9 -> 42.3 us, n = 131072: 99 -> 117 us)
-    const size_t self_max = fuse ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
-    const bool self = sizeof(FD) == 8 && !exact && chunks > 1 && opt_self && (span & (span - 1)) == 0 && span >= 16 && span <= 4096 &&
-                      n <= self_max && (fuse ? folded_fuse : use_rows);
+    // instruction issue: n = 48000: 45.9 -> 42.3 us, n = 131072: 99 -> 117 us; hence self_eligible's limit for it)
+    const bool self = self_form && chunks > 1;
     last_self = self;
     if (self) return forward_self(n, x, x_stride, out, out_stride, chunks, len, fuse);
     // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
@@ -964,6 +966,14 @@ class Plan
     cursor = (cursor + n) % span;
     st_cur ^= 1;
     return true;
+  }
+
+  // what the self-carried form needs of the plan and the call (the kernel that has it is chosen by the caller)
+  bool self_eligible(size_t n, bool fused_call) const
+  {
+    const size_t span = 2 * nbins;
+    const size_t self_max = fused_call ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
+    return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && (span & (span - 1)) == 0 && span >= 16 && span <= 4096 && n <= self_max;
   }
 
   // ---- self-carried chunks: the whole chunk-parallel call in one launch (SelfArgs in sdft_kernels.hpp) ----

@@ -47,3 +47,74 @@ def test_single_rank_bench_line_contract():
     assert res["n_gpus"] == 1 and res["vs_baseline"] is None and res["dtype"] == "f64" and res["data"] == "synthetic"
     assert res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0
     assert res["analysis_plus_synthesis_msamples_s"] > 0 and res["analysis_plus_synthesis_msamples_s"] < res["value"]
+
+
+def test_eight_rank_bench_plumbing():
+    """The N = 8 branch of bench.py (configs[4]: channels sharded over 8 ranks, weak scaling) has never seen 8 GPUs; so that
+    the first such run cannot fail on plumbing it runs here with 8 ranks -- nccl where 8 GPUs exist, else all ranks on the
+    one GPU over gloo: 2 channels per rank, short calls, ONE JSON line, value = all ranks' samples / slowest rank's time."""
+    import torch
+    backend = {} if torch.cuda.device_count() >= 8 else {"SDFT_BENCH_BACKEND": "gloo"}
+    res = run_bench(8, "--steps", "2", "--warmup", "1", "--samples", "4096", "--channels-per-gpu", "2", "--no-extras", env_extra=backend)
+    assert res["n_gpus"] == 8 and res["config"]["channels_total"] == 16 and res["config"]["samples_per_channel"] == 4096
+    assert res["scaling"] == "weak" and res["cpu_baseline"] is None
+    assert abs(res["value"] - 16 * 4096 / (res["ms_per_step"] * 1e-3) / 1e6) <= 0.02 * res["value"]
+    assert "configs[4]" in res["config"]["workload"] and "2/GPU" in res["config"]["workload"]
+
+
+def _hip_rank(rank, world, port, q):
+    """One rank of a sharded job on the HIP path: its block of channels through a batched plan, digests all-reduced."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sdft_amd import shard
+    from sdft_amd.sdft import SDFT
+    from sdft_amd.signals import sine_sweep
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+        channels, n, m = 5, 3000, 64
+        first, count = shard.channel_block(channels, world, rank)
+        x = np.stack([sine_sweep(n, channel=c, channels=channels) for c in range(first, first + count)])
+        with SDFT(m, "hann", 1.0, "f32f64", channels=count) as p:
+            d = p.sdft(torch.from_numpy(x).cuda())
+            y = p.isdft(d)
+            local = float(d.real.sum().item())
+            ysum = float(y.double().sum().item())
+        shard.barrier()
+        total = shard.sum_over_ranks(local)
+        ytotal = shard.sum_over_ranks(ysum)
+        q.put((rank, first, count, total, ytotal))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_on_the_hip_path():
+    """tests/test_shard_gloo.py covers the partition arithmetic with the oracle standing in for the device; here every rank
+    runs its channel block through the HIP kernels (batched plan) and the all-reduced digests meet the oracle's."""
+    import numpy as np
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from sdft_amd.signals import sine_sweep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want, ywant = 0.0, 0.0
+    for c in range(5):
+        ref = O.best(64, "hann", 1.0, "f32f64")
+        d = ref.sdft(sine_sweep(3000, channel=c, channels=5))
+        want += float(d.real.sum()); ywant += float(ref.isdft(d).astype(np.float64).sum())
+    assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 2)]
+    assert all(np.isclose(r[3], want, rtol=1e-9, atol=1e-9) and np.isclose(r[4], ywant, rtol=1e-6, atol=1e-6) for r in res)
+    assert res[0][3] == res[1][3]
