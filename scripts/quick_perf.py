@@ -26,7 +26,7 @@ def run(n, m, window="hann", combo="f32f64", channels=1, reps=5, **opts):
     esz = 16 if combo[3:] == "f64" else 8
     byts = channels * n * (m * esz + x.element_size())
     f = pr["forward"][0] / pr["forward"][1]; i = pr["inverse"][0] / pr["inverse"][1]
-    c = pr["carry"][0] / max(pr["carry"][1], 1); d = pr["delta"][0] / pr["delta"][1]
+    c = pr["carry"][0] / max(pr["carry"][1], 1); d = pr["delta"][0] / max(pr["delta"][1], 1)
     print(f"n={n} m={m} {window} {combo} ch={channels} opts={opts} chunks={p.get_option('last_chunks')} len={p.get_option('last_chunk_len')} chain={p.get_option('last_chain')} flow={p.get_option('last_flow')}: "
           f"fwd {f:.3f} ms ({byts/f/1e9:.0f} GB/s, {channels*n/f/1e3:.1f} Msamp/s) carry {c:.3f} delta {d:.3f} inv {i:.3f} ms ({byts/i/1e9:.0f} GB/s) wall/iter {wall*1e3:.3f} ms", flush=True)
     p.close(); del out

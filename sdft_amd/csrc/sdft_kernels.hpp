@@ -2125,6 +2125,7 @@ template <typename TD, typename FD> struct SelfArgs
   TD* hist_out;               // the other buffer: written by the workgroup of the call's last chunk
   const cx<FD>* acc_in;       // [channels][N] accumulator before the call (ForwardArgs::acc_state receives the new one)
   unsigned log2m;             // 2N = 1 << log2m
+  unsigned lds_deltas;        // fused kernel: samples of a chunk whose differences are staged in dynamic LDS (0: formed in the loop)
 };
 
 // cells[v] = sum of the differences (sdft.h:564, the subtraction in TD precision) of the samples t < t0 whose
@@ -3620,6 +3621,25 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 
   for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (AT)0;   // waves that do not exist add 0
+  // SELF: the chunk's differences, formed once by the workgroup (this kernel is bound by vector-instruction issue: formed in
+  // the time loop from scalar loads they cost every wave 16 of its 74 instructions per 8 samples)
+  extern __shared__ __align__(16) unsigned char proc_dyn_lds[];
+  FD* const dl_lds = reinterpret_cast<FD*>(proc_dyn_lds);
+  const bool staged = SELF && sa.lds_deltas != 0 && (t1 - t0) <= (size_t)sa.lds_deltas;
+  if constexpr (SELF)
+  {
+    if (staged)
+    {
+      const TD* xs = sa.x + ch * sa.x_stride;
+      const TD* hs = sa.hist_in + ch * (size_t)span;
+      for (size_t i = threadIdx.x; i < t1 - t0; i += blockDim.x)
+      {
+        const size_t tt = t0 + i;
+        const TD dd = xs[tt] - (tt < span ? hs[tt] : xs[tt - span]);          // TD precision (sdft.h:564)
+        dl_lds[i] = (FD)dd;
+      }
+    }
+  }
 
   // SELF: carry-in by fold + FFT of everything before this chunk; the 2N cells borrow the transpose tiles, which
   // the time loop does not touch before the barrier below
@@ -3652,6 +3672,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
              : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
     }
     if (!live[j]) { s[j].tw = cmake<FD>((FD)0, (FD)0); s[j].acc = s[j].tw; s[j].fid = s[j].tw; }
+    if constexpr (FUSED)
+    {
+      // chunk-parallel FD double path: carry the demodulated bin (see step_all)
+      s[j].acc = cmake<FD>(__builtin_fma(s[j].acc.re, s[j].fid.re, s[j].acc.im * s[j].fid.im),
+                           __builtin_fma(s[j].acc.im, s[j].fid.re, -(s[j].acc.re * s[j].fid.im)));      // X = acc * conj(fid)
+      s[j].tw.im = -s[j].tw.im;
+    }
   }
   // coefficients: one vector for the call, or (time-varying gains) vector r for the samples [r*hop, (r+1)*hop)
   size_t coeff_row = 0, coeff_next = ~(size_t)0;
@@ -3684,22 +3711,19 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
       BinState<FD>& b = s[j];
       if constexpr (FUSED)
       {
-        b.acc.re = __builtin_fma(b.fid.re, dl, b.acc.re);
-        b.acc.im = __builtin_fma(b.fid.im, dl, b.acc.im);
-        if (wrap) b.fid = cmake<FD>((FD)1, (FD)0);
-        else
-        {
-          const FD nr = __builtin_fma(b.fid.re, b.tw.re, -(b.fid.im * b.tw.im));
-          const FD ni = __builtin_fma(b.fid.re, b.tw.im, b.fid.im * b.tw.re);
-          b.fid.re = nr; b.fid.im = ni;
-        }
-        const FD xr = __builtin_fma(b.acc.re, b.fid.re, b.acc.im * b.fid.im);          // re(acc * conj(fid))
-        vv = __builtin_fma(al[j], xr, vv);
-        if constexpr (HASB)
-        {
-          const FD xi = __builtin_fma(b.acc.im, b.fid.re, -(b.acc.re * b.fid.im));
-          vv = __builtin_fma(be[j], xi, vv);
-        }
+        // The demodulated bin itself is carried through the chunk (b.acc holds X, b.tw holds conj(tw)):
+        //   X' = (acc + fid*d) * conj(fid*tw) = (X + |fid|^2 d) * conj(tw) = (X + d) * conj(tw),
+        // 1 addition + 1 complex multiplication = 5 instructions where acc, fid and the demodulation take 8 (sdft.h:583-585;
+        // at the roll-over, :572-574, fid*tw is W[2N*k] = 1 and the same line holds).  What the modulated form is for -- no
+        // error growth over an endless stream (sdft.h:6-16) -- is served by the chunk: X starts from (acc, fid) and runs
+        // for at most a few thousand multiplications by a unit-modulus constant, 1e-16 relative each.
+        (void)wrap;
+        const FD xr0 = b.acc.re + dl;
+        const FD nr = __builtin_fma(xr0, b.tw.re, -(b.acc.im * b.tw.im));
+        const FD ni = __builtin_fma(xr0, b.tw.im, b.acc.im * b.tw.re);
+        b.acc.re = nr; b.acc.im = ni;
+        vv = __builtin_fma(al[j], nr, vv);
+        if constexpr (HASB) vv = __builtin_fma(be[j], ni, vv);
       }
       else
       {
@@ -3745,7 +3769,15 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
     if (m == G && c + G <= maxc && t + G <= coeff_next)
     {
       FD dl[G];
-      if constexpr (SELF) self_deltas<G>(dl, xin, hin, t, (size_t)span);
+      if constexpr (SELF)
+      {
+        if (staged)
+        {
+#pragma unroll
+          for (int u = 0; u < G; ++u) dl[u] = dl_lds[t - t0 + u];            // broadcast reads
+        }
+        else self_deltas<G>(dl, xin, hin, t, (size_t)span);
+      }
       else
       {
 #pragma unroll
@@ -3808,8 +3840,18 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
       if (live[j])
       {
         const size_t k = (size_t)((j * nwaves + wave) * kWave + lane);
-        a.acc_state[ch * a.nbins + k] = s[j].acc;
-        a.fid_state[ch * a.nbins + k] = s[j].fid;
+        if constexpr (FUSED)
+        {
+          // back to the stream's state: fid at the cursor the call ends on (closed form, as the chunks were seeded), acc = X * fid
+          const cx<FD> f = a.wtab[(size_t)(((unsigned long long)k * c) % span)];
+          a.acc_state[ch * a.nbins + k] = cmul(s[j].acc, f);
+          a.fid_state[ch * a.nbins + k] = f;
+        }
+        else
+        {
+          a.acc_state[ch * a.nbins + k] = s[j].acc;
+          a.fid_state[ch * a.nbins + k] = s[j].fid;
+        }
       }
   }
   signal_done_workgroup(a.done);

@@ -986,6 +986,7 @@ class Plan
     sa.hist_in = d_hist[hist_cur].p; sa.hist_out = d_hist[hist_cur ^ 1].p;
     sa.acc_in = d_accs[st_cur].p;
     sa.log2m = 0; while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
+    sa.lds_deltas = 0;
     ForwardArgs<FD> fa{};
     fa.delta = nullptr; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = nullptr; fa.seed = nullptr; fa.fseed = nullptr; fa.fseed_L = 0;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = nullptr;
@@ -1310,7 +1311,14 @@ class Plan
   {
     if constexpr (sizeof(FD) == 8 && J <= 2)
     {
-      if (self) { hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB, true>), dim3(blocks), dim3(threads), 0, stream, fa, pz, *self); return; }
+      if (self)
+      {
+        // the chunk's differences in LDS while two workgroups still fit a CU (4 KiB each beside the transpose tiles)
+        SelfArgs<TD, FD> sa = *self;
+        sa.lds_deltas = (J == 1 && fa.chunk_len <= 512) ? fa.chunk_len : 0u;
+        hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB, true>), dim3(blocks), dim3(threads), sa.lds_deltas * sizeof(FD), stream, fa, pz, sa);
+        return;
+      }
     }
     hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB>), dim3(blocks), dim3(threads), 0, stream, fa, pz, SelfArgs<TD, FD>{});
   }
