@@ -66,6 +66,16 @@ if __name__ == "__main__":
         run(1000000, 1024)
         sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "base"
+    if which == "procj":
+        for kw in ({}, {"proc_slots": 2}, {"proc_slots": 4}):
+            run_process(1000000, 1024, fused_exact=0, reps=5, **kw)
+            run_process(48000, 1024, fused_exact=0, reps=20, **kw)
+            run_process(48000, 1024, channels=64, fused_exact=0, reps=3, **kw)
+        sys.exit(0)
+    if which == "process1":
+        # the fused call alone (counter passes): folded form, n = 1e6
+        run_process(1000000, 1024, fused_exact=0, reps=3)
+        sys.exit(0)
     if which == "invonly":
         # synthesis alone, repeated on the same matrix (no analysis in between), against the round trip
         for n, m, ch in ((48000, 1024, 1), (131072, 1024, 1), (12000, 1024, 1), (48000, 1024, 4)):

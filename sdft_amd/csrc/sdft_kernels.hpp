@@ -3604,7 +3604,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
   constexpr int G = kProcGroup;
   constexpr int R = kProcRing, K = kProcSync;
   using AT = double;                                        // arithmetic type of everything after the recurrence
-  __shared__ AT tile[kRowWavesMax][G * kProcRow];
+  // dynamic LDS: the waves' transpose tiles [waves][G * kProcRow] (the launch has as many waves as the row needs, so that
+  // several workgroups share a CU), then the staged differences of a self-carried chunk
+  extern __shared__ __align__(16) unsigned char proc_dyn_lds[];
+  AT* const tiles = reinterpret_cast<AT*>(proc_dyn_lds);
   __shared__ AT part[R][kRowWavesMax][G];                  // [group][wave][sample]: eight lanes write eight neighbours
 
   const int lane = threadIdx.x & (kWave - 1);
@@ -3623,8 +3626,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
   for (int i = threadIdx.x; i < R * G * kRowWavesMax; i += blockDim.x) (&part[0][0][0])[i] = (AT)0;   // waves that do not exist add 0
   // SELF: the chunk's differences, formed once by the workgroup (this kernel is bound by vector-instruction issue: formed in
   // the time loop from scalar loads they cost every wave 16 of its 74 instructions per 8 samples)
-  extern __shared__ __align__(16) unsigned char proc_dyn_lds[];
-  FD* const dl_lds = reinterpret_cast<FD*>(proc_dyn_lds);
+  FD* const dl_lds = reinterpret_cast<FD*>(tiles + (size_t)(blockDim.x >> 6) * G * kProcRow);
   const bool staged = SELF && sa.lds_deltas != 0 && (t1 - t0) <= (size_t)sa.lds_deltas;
   if constexpr (SELF)
   {
@@ -3643,8 +3645,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
 
   // SELF: carry-in by fold + FFT of everything before this chunk; the 2N cells borrow the transpose tiles, which
   // the time loop does not touch before the barrier below
-  static_assert(!SELF || sizeof(tile) >= (size_t)4096 * sizeof(cx<FD>), "2N <= 4096 cells must fit the transpose tiles");
-  cx<FD>* cells = reinterpret_cast<cx<FD>*>(&tile[0][0]);
+  // (the host launches the self-carried form only where 2N cells fit the tiles: Plan::launch_process)
+  cx<FD>* cells = reinterpret_cast<cx<FD>*>(tiles);
   bool have_cells = false;
   if constexpr (SELF) have_cells = self_carry<1, 8>(sa, a, cells, chunk, ch, t0);
 
@@ -3745,7 +3747,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
   const SDFT_CONSTANT TD* xin = SELF ? as_uniform(sa.x + ch * sa.x_stride) : nullptr;
   const SDFT_CONSTANT TD* hin = SELF ? as_uniform(sa.hist_in + ch * (size_t)span) : nullptr;
   TD* yo = pz.y + ch * pz.y_stride;
-  AT* my = tile[wave];
+  AT* my = tiles + (size_t)wave * G * kProcRow;
   const int ru = lane >> 3, rs = lane & 7;                 // transposed role: sample of the group, segment of the row
   // the waves' sums of group g wait in part[g % R]; every K groups a barrier, after which K waves add one
   // finished group each (tables K .. 2K-1 groups back are rewritten only after the barrier that follows)

@@ -150,8 +150,9 @@ class Plan
                                  // -1 = in order exactly when the host asked for exact carries at FD double (carry = 1)
   long last_fused_exact = 0, last_fused_fold = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
+  long opt_proc_slots = 0;       // fused kernel, development option: bins per lane (0 = as few as the row needs)
   long opt_self = 1;             // chunk-parallel FD double calls, 2N a power of two: self-carried chunks (no pre-pass launches)
-  long opt_self_max = (long)1 << 20;   // ... for calls of up to this many samples per channel (the fold of a chunk's past grows with n)
+  long opt_self_max = (long)1 << 19;   // ... for calls of up to this many samples per channel (the fold of a chunk's past grows with n)
   long last_self = 0;
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
@@ -653,7 +654,14 @@ class Plan
     long chunks, len;
     // (the folded fused kernel and the row-group forward kernel have the self-carried form)
     const bool folded_fuse = fuse && !wants_reference_order() && !fuse->store && opt_fold && coeff_ready;
-    const bool self_form = self_eligible(n, fuse != nullptr) && (fuse ? folded_fuse : use_rows);
+    bool self_form = self_eligible(n, fuse != nullptr) && (fuse ? folded_fuse : use_rows);
+    if (self_form && fuse)
+    {
+      // the fused kernel folds into its transpose tiles: the 2N cells have to fit them, and it has one or two bins per lane
+      long pw, ps;
+      process_geometry(opt_fused != 0, pw, ps, n);
+      self_form = ps <= 2 && span * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
+    }
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
@@ -1306,45 +1314,83 @@ class Plan
     coeff_ready = true;
     return true;
   }
+  static size_t process_tiles_bytes(unsigned threads) { return (size_t)(threads / kWave) * kProcGroup * kProcRow * sizeof(double); }
   template <int J, bool FUSED, bool HASB>
-  void launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, const SelfArgs<TD, FD>* self)
+  bool launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, const SelfArgs<TD, FD>* self)
   {
-    if constexpr (sizeof(FD) == 8 && J <= 2)
+    const size_t tiles = process_tiles_bytes(threads);
+    if (self)
     {
-      if (self)
+      if constexpr (sizeof(FD) == 8 && J <= 2)
       {
-        // the chunk's differences in LDS while two workgroups still fit a CU (4 KiB each beside the transpose tiles)
+        // the chunk's differences in LDS beside the transpose tiles (at most 4 KiB: several workgroups share a CU)
         SelfArgs<TD, FD> sa = *self;
-        sa.lds_deltas = (J == 1 && fa.chunk_len <= 512) ? fa.chunk_len : 0u;
-        hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB, true>), dim3(blocks), dim3(threads), sa.lds_deltas * sizeof(FD), stream, fa, pz, sa);
-        return;
+        sa.lds_deltas = fa.chunk_len <= 512 ? fa.chunk_len : 0u;
+        auto kern = process_rows_kernel<TD, FD, J, FUSED, HASB, true>;
+        static thread_local int raised_on = -1;              // dynamic LDS beyond 48 KiB has to be asked for (per device)
+        if (raised_on != device)
+        {
+          SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+          raised_on = device;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), tiles + sa.lds_deltas * sizeof(FD), stream, fa, pz, sa);
+        return true;
       }
+      set_error("sdft_hip_process_n", "internal: the self-carried form has one or two bins per lane");
+      return false;
     }
-    hipLaunchKernelGGL((process_rows_kernel<TD, FD, J, FUSED, HASB>), dim3(blocks), dim3(threads), 0, stream, fa, pz, SelfArgs<TD, FD>{});
+    auto kern = process_rows_kernel<TD, FD, J, FUSED, HASB>;
+    static thread_local int raised_on = -1;
+    if (raised_on != device)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      raised_on = device;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), tiles, stream, fa, pz, SelfArgs<TD, FD>{});
+    return true;
   }
   template <bool FUSED, bool HASB>
-  void launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots, const SelfArgs<TD, FD>* self)
+  bool launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots, const SelfArgs<TD, FD>* self)
   {
-    if (slots <= 1) launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads, self);
-    else if (slots == 2) launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads, self);
-    else launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads, self);
+    if (slots <= 1) return launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads, self);
+    if (slots == 2) return launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads, self);
+    return launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads, self);
+  }
+  // waves of a fused-kernel workgroup and bins per lane (1, 2, 4).  FD double in the chunk-parallel path: two bins per lane
+  // from 256 bins on -- the sum over bins (a transpose through LDS per wave and 8 samples) is paid per wave, the recurrence
+  // per bin: n = 1e6, N = 1024: 0.485 -> 0.397 ms with 8 waves of 2 bins instead of 16 of 1
+  // (four bins per lane where the call is long enough to fill the chip with such workgroups: 64 channels x 48000: 1.29 ->
+  // 1.13 ms, n = 1e6: 0.397 -> 0.388 ms; n = 48000 alone: 0.038 -> 0.045 ms, so not there)
+  void process_geometry(bool fused, long& waves, long& slots, size_t n = 0) const
+  {
+    waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
+    long want = opt_proc_slots > 0 ? opt_proc_slots
+              : ((fused && sizeof(FD) == 8 && nbins >= 256) ? ((nbins >= 512 && channels * n >= 400000) ? 4 : 2) : 1);
+    if (want > 1) waves = std::max(1L, std::min(waves, (long)((nbins + kWave * want - 1) / (kWave * want))));
+    slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
   }
   bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused, const SelfArgs<TD, FD>* self = nullptr)
   {
     ProcArgs<TD, FD> pz;
     pz.y = fz.y; pz.y_stride = fz.y_stride; pz.alpha = d_alpha.p; pz.beta = d_beta.p; pz.sweight = fz.sweight;
     pz.rows = coeff_rows; pz.hop = fz.op.hop;
-    const long waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
-    const long slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
+    long waves, slots;
+    process_geometry(fused, waves, slots, fa.n);
     const unsigned threads = (unsigned)(waves * kWave);
     const bool hasb = coeff_has_beta;
+    bool ok;
     if constexpr (sizeof(FD) == 8)
     {
-      if (fused) { if (hasb) launch_process_t<true, true>(fa, pz, blocks, threads, slots, self); else launch_process_t<true, false>(fa, pz, blocks, threads, slots, self); SDFT_TRY(hipGetLastError()); return true; }
+      if (fused)
+      {
+        ok = hasb ? launch_process_t<true, true>(fa, pz, blocks, threads, slots, self) : launch_process_t<true, false>(fa, pz, blocks, threads, slots, self);
+        SDFT_TRY(hipGetLastError());
+        return ok;
+      }
     }
-    if (hasb) launch_process_t<false, true>(fa, pz, blocks, threads, slots, self); else launch_process_t<false, false>(fa, pz, blocks, threads, slots, self);
+    ok = hasb ? launch_process_t<false, true>(fa, pz, blocks, threads, slots, self) : launch_process_t<false, false>(fa, pz, blocks, threads, slots, self);
     SDFT_TRY(hipGetLastError());
-    return true;
+    return ok;
   }
 
   template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
