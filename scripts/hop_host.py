@@ -10,7 +10,7 @@ print(bench.cpu_hop_baseline(np, sine_sweep, "f32f64", np.float32))
 # kernel times of the mapped host path
 m, hop, total = 1000, 100, 20000
 xh = sine_sweep(total); yh = np.zeros(total, np.float32); dh = np.zeros((hop, m), np.complex128)
-p = SDFT(m, "hann", 1.0, "f32f64"); p.set_option("profile", 2)
+p = SDFT(m, "hann", 1.0, "f32f64"); p.set_option("profile", 2); p.set_option("host_register", 1)
 for rep in range(2):
     for i in range(0, total, hop):
         p.api.sdft_n(p._p, hop, C.c_void_p(xh.ctypes.data + i * 4), C.c_void_p(dh.ctypes.data))
