@@ -768,6 +768,14 @@ class Plan
       // would be a deadlock -- every wait in the kernels is bounded all the same, and a time-out re-runs the call (forward_device).
       flow = use_relay && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && wait_value_ok();
       if (flow) segments = 1;
+      if (flow && started_target > (1u << 30))
+      {
+        // long before the start counter could wrap: drain both streams and begin it again (once per ~8 million calls)
+        if (aux) SDFT_TRY(hipStreamSynchronize(aux));
+        SDFT_TRY(hipStreamSynchronize(stream));
+        SDFT_TRY(hipMemset(d_started, 0, 8));
+        started_target = 0;
+      }
       segments = std::max(1L, std::min(segments, chunks));
       if (segments > 1 || flow)
       {

@@ -146,6 +146,16 @@ def test_kernels_contain_no_fused_multiply_add(hip_library, combo):
         params = [a.strip() for a in args.group(1).split(",")] if args else []
         deliberately_fused = name.startswith("chunk_sum_kernel") or \
             (name.startswith(("forward_rows_kernel", "process_rows_kernel")) and params[3] == "true")
+        # round 3: the magnitude power law of sdft_hip_process_n calls pow(), whose library code is built on fused
+        # multiply-adds; it is inlined into the kernels that apply spectral operations to windowed bins -- the fused-synthesis
+        # instantiations of the row-group kernel (SYN != 0), the OPS instantiations of the synthesis kernels and
+        # scale_rows_kernel.  Their reference arithmetic is the same source as their SYN = 0 / OPS = false twins', which stay
+        # under the zero-FMA rule below (and the bit-exact GPU tests cover the fused ones: tests/test_gpu_process.py).
+        carries_pow = (name.startswith("forward_rows_kernel") and len(params) > 5 and params[5] != "0") or \
+            (name.startswith(("inverse_kernel", "inverse_exact_kernel", "inverse_row_kernel")) and params[-1] == "true") or \
+            name.startswith("scale_rows_kernel")
+        if carries_pow and not deliberately_fused:
+            continue
         fused = [l for l in body if re.search(FUSED_OPS, l)]
         if deliberately_fused:
             continue
@@ -170,3 +180,25 @@ def test_hand_written_sequences_are_in_place(hip_library):
             assert len(re.findall(r"v_mul_f32_dpp v\d+, v\d+, v\d+ quad_perm:\[1,0,3,2\]", chain)) >= L
             assert "v_pk_mul_f32" not in chain and "v_pk_add_f32" not in chain                 # what the spelling-out prevents
             assert "ds_write_b128" in chain and "ds_read_b128" in chain
+
+
+def test_relay_form_is_what_it_claims(hip_library):
+    """carry_relay_kernel keeps a block's products in registers and the chain free of everything but additions: the
+    products pick their difference with the DPP row broadcast (no scalar operand, no v_readlane), the chain is L dependent
+    additions back to back, the wait for the token is one ds_read per poll -- and there is no LDS traffic for products."""
+    k = disassemble("f32f32", hip_library)
+    body = k["carry_relay_kernel<float, 128, false>"]
+    text = "\n".join(body)
+    assert len(re.findall(r"v_mul_f32_dpp v\d+, v\d+, v\d+ row_newbcast:\d+", text)) >= 128
+    assert len(re.findall(r"v_mul_f32_dpp v\d+, v\d+, v\d+ quad_perm:\[1,0,3,2\]", text)) >= 128
+    assert "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text and "ds_read_b128" not in text and "ds_write_b128" not in text
+    # the chain: a run of at least 128 consecutive dependent v_add_f32 on one accumulator
+    best = run = 0
+    for line in body:
+        run = run + 1 if re.match(r"v_add_f32_e32 v\d+, v\d+, v\d+", line) else 0
+        best = max(best, run)
+    assert best >= 128, best
+    assert len(re.findall(r"ds_read_b64 v\[4:5\]", text)) >= 1 and "flat_load" not in text
+    d = disassemble("f32f64", hip_library)
+    dbl = "\n".join(d["carry_relay_kernel<double, 64, false>"])
+    assert len(re.findall(r"v_mov_b32_dpp v1[23], v\d+ row_newbcast:\d+", dbl)) >= 128 and "scratch_" not in dbl
