@@ -101,13 +101,15 @@ if __name__ == "__main__":
             pl.close(); del out
     if which == "self":
         # self-carried chunks (one launch) against the pre-pass form: asynchronous and synchronous wall time per call
+        import os
+        M = int(os.environ.get("SDFT_M", "1024"))                 # 1000: the reference test size (mixed-radix FFT in the kernel)
         sizes = [int(a) for a in sys.argv[2:]] or [1024, 4096, 12000, 24000, 48000, 131072, 262144, 1000000]
         for n in sizes:
             x = torch.from_numpy(sine_sweep(n)).cuda()
-            out = torch.empty((n, 1024), dtype=torch.complex128, device="cuda")
+            out = torch.empty((n, M), dtype=torch.complex128, device="cuda")
             y = torch.empty_like(x)
             for sc in (0, 1):
-                pl = SDFT(1024, "hann", 1.0, "f32f64"); pl.set_option("self_carry", sc); pl.set_option("self_carry_max", 1 << 30)
+                pl = SDFT(M, "hann", 1.0, "f32f64"); pl.set_option("self_carry", sc); pl.set_option("self_carry_max", 1 << 30)
                 res = {}
                 for mode in ("async", "sync"):
                     pl.set_option("async", 1 if mode == "async" else 0)
@@ -118,7 +120,7 @@ if __name__ == "__main__":
                         t0 = time.perf_counter()
                         for _ in range(reps): f()
                         pl.synchronize(); res[(mode, what)] = (time.perf_counter() - t0) / reps
-                b = n * (1024 * 16 + 4)
+                b = n * (M * 16 + 4)
                 print(f"n={n} self_carry={sc} last_self={pl.get_option('last_self')} chunks={pl.get_option('last_chunks')} len={pl.get_option('last_chunk_len')}: "
                       f"sdft async {res[('async','sdft')]*1e6:.1f} us ({b/res[('async','sdft')]/8e12:.3f} of peak) sync {res[('sync','sdft')]*1e6:.1f} us ({b/res[('sync','sdft')]/8e12:.3f}) | "
                       f"process async {res[('async','process')]*1e6:.1f} us sync {res[('sync','process')]*1e6:.1f} us", flush=True)

@@ -2124,8 +2124,9 @@ template <typename TD, typename FD> struct SelfArgs
   const TD* hist_in;          // [channels][2N] delay line in time order
   TD* hist_out;               // the other buffer: written by the workgroup of the call's last chunk
   const cx<FD>* acc_in;       // [channels][N] accumulator before the call (ForwardArgs::acc_state receives the new one)
-  unsigned log2m;             // 2N = 1 << log2m
+  unsigned log2m;             // 2N = 1 << log2m, or 0: 2N = product of rl's radices (2, 3, 4, 5), Stockham between two buffers
   unsigned lds_deltas;        // fused kernel: samples of a chunk whose differences are staged in dynamic LDS (0: formed in the loop)
+  RadixList rl;
 };
 
 // cells[v] = sum of the differences (sdft.h:564, the subtraction in TD precision) of the samples t < t0 whose
@@ -2148,7 +2149,7 @@ SDFT_D void self_fold(const SelfArgs<TD, FD>& sa, cx<FD>* cells, unsigned m, uns
     for (int c = 0; c < CP; ++c)
     {
       const unsigned v = v0 + (unsigned)c * nthr;
-      tv[c] = (size_t)(((v < m ? v : v0) + m - cursor0) & (m - 1));      // first sample that arrives at cursor v (cursor0 < m)
+      tv[c] = (size_t)(((v < m ? v : v0) + m - cursor0) % m);           // first sample that arrives at cursor v (cursor0 < m)
       sum[c] = (FD)0;
       prev[c] = hs[tv[c]];                                 // x[tv - 2N]
     }
@@ -2220,12 +2221,61 @@ SDFT_D void lds_fft_dif(cx<FD>* x, unsigned log2m, const cx<FD>* __restrict__ w)
   }
 }
 
-// the whole prologue of a self-carried chunk: delay line for the next call (last chunk's workgroup), fold, FFT.
-// Returns true when cells[] holds the DFT (chunks that start at sample 0 need none).  Workgroup-uniform.
-template <int CP, int QB, typename TD, typename FD>
-SDFT_D bool self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<FD>* cells, unsigned chunk, size_t ch, size_t t0)
+// the same DFT for 2N = product of 2, 3, 4, 5 (the reference's own test size N = 1000: 2N = 4*4*5*5*5): Stockham autosort
+// between x and x + m, natural-order output, the workgroup's version of chunk_fft_mixed_kernel; returns the buffer that
+// holds the result; ends with a barrier
+template <typename FD>
+SDFT_D cx<FD>* lds_fft_mixed(cx<FD>* x, unsigned m, const RadixList& rl, const cx<FD>* __restrict__ w)
 {
-  const unsigned m = 1u << sa.log2m;
+  cx<FD>* y = x + m;
+  unsigned ns = 1;                                         // product of the radices already applied
+  for (unsigned st = 0; st < rl.count; ++st)
+  {
+    const unsigned r = rl.r[st];
+    const unsigned nr = m / r;
+    const unsigned tstep = m / (ns * r);                   // table stride of the stage twiddle
+    const unsigned rstep = nr;                             // table stride of the r-th roots of unity
+    for (unsigned i = threadIdx.x; i < nr; i += blockDim.x)
+    {
+      const unsigned k = i % ns;
+      cx<FD> v[5];
+#pragma unroll
+      for (unsigned t = 0; t < 5; ++t)
+        if (t < r)
+        {
+          const cx<FD> in = x[i + t * nr];
+          v[t] = t == 0 ? in : cmul(in, w[(size_t)(((unsigned long long)t * k * tstep) % m)]);
+        }
+      const unsigned base = (i / ns) * ns * r + k;
+#pragma unroll
+      for (unsigned q = 0; q < 5; ++q)
+        if (q < r)
+        {
+          cx<FD> o = v[0];
+#pragma unroll
+          for (unsigned t = 1; t < 5; ++t)
+            if (t < r) o = cadd(o, cmul(v[t], w[(size_t)(((unsigned long long)q * t * rstep) % m)]));
+          y[base + q * ns] = o;
+        }
+    }
+    __syncthreads();
+    cx<FD>* tmp = x; x = y; y = tmp;
+    ns *= r;
+  }
+  return x;
+}
+
+// the whole prologue of a self-carried chunk: delay line for the next call (last chunk's workgroup), fold, FFT.
+// Returns the buffer that holds the DFT (bin k at self_slot(k)), or nullptr: chunks that start at sample 0 need none.
+// Workgroup-uniform.
+template <typename TD, typename FD> SDFT_D unsigned self_slot(const SelfArgs<TD, FD>& sa, unsigned k)
+{
+  return sa.log2m ? (__brev(k) >> (32u - sa.log2m)) : k;
+}
+template <int CP, int QB, typename TD, typename FD>
+SDFT_D cx<FD>* self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<FD>* cells, unsigned chunk, size_t ch, size_t t0)
+{
+  const unsigned m = 2u * a.nbins;
   if (chunk + 1 == a.chunks)
   {
     const TD* xv = sa.x + ch * sa.x_stride;
@@ -2237,11 +2287,11 @@ SDFT_D bool self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<
       ho[i] = (q >= m) ? xv[q - m] : hv[q];
     }
   }
-  if (t0 == 0) return false;
+  if (t0 == 0) return nullptr;
   self_fold<CP, QB>(sa, cells, m, a.cursor0, ch, t0);
   __syncthreads();
-  lds_fft_dif(cells, sa.log2m, a.wtab);
-  return true;
+  if (sa.log2m) { lds_fft_dif(cells, sa.log2m, a.wtab); return cells; }
+  return lds_fft_mixed(cells, m, sa.rl, a.wtab);
 }
 
 // differences of G consecutive samples from scalar loads of the input and the delay line (wave-uniform)
@@ -3119,8 +3169,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   // SELF: carry-in by fold + FFT of everything before this chunk (dynamic LDS: 2N cells)
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
-  bool have_cells = false;
-  if constexpr (SELF) have_cells = self_carry<4, 8>(sa, a, cells, chunk, ch, t0);
+  cx<FD>* dft = nullptr;                                   // the chunk's carry-in minus acc(0), bin k at self_slot(k)
+  if constexpr (SELF) dft = self_carry<4, 8>(sa, a, cells, chunk, ch, t0);
 
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
   BinState<FD> s[S][BPL];
@@ -3146,7 +3196,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       if constexpr (SELF)
       {
         s[q][b].acc = sa.acc_in[ch * a.nbins + kk];
-        if (have_cells) s[q][b].acc = cadd(s[q][b].acc, cells[__brev((unsigned)kk) >> (32u - sa.log2m)]);
+        if (dft) s[q][b].acc = cadd(s[q][b].acc, dft[self_slot(sa, (unsigned)kk)]);
         s[q][b].fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
       }
       else
@@ -3647,8 +3697,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
   // the time loop does not touch before the barrier below
   // (the host launches the self-carried form only where 2N cells fit the tiles: Plan::launch_process)
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(tiles);
-  bool have_cells = false;
-  if constexpr (SELF) have_cells = self_carry<1, 8>(sa, a, cells, chunk, ch, t0);
+  cx<FD>* dft = nullptr;
+  if constexpr (SELF) dft = self_carry<1, 8>(sa, a, cells, chunk, ch, t0);
 
   BinState<FD> s[J];
   AT al[J], be[J];
@@ -3664,7 +3714,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax, J == 1 ? 8 : 4) void process_
     if constexpr (SELF)
     {
       s[j].acc = sa.acc_in[ch * a.nbins + kk];
-      if (have_cells) s[j].acc = cadd(s[j].acc, cells[__brev(kk) >> (32u - sa.log2m)]);
+      if (dft) s[j].acc = cadd(s[j].acc, dft[self_slot(sa, kk)]);
       s[j].fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
     }
     else

@@ -660,7 +660,7 @@ class Plan
       // the fused kernel folds into its transpose tiles: the 2N cells have to fit them, and it has one or two bins per lane
       long pw, ps;
       process_geometry(opt_fused != 0, pw, ps, n);
-      self_form = ps <= 2 && span * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
+      self_form = ps <= 2 && self_cells() * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
     }
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
@@ -676,7 +676,9 @@ class Plan
     // (the fold of a chunk's past costs t0 / threads loads: hidden behind the other workgroups' row stores in the
     // analysis, which is bound by HBM -- n = 1e6: 2.885 -> 2.853 ms -- but not in the fused call, which is bound by
     // instruction issue: n = 48000: 45.9 -> 42.3 us, n = 131072: 99 -> 117 us; hence self_eligible's limit for it)
-    const bool self = self_form && chunks > 1;
+    // (2N = 2/3/5-smooth: five Stockham stages with table look-ups -- n = 12000, N = 1000, chunks of 64 samples: 47 us with
+    // the pre-pass, 55 us self-carried; n = 48000, chunks of 192: 192 -> 173 us)
+    const bool self = self_form && chunks > 1 && ((span & (span - 1)) == 0 || len > 64);
     last_self = self;
     if (self) return forward_self(n, x, x_stride, out, out_stride, chunks, len, fuse);
     // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
@@ -714,13 +716,7 @@ class Plan
     {
       const size_t span_bytes = span * sizeof(fdx);
       const bool pow2 = (span & (span - 1)) == 0 && span >= 2;
-      if (!pow2)
-      {
-        size_t rem = span;
-        for (unsigned f : {4u, 2u, 3u, 5u})
-          while (rem % f == 0 && rl.count < 15) { rl.r[rl.count++] = (unsigned char)f; rem /= f; }
-        if (rem != 1) rl.count = 0;                                   // other prime factors: direct sums
-      }
+      if (!pow2) rl = smooth_radices(span);                           // other prime factors: direct sums
       const bool short_chunks = len <= 64 && opt_fft_carry != 2;
       if (opt_fft_carry && !short_chunks && pow2 && span_bytes <= (size_t)64 * 1024) sums_form = SUMS_FFT2;
       else if (opt_fft_carry && !short_chunks && rl.count > 0 && 2 * span_bytes <= (size_t)64 * 1024) sums_form = SUMS_FFT_MIXED;
@@ -984,12 +980,30 @@ class Plan
     return true;
   }
 
+  // radices of the mixed-radix FFT of `span` points (4, 2, 3, 5); count == 0: span has other prime factors
+  static RadixList smooth_radices(size_t span)
+  {
+    RadixList rl; rl.count = 0;
+    size_t rem = span;
+    for (unsigned f : {4u, 2u, 3u, 5u})
+      while (rem % f == 0 && rl.count < 15) { rl.r[rl.count++] = (unsigned char)f; rem /= f; }
+    if (rem != 1) rl.count = 0;
+    return rl;
+  }
+  // LDS cells the in-kernel DFT of a self-carried chunk works in: 2N in place for powers of two, two buffers of 2N for
+  // the 2/3/5-smooth sizes (Stockham); 0: this 2N has neither form
+  size_t self_cells() const
+  {
+    const size_t span = 2 * nbins;
+    if (span < 16 || span > 4096) return 0;
+    if ((span & (span - 1)) == 0) return span;
+    return (opt_self >= 1 && smooth_radices(span).count > 0 && 2 * span * sizeof(fdx) <= (size_t)80 * 1024) ? 2 * span : 0;
+  }
   // what the self-carried form needs of the plan and the call (the kernel that has it is chosen by the caller)
   bool self_eligible(size_t n, bool fused_call) const
   {
-    const size_t span = 2 * nbins;
     const size_t self_max = fused_call ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
-    return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && (span & (span - 1)) == 0 && span >= 16 && span <= 4096 && n <= self_max;
+    return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && self_cells() != 0 && n <= self_max;
   }
 
   // ---- self-carried chunks: the whole chunk-parallel call in one launch (SelfArgs in sdft_kernels.hpp) ----
@@ -1001,7 +1015,9 @@ class Plan
     sa.x = x; sa.x_stride = x_stride;
     sa.hist_in = d_hist[hist_cur].p; sa.hist_out = d_hist[hist_cur ^ 1].p;
     sa.acc_in = d_accs[st_cur].p;
-    sa.log2m = 0; while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
+    sa.log2m = 0; sa.rl.count = 0;
+    if ((span & (span - 1)) == 0) while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
+    else sa.rl = smooth_radices(span);
     sa.lds_deltas = 0;
     ForwardArgs<FD> fa{};
     fa.delta = nullptr; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = nullptr; fa.seed = nullptr; fa.fseed = nullptr; fa.fseed_L = 0;
@@ -1040,7 +1056,7 @@ class Plan
   bool launch_forward_rows_self_ws(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads)
   {
     auto kern = forward_rows_kernel<FD, 1, WIN, FUSED, S, 0, true, TD, true>;
-    const size_t lds = ((size_t)1 << sa.log2m) * sizeof(fdx);
+    const size_t lds = self_cells() * sizeof(fdx);
     static thread_local int raised_on = -1;                  // static + dynamic LDS beyond 64 KiB has to be asked for (per device)
     if (raised_on != device)
     {
