@@ -94,6 +94,10 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "async"         0|1   see above
    "carry"         0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
                        serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
+   "float_carry_parallel"  0 (default) | 1 = FD float plans take the chunk-parallel carries too: long calls run at
+                       twice the speed and land closer to the double-precision result than the reference's float
+                       arithmetic does, but NOT within 1e-4 of the float reference (which itself drifts about 2e-4
+                       of the largest bin per 262144 samples); the state then differs from the reference's by the same
    "exact_inverse" 1 (default) = synthesis adds the bins of a row in the reference's order
                        (bit-identical), 0 = wave-parallel tree sum
    "chunk"         samples per time chunk (0 = heuristic)

@@ -82,6 +82,8 @@ if __name__ == "__main__":
     run("configs[1] with bit-exact carries (carry=1)", 1_000_000, 1024, "hann", "f32f64", carry=1)
     run("configs[2] with the serial pass instead of the chain form", 262144, 4096, "blackman", "f32f32", chain=0)
     run("FD float, m=1024", 262144, 1024, "hann", "f32f32")
+    run("FD float, m=1024, float_carry_parallel=1 (not the float reference's bits)", 262144, 1024, "hann", "f32f32", float_carry_parallel=1)
+    run("configs[2] with float_carry_parallel=1 (not the float reference's bits)", 262144, 4096, "blackman", "f32f32", float_carry_parallel=1)
     print(f"# BASELINE config shapes on 1× MI355X ({torch.cuda.get_device_name(0)}), device-resident buffers\n")
     print("forward = sdft_sdft_n (delta + carries + forward kernel, wall per call incl. launches); inverse = sdft_isdft_n.")
     print("TB/s = algorithmic bytes (N·sizeof(fdx) + sizeof(td) per sample) / wall time.")

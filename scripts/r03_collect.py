@@ -11,6 +11,8 @@ for src, dst in (("bench_n1e6_m1024.json", "r03_bench_n1e6_m1024.json"), ("bench
                  ("process_perf.txt", "r03_fused_process_perf.txt"), ("self_perf.txt", "r03_self_carried_chunks_perf.txt"),
                  ("relay_perf.txt", "r03_exact_carry_relay_perf.txt"), ("relay_stats.txt", "r03_relay_wave_cycles.txt"),
                  ("relay_stamps.txt", "r03_relay_critical_path_stamps.txt"), ("relay_probe.txt", "r03_relay_token_probe.txt"),
+                 ("add_latency_probe.txt", "r03_dependent_add_latency.txt"), ("nonlinear_perf.txt", "r03_nonlinear_ops_perf.txt"),
+                 ("float_parallel_carries.txt", "r03_float_parallel_carries.txt"),
                  ("north_star_ab.txt", "r03_north_star_n48000_ab.txt"), ("hop_host.txt", "r03_hop_host_pointers.txt")):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))

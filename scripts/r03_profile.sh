@@ -18,6 +18,9 @@ python3 $R/scripts/config_report.py > $O/configs.md 2>/dev/null
 python3 $R/scripts/relay_stats.py 2>/dev/null > $O/relay_stats.txt
 python3 $R/scripts/relay_stamps.py 2>/dev/null > $O/relay_stamps.txt
 $R/scripts/bin/relay_probe > $O/relay_probe.txt 2>&1
+$R/scripts/bin/add_latency_probe > $O/add_latency_probe.txt 2>&1
+python3 $R/scripts/nonlinear_perf.py 2>/dev/null > $O/nonlinear_perf.txt
+python3 $R/scripts/float_fast_probe.py 2>/dev/null > $O/float_parallel_carries.txt
 python3 $R/scripts/quick_perf.py process 2>/dev/null > $O/process_perf.txt
 python3 $R/scripts/quick_perf.py self 2>/dev/null > $O/self_perf.txt
 python3 $R/scripts/quick_perf.py relay 2>/dev/null > $O/relay_perf.txt

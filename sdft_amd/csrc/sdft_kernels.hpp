@@ -3048,10 +3048,15 @@ template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>
   if (op.kind == OP_POWER)
   {
     const FD mag2 = v.re * v.re + v.im * v.im;
-    if (!(mag2 > (FD)0)) return cmake<FD>((FD)0, (FD)0);
+    // (FD float: |v| below 1e-19 -- a denormal square, which v_log_f32 would flush -- counts as zero)
+    if (!(mag2 > (sizeof(FD) == 8 ? (FD)0 : (FD)1.17549435e-38f))) return cmake<FD>((FD)0, (FD)0);
+    // |v|^(p-1) = exp((p-1)/2 * ln |v|^2): mag2 is positive and finite here, so none of pow()'s case analysis is needed
+    // (a third of its instructions and registers; 1e-15 / 1e-6 of the factor at FD double / float, the float one
+    // through v_log_f32 / v_exp_f32)
+    const FD h = (op.p0 - (FD)1) * (FD)0.5;
     FD f;
-    if constexpr (sizeof(FD) == 8) f = op.p1 * pow(mag2, (op.p0 - (FD)1) * (FD)0.5);
-    else f = op.p1 * powf(mag2, (op.p0 - (FD)1) * (FD)0.5);
+    if constexpr (sizeof(FD) == 8) f = op.p1 * exp(h * log(mag2));
+    else f = op.p1 * __builtin_amdgcn_exp2f(h * __builtin_amdgcn_logf(mag2));
     return cscale(v, f);
   }
   return v;
@@ -3124,7 +3129,13 @@ constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockste
 // lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
 constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
 // samples per lockstep group of the fused synthesis path (the plan sizes the terms image with it)
-constexpr int syn_group(int S, int BPL, int SYN) { return (S == 2 && BPL == 2 && SYN == 1) ? SDFT_SYN_GROUP_S2F : kRowGroup / S; }
+#ifndef SDFT_SYN_GROUP_TREE
+#define SDFT_SYN_GROUP_TREE 8
+#endif
+constexpr int syn_group(int S, int BPL, int SYN)
+{
+  return (S == 2 && BPL == 2 && SYN == 1) ? SDFT_SYN_GROUP_S2F : (SYN == 1 && S == 1) ? SDFT_SYN_GROUP_TREE : kRowGroup / S;
+}
 
 // SYN (fused analysis -> operation -> synthesis): 0 = rows are stored (the
 // plain forward kernel), 1 = the row is turned into the terms sdft_isdft adds (sdft.h:641-651), parked in
@@ -3411,6 +3422,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           constexpr int NV = 16 / (int)sizeof(FD);
           const FD* tr = tbase + (size_t)lane * term_stride;
           FD sum = (FD)0;
+          // (the chain of additions is the critical path of the kernel: 12 cycles per addition, 6.5 of them the dependent
+          // v_add_f64 itself and the rest the issue of the eight-lane ds_read_b128; requesting the next vectors ahead of
+          // the additions changes nothing -- scripts/add_latency_probe.hip)
           for (unsigned k0 = 0; k0 < term_bins; k0 += 8 * NV)       // term_bins is a multiple of 64
           {
             tvec tv[8];

@@ -130,6 +130,10 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
+  // FD float plans take the chunk-parallel carries too: 2x faster on long calls and closer to the double-precision
+  // result than the reference's float arithmetic is, but not within 1e-4 of it (the float reference itself drifts
+  // 2e-4 of the largest bin per 262144 samples: profiles/r03_float_parallel_carries.txt)
+  long opt_float_parallel = 0;
   long opt_chunk = 0;            // forced chunk length (0 = heuristic)
   long opt_interior = 0;         // forced interior lanes per wave (0 = maximum)
   long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
@@ -225,7 +229,7 @@ class Plan
     own_stream = true;
     if (const char* e = getenv("SDFT_HIP_CARRY"))
       carry_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? CARRY_EXACT : CARRY_FAST;
-    if (sizeof(FD) == 4) carry_mode = CARRY_EXACT;         // float FD must follow the reference's rounding
+    if (sizeof(FD) == 4) carry_mode = CARRY_EXACT;         // float FD follows the reference's rounding (unless "float_carry_parallel")
     if (const char* e = getenv("SDFT_HIP_CHUNK")) opt_chunk = atol(e);
     if (const char* e = getenv("SDFT_HIP_INTERIOR")) opt_interior = atol(e);
     if (const char* e = getenv("SDFT_HIP_TARGET_WAVES")) opt_target_waves = atol(e);

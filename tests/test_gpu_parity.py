@@ -491,6 +491,40 @@ def test_self_carried_chunks_batched_and_fused():
             assert p.get_option("last_self") == 0
 
 
+def test_float_plans_with_chunk_parallel_carries():
+    """Option float_carry_parallel: FD float plans take the chunk-parallel carries.  The float reference drifts from the
+    double-precision result by its own rounding (about 2e-4 of the largest bin per 262144 samples), so no path other
+    than the bit-exact one stays within 1e-4 of it on long calls; what this option promises instead is checked here:
+    closer to the double-precision reference than the float reference is, and within 1e-4 of it."""
+    for m, window, n in ((1024, "hann", 120000), (4096, "blackman", 40000), (1000, "hamming", 60000), (256, "boxcar", 50000)):
+        x = noise(n, seed=71) if m != 1024 else sine_sweep(n)
+        ref32, ref64 = O.best(m, window, 1.0, "f32f32"), O.best(m, window, 1.0, "f32f64")
+        want32, truth = ref32.sdft(x), ref64.sdft(x)
+        with make(m, window, 1.0, "f32f32") as p:
+            assert p.get_option("carry") == 1
+            p.set_option("carry", 0)
+            assert p.get_option("carry") == 1                       # FD float stays exact without the explicit option
+            p.set_option("float_carry_parallel", 1)
+            assert p.get_option("carry") == 0
+            got = p.sdft(x)
+            assert p.get_option("last_chunks") > 1 and p.get_option("last_chain") == 0
+            assert rel_err(got, truth) <= 1e-4, (m, rel_err(got, truth))
+            assert rel_err(got, truth) <= rel_err(want32, truth), (m, rel_err(got, truth), rel_err(want32, truth))
+            hop = noise(300, seed=72)
+            got2 = p.sdft(hop)
+            assert rel_err(got2, ref64.sdft(hop)) <= 1e-4
+            ref32.sdft(hop)
+            # the fused call follows the option too
+            part = noise(30000, seed=73)
+            y = p.process(part, "identity")
+            assert rel_err(y, ref64.isdft(ref64.sdft(part))) <= 1e-4
+            # and back: a reset plan without the option is bit-identical again
+            p.set_option("float_carry_parallel", 0)
+            assert p.get_option("carry") == 1
+            p.reset(); ref32.reset()
+            assert np.array_equal(p.sdft(x[:20000]), ref32.sdft(x[:20000]))
+
+
 def test_exact_carry_relay_flow_mode():
     """Flow mode (default with the relay form): one relay launch on the auxiliary stream, one forward launch whose
     workgroups wait for their chunk's carries (time-major numbering for batched plans), against the segmented form and
