@@ -520,9 +520,16 @@ def main():
         # small launch in front), and a spectral gate (not linear: the windowed rows in LDS, tree sum)
         if count == 1:
             rows_g = torch.rand(((n + 511) // 512, m), dtype=torch.float64 if esz == 16 else torch.float32, device="cuda") + 0.5
-            for label, kw in (("gain_rows_hop512", dict(op="gain_rows", gain=rows_g, hop=512)), ("gate", dict(op="gate", threshold=1e-3, floor=0.0))):
+            # ... and the same gate handed in as code (sdft_hip_op_expr: compiled into the fused kernel at run time; the
+            # compilation is outside the timed calls and reported beside them)
+            gate_code = "if (re * re + im * im < p[0] * p[0]) { re = 0; im = 0; }"
+            for label, kw in (("gain_rows_hop512", dict(op="gain_rows", gain=rows_g, hop=512)), ("gate", dict(op="gate", threshold=1e-3, floor=0.0)),
+                              ("gate_as_expression", dict(op="expr", expr=gate_code, expr_params=[1e-3]))):
+                tc = time.perf_counter()
                 yf = plan.process(x, **kw)
                 sync()
+                if label == "gate_as_expression":
+                    fp["expression_first_call_s"] = round(time.perf_counter() - tc, 2)
                 tf = time.perf_counter()
                 for _ in range(5):
                     plan.process(x, out=yf, **kw)

@@ -28,6 +28,9 @@ int         sdft_hip_set_device(int device); /* plans are created on the current
 int         sdft_hip_get_device(void);
 const char* sdft_hip_version(void);
 int         sdft_hip_selftest(void);         /* 0 = cross-lane primitives behave as the kernels assume */
+/* compiles the statements of a sdft_hip_op_expr operation (below) for `arch` (NULL: "gfx950") without running them:
+   0, or -1 with the compiler's words in sdft_hip_last_error().  Needs no GPU. */
+int         sdft_hip_check_expr(const char* expr, const char* arch);
 
 /* measurement aid: average ms of a store-only kernel over `bytes` of device memory.
    pattern 0 = linear fill; pattern 1 = the forward kernel's tiling (rows of `row_slots` 16-byte
@@ -69,6 +72,18 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
                            |X'[k]| = scale * |X[k]|^exponent with the phase kept (spectral compression / expansion)
                            (gate and power are not linear in the spectrum: they run on the windowed rows inside the
                            row-group kernel, dftsize <= 2048 double / 4096 float, two passes beyond)
+     sdft_hip_op_expr      the host's own operation, handed in as code: params = const sdft_hip_expr_t*
+                           { expr, params, nparams }.  expr is a string of HIP C++ statements applied to every windowed
+                           bin; in scope are  re, im  (sdft_fd_t; read and assign them: the value of bin k),  k, nbins
+                           (unsigned),  t  (size_t: index of the sample within the call),  ch  (size_t: channel),
+                           p  (const sdft_fd_t*: the call's nparams parameters, copied from host memory with the call)
+                           and HIP's math functions.  Example (a gate with a frequency-dependent threshold):
+                               "if (re * re + im * im < p[0] * p[0] * (1 + k)) { re = 0; im = 0; }"
+                           The statements are compiled into the fused kernel at run time (hiprtc: libhiprtc.so is opened
+                           on first use; about a second per new expression and kernel shape, then cached for the life of
+                           the process), so the call still moves no matrix; rows beyond the row-group kernel and calls of
+                           one time chunk run analysis -> expression on the rows -> synthesis as three launches.
+                           What sdft.h leaves to the host between sdft_sdft_n and sdft_isdft_n (README.md:42-47), on the GPU.
    dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
    (not with the shift).  Batched plans: samples / out [channels][nsamples].
    Results equal sdft_sdft_n + operation + sdft_isdft_n of the reference within the path's bar (1e-6
@@ -77,8 +92,10 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
    carry = 1.  The stream state a call leaves behind is the one the two calls leave.  Returns 0, or -1
    with sdft_hip_last_error() set. */
 enum sdft_hip_op { sdft_hip_op_identity = 0, sdft_hip_op_gain = 1, sdft_hip_op_shift = 2, sdft_hip_op_cgain = 3,
-                   sdft_hip_op_gain_rows = 4, sdft_hip_op_cgain_rows = 5, sdft_hip_op_gate = 6, sdft_hip_op_power = 7 };
+                   sdft_hip_op_gain_rows = 4, sdft_hip_op_cgain_rows = 5, sdft_hip_op_gate = 6, sdft_hip_op_power = 7,
+                   sdft_hip_op_expr = 8 };
 typedef struct { const void* gains; size_t rows; size_t hop; } sdft_hip_gain_rows_t;
+typedef struct { const char* expr; const void* params; size_t nparams; } sdft_hip_expr_t;
 int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t* samples, sdft_td_t* const out,
                        const int op, const void* params, sdft_fdx_t* dfts) SDFT_HIP_SYMBOL(process_n);
 

@@ -14,6 +14,7 @@ for combo, win in (("f32f64", "hann"), ("f32f64", "blackman"), ("f32f32", "hann"
     y = torch.empty_like(x)
     for label, op, kw, opts in (("identity (folded)", "identity", {}, {}), ("identity, windowed rows (fold=0)", "identity", {}, {"fold": 0}),
                                 ("gate", "gate", {"threshold": 0.01, "floor": 0.0}, {}), ("power", "power", {"exponent": 0.7, "scale": 1.0}, {}),
+                                ("gate as an expression (run-time compiled)", "expr", {"expr": "if (re * re + im * im < p[0] * p[0]) { re *= p[1]; im *= p[1]; }", "expr_params": [0.01, 0.0]}, {}),
                                 ("identity, reference order", "identity", {}, {"fused_exact": 2})):
         if combo == "f32f32" and n > 300000: continue
         if only and (only not in label or (combo, win) != ("f32f64", "hann")): continue

@@ -65,10 +65,18 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
     obj_dir = os.path.join(OUT_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
+    # the text of the kernels, for the run-time compilation of a host's own spectral operation (sdft_hip_process_expr_n):
+    # a raw string literal in pieces (compilers bound the length of one literal), included by sdft_common.hip
+    with open(os.path.join(CSRC, "sdft_kernels.hpp")) as fh:
+        text = fh.read()
+    assert ')SDFTSRC"' not in text
+    pieces = [text[i:i + 8000] for i in range(0, len(text), 8000)]
+    with open(os.path.join(obj_dir, "sdft_kernels_src.inc"), "w") as fh:
+        fh.write("\n".join(f'R"SDFTSRC({piece})SDFTSRC"' for piece in pieces) + "\n")
 
     def compile_one(src: str) -> str:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *extra_flags, f"-I{obj_dir}", "-c", os.path.join(CSRC, src), "-o", obj]
         if save_temps:
             cmd.insert(1, "-save-temps=obj")
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=obj_dir)

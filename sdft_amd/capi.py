@@ -14,7 +14,7 @@ from . import build as _build
 COMBOS = _build.COMBOS
 WINDOWS = {"boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3}   # sdft.h:127-133 of the reference
 STAGES = ("delta", "carry", "forward", "inverse")
-OPS = {"identity": 0, "gain": 1, "shift": 2, "cgain": 3, "gain_rows": 4, "cgain_rows": 5, "gate": 6, "power": 7}   # enum sdft_hip_op (sdft_hip.h)
+OPS = {"identity": 0, "gain": 1, "shift": 2, "cgain": 3, "gain_rows": 4, "cgain_rows": 5, "gate": 6, "power": 7, "expr": 8}   # enum sdft_hip_op (sdft_hip.h)
 
 # every typed entry point exported per (td, fd) combination:  name -> (restype, argtypes)
 _TD = {"f32": C.c_float, "f64": C.c_double}
@@ -63,6 +63,7 @@ UNTYPED = {
     "sdft_hip_get_device": (C.c_int, []),
     "sdft_hip_version": (C.c_char_p, []),
     "sdft_hip_selftest": (C.c_int, []),
+    "sdft_hip_check_expr": (C.c_int, [C.c_char_p, C.c_char_p]),
     "sdft_hip_store_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int]),
     "sdft_hip_load_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_int]),
 }

@@ -2,6 +2,9 @@
 
 #include "sdft_plan.hpp"
 
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <map>
 #include <mutex>
 
 namespace sdfthip {
@@ -13,6 +16,107 @@ void set_error(const char* what, const char* detail)
 {
   g_error = std::string(what ? what : "?") + ": " + (detail ? detail : "?");
   g_has_error = true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Run-time compilation of a host's own spectral operation (sdft_hip_process_n with sdft_hip_op_expr).  The library carries the text of
+// sdft_kernels.hpp; the host's statements become the header "sdft_user_expr.inc" of a hiprtc program that instantiates
+// ONE kernel (the name expression the plan asks for: about a second).  libhiprtc.so is opened on first use -- the
+// library itself depends on no HIP library (build.py) -- and a compiled kernel stays loaded for the life of the process.
+// ------------------------------------------------------------------------------------------
+static const char kKernelSource[] =
+#include "sdft_kernels_src.inc"
+    ;
+
+namespace {
+struct Rtc
+{
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcAddNameExpression) add_name = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetLoweredName) lowered = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  bool tried = false;
+  std::map<std::string, hipFunction_t> kernels;            // device | expression | name expression -> function
+  std::mutex mu;
+
+  bool open()
+  {
+    if (tried) return lib != nullptr;
+    tried = true;
+    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"})
+      if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    if (!lib) return false;
+#define SDFT_RTC_SYM(field, symbol) field = reinterpret_cast<decltype(field)>(dlsym(lib, #symbol)); if (!field) { lib = nullptr; return false; }
+    SDFT_RTC_SYM(create, hiprtcCreateProgram) SDFT_RTC_SYM(destroy, hiprtcDestroyProgram) SDFT_RTC_SYM(add_name, hiprtcAddNameExpression)
+    SDFT_RTC_SYM(compile, hiprtcCompileProgram) SDFT_RTC_SYM(log_size, hiprtcGetProgramLogSize) SDFT_RTC_SYM(log, hiprtcGetProgramLog)
+    SDFT_RTC_SYM(lowered, hiprtcGetLoweredName) SDFT_RTC_SYM(code_size, hiprtcGetCodeSize) SDFT_RTC_SYM(code, hiprtcGetCode)
+#undef SDFT_RTC_SYM
+    return true;
+  }
+};
+Rtc g_rtc;
+}  // namespace
+
+// the code object of `name_expr` (a kernel of sdft_kernels.hpp) with the host's statements compiled in; no GPU is needed
+bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std::string& lowered_name, std::vector<char>& code)
+{
+  if (!g_rtc.open()) { set_error("sdft_hip_process_n (expression)", "libhiprtc.so could not be opened (the operation is compiled at run time)"); return false; }
+  const std::string source = std::string("#define SDFT_USER_EXPR 1\n") + kKernelSource;
+  const std::string body = std::string(expr) + "\n";
+  const char* headers[] = {body.c_str()};
+  const char* include_names[] = {"sdft_user_expr.inc"};
+  hiprtcProgram prog = nullptr;
+  if (g_rtc.create(&prog, source.c_str(), "sdft_kernels_user.hip", 1, headers, include_names) != HIPRTC_SUCCESS)
+  { set_error("sdft_hip_process_n (expression)", "hiprtcCreateProgram failed"); return false; }
+  bool ok = g_rtc.add_name(prog, name_expr) == HIPRTC_SUCCESS;
+  const std::string arch_flag = std::string("--offload-arch=") + arch;
+  const char* opts[] = {arch_flag.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-pragma-once-outside-header"};
+  if (ok && g_rtc.compile(prog, 6, opts) != HIPRTC_SUCCESS)
+  {
+    // the compiler's words about the host's statements are the useful part of the failure
+    size_t n = 0; g_rtc.log_size(prog, &n);
+    std::string text(n ? n : 1, '\0');
+    if (n > 1) g_rtc.log(prog, &text[0]);
+    const size_t at = text.find("sdft_user_expr.inc");
+    set_error("sdft_hip_process_n: the expression does not compile", text.substr(at == std::string::npos ? 0 : at, 1500).c_str());
+    ok = false;
+  }
+  const char* low = nullptr;
+  if (ok) ok = g_rtc.lowered(prog, name_expr, &low) == HIPRTC_SUCCESS && low;
+  size_t bytes = 0;
+  if (ok) { lowered_name = low; ok = g_rtc.code_size(prog, &bytes) == HIPRTC_SUCCESS && bytes > 0; }
+  if (ok) { code.resize(bytes); ok = g_rtc.code(prog, code.data()) == HIPRTC_SUCCESS; }
+  g_rtc.destroy(&prog);
+  if (!ok && !g_has_error) set_error("sdft_hip_process_n (expression)", "run-time compilation failed");
+  return ok;
+}
+
+// the kernel `name_expr` with the host's statements, loaded on `device` (compiled once per process, expression and kernel)
+bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn)
+{
+  std::lock_guard<std::mutex> lock(g_rtc.mu);
+  const std::string key = std::to_string(device) + "|" + expr + "|" + name_expr;
+  auto it = g_rtc.kernels.find(key);
+  if (it != g_rtc.kernels.end()) { *fn = it->second; return true; }
+  hipDeviceProp_t prop;
+  SDFT_TRY(hipGetDeviceProperties(&prop, device));
+  std::string arch = prop.gcnArchName;                     // "gfx950:sramecc+:xnack-"
+  arch = arch.substr(0, arch.find(':'));
+  std::string lowered; std::vector<char> code;
+  if (!rtc_compile(expr, name_expr, arch.c_str(), lowered, code)) return false;
+  hipModule_t module = nullptr;
+  SDFT_TRY(hipModuleLoadData(&module, code.data()));
+  hipFunction_t f = nullptr;
+  SDFT_TRY(hipModuleGetFunction(&f, module, lowered.c_str()));
+  g_rtc.kernels[key] = f;
+  *fn = f;
+  return true;
 }
 
 __global__ void lane_selftest_kernel(int* out)
@@ -207,5 +311,17 @@ int sdft_hip_get_device(void)
 }
 const char* sdft_hip_version(void) { return "sdft-hip 0.1 (gfx950)"; }
 int sdft_hip_selftest(void) { return sdfthip::lane_selftest() ? 0 : -1; }
+// compiles the statements of a sdft_hip_op_expr operation for `arch` (NULL: gfx950) without running them: 0, or -1 with the
+// compiler's words in sdft_hip_last_error().  Needs no GPU -- a host can check its expressions where it is built.
+int sdft_hip_check_expr(const char* expr, const char* arch)
+{
+  if (!expr || !*expr) { sdfthip::set_error("sdft_hip_check_expr", "no statements"); return -1; }
+  std::string lowered; std::vector<char> code;
+  const char* target = arch && *arch ? arch : "gfx950";
+  // (both bin types on the two-pass route, and the fused kernel of the headline shape)
+  return sdfthip::rtc_compile(expr, "sdfthip::user_rows_kernel<double>", target, lowered, code) &&
+         sdfthip::rtc_compile(expr, "sdfthip::user_rows_kernel<float>", target, lowered, code) &&
+         sdfthip::rtc_compile(expr, "sdfthip::forward_rows_kernel<double, 1, 1, true, 1, 1, true, float, false>", target, lowered, code) ? 0 : -1;
+}
 
 }  // extern "C"

@@ -37,9 +37,15 @@
 
 #pragma once
 
+// (this file is also compiled at run time, by hiprtc, for sdft_hip_process_n with sdft_hip_op_expr: the library carries its text, and the
+// run-time compiler brings its own HIP declarations)
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#else
+typedef unsigned long uintptr_t;
+#endif
 
 #pragma clang fp contract(off)
 
@@ -2998,7 +3004,8 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
 //   power (p, scale)    X'_k = X_k * scale * |X_k|^(p-1), i.e. |X'_k| = scale * |X_k|^p with the phase kept
 // Gains may change with time: `rows` gain vectors, row r for the call's samples [r*hop, (r+1)*hop), the last one for
 // everything after it (what a host does when it recomputes its mask every hop; README.md:42-47 leaves that loop to it).
-enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2, OP_CGAIN = 3, OP_GATE = 4, OP_POWER = 5 };
+//   user  (expression)   X'_k = whatever the host's statements leave in (re, im): compiled at run time (user_op below)
+enum : int { OP_IDENTITY = 0, OP_GAIN = 1, OP_SHIFT = 2, OP_CGAIN = 3, OP_GATE = 4, OP_POWER = 5, OP_USER = 6 };
 template <typename FD> struct SpectralOp
 {
   int kind;
@@ -3061,6 +3068,35 @@ template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>
   }
   return v;
 }
+
+// the host's own operation (sdft_hip_process_n with sdft_hip_op_expr): its statements are the text of the header "sdft_user_expr.inc" of the
+// run-time compilation, which defines SDFT_USER_EXPR; the library's own build has no such operation.
+// In scope: re, im (sdft_fd_t, read and assign: the windowed value of bin k), k, nbins (unsigned), t (size_t: sample index
+// within the call), ch (size_t: channel), p (const sdft_fd_t*: the call's parameters, device memory), and HIP's math.
+#ifdef SDFT_USER_EXPR
+template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbins, size_t t, size_t ch, const FD* p)
+{
+  typedef FD sdft_fd_t;
+  FD re = v.re, im = v.im;
+  {
+#include "sdft_user_expr.inc"
+  }
+  return cmake<FD>(re, im);
+}
+// rows[ch][t][k] = user_op(rows[ch][t][k]): the two-pass route (rows that no workgroup holds, one-chunk calls)
+template <typename FD>
+__global__ __launch_bounds__(256) void user_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, size_t t0, const FD* p)
+{
+  const size_t per = rows * nbins, total = per * channels;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+  {
+    const size_t ch = i / per, r = i - ch * per;
+    const size_t t = r / nbins, k = r - t * nbins;
+    cx<FD>* q = mat + ch * stride + r;
+    *q = user_op(*q, (unsigned)k, nbins, t0 + t, ch, p);
+  }
+}
+#endif
 
 // grow: the gain vector of the row v belongs to (gain_row / GainCursor); unused by the other operations
 template <typename FD, bool LAT1, bool OPS>
@@ -3357,6 +3393,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           const unsigned k = off_elems[q] + (unsigned)b;
           if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], gcur.g[keep[q][b] ? k : 0]);
           else if (fz.op.kind == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(gcur.g)[keep[q][b] ? k : 0]);
+#ifdef SDFT_USER_EXPR
+          else if (fz.op.kind == OP_USER) { if (keep[q][b]) y[b] = user_op(y[b], k, a.nbins, gtime - 1, ch, fz.op.gain); }
+#endif
           else if (fz.op.kind >= OP_GATE) y[b] = op_pointwise(y[b], fz.op);
           SpectralOp<FD> shift_only = fz.op; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
           shift_only.gain = nullptr;

@@ -23,6 +23,9 @@ namespace sdfthip {
 // ---- error channel (the reference has none: void returns, sdft.h:413-687) -----------------
 void set_error(const char* what, const char* detail);   // sdft_common.hip
 bool lane_selftest();                                   // sdft_common.hip
+// run-time compilation of a host's own spectral operation (sdft_common.hip)
+bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn);
+bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std::string& lowered_name, std::vector<char>& code);
 
 #define SDFT_TRY(expr)                                                        \
   do {                                                                        \
@@ -130,6 +133,8 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
+  std::string user_expr;                                   // sdft_hip_process_expr_n: the statements of the call in flight
+  template <typename T> static const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
   // FD float plans take the chunk-parallel carries too: 2x faster on long calls and closer to the double-precision
   // result than the reference's float arithmetic is, but not within 1e-4 of it (the float reference itself drifts
   // 2e-4 of the largest bin per 262144 samples: profiles/r03_float_parallel_carries.txt)
@@ -1285,6 +1290,21 @@ class Plan
       SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
       raised_on = device;
     }
+    if (fz.op.kind == OP_USER)
+    {
+      // the host's own operation: this instantiation, compiled at run time with its statements (sdft_common.hip)
+      char name[256];
+      snprintf(name, sizeof(name), "sdfthip::forward_rows_kernel<%s, %d, %d, %s, %d, %d, %s, %s, false>", type_name<FD>(), BPL, WIN,
+               FUSED ? "true" : "false", S, SYN, LAT1 ? "true" : "false", type_name<TD>());
+      hipFunction_t fn = nullptr;
+      if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
+      if (syn_lds(SYN) > (size_t)64 * 1024)
+        SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
+      ForwardArgs<FD> a1 = fa; FuseArgs<TD, FD> f1 = fz; SelfArgs<TD, FD> s1{};
+      void* args[] = {&a1, &f1, &s1};
+      SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, threads, 1, 1, (unsigned)syn_lds(SYN), stream, args, nullptr));
+      return true;
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(SYN), stream, fa, fz, SelfArgs<TD, FD>{});
     SDFT_TRY(hipGetLastError());
     return true;
@@ -1945,11 +1965,12 @@ class Plan
   {
     if (n == 0) return true;
     if (!bind()) return false;
-    // public operation numbers (enum sdft_hip_op): 0 identity, 1 gain, 2 shift, 3 cgain, 4 gain_rows, 5 cgain_rows, 6 gate, 7 power
+    // public operation numbers (enum sdft_hip_op): 0 identity, 1 gain, 2 shift, 3 cgain, 4 gain_rows, 5 cgain_rows, 6 gate, 7 power,
+    // 8 expression
     const int op_public = op_kind;
-    if (op_public < 0 || op_public > 7) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
+    if (op_public < 0 || op_public > 8) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
     if ((op_public != 0) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
-    op_kind = op_public == 4 ? OP_GAIN : op_public == 5 ? OP_CGAIN : op_public == 6 ? OP_GATE : op_public == 7 ? OP_POWER : op_public;
+    op_kind = op_public == 4 ? OP_GAIN : op_public == 5 ? OP_CGAIN : op_public == 6 ? OP_GATE : op_public == 7 ? OP_POWER : op_public == 8 ? OP_USER : op_public;
     if (op_kind == OP_SHIFT && dfts) { set_error("sdft_hip_process_n", "a copy of the spectrum is not available with the shift operation"); return false; }
     const bool yd = on_device(y);
     if (nbins == 0)
@@ -1983,6 +2004,17 @@ class Plan
     }
     else if (op_kind == OP_SHIFT) op.shift = *static_cast<const long*>(params);
     else if (op_kind == OP_GATE || op_kind == OP_POWER) { const FD* q = static_cast<const FD*>(params); op.p0 = q[0]; op.p1 = q[1]; }   // host memory
+    else if (op_kind == OP_USER)
+    {
+      // { expr, p, np }: the parameters travel to the device with the call (host memory; np may be 0)
+      struct expr_t { const char* expr; const void* p; size_t np; };
+      const expr_t* ex = static_cast<const expr_t*>(params);
+      if (!ex->expr || !*ex->expr) { set_error("sdft_hip_process_n", "expression: no statements"); return false; }
+      user_expr = ex->expr;
+      if (!d_gain.reserve(std::max<size_t>(ex->np, 1))) return false;
+      if (ex->np) SDFT_TRY(hipMemcpyAsync(d_gain.p, ex->p, ex->np * sizeof(FD), hipMemcpyHostToDevice, stream));
+      op.gain = d_gain.p;
+    }
     const bool linear = op_is_linear<FD>(op_kind);
     const bool one_vector = op.rows <= 1;
 
@@ -2061,8 +2093,13 @@ class Plan
         fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
         const size_t mstride = dfts ? n * nbins : m * nbins;
         SpectralOp<FD> ops = op; ops.t0 = t;                  // gain vectors count from the start of the call
+        if (op_kind == OP_USER)                               // the host's operation rewrites the rows in place, then plain synthesis
+          ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && user_rows(mat, mstride, m, ops) && inverse_device(m, mat, mstride, nullptr, ys + t, n, nullptr);
+        else
+        {
         ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &ops);
         if (ok && (op_kind == OP_GAIN || op_kind == OP_CGAIN || op_kind >= OP_GATE) && dfts) ok = scale_rows(mat, mstride, m, ops);
+        }
       }
     }
     if (!ok) return false;
@@ -2072,6 +2109,21 @@ class Plan
       return synchronize();
     }
     return finish(channels * n * nbins);
+  }
+
+  // the host's own operation on stored rows (two-pass route): user_rows_kernel compiled at run time with its statements
+  bool user_rows(fdx* mat, size_t stride, size_t rows, const SpectralOp<FD>& op)
+  {
+    char name[96];
+    snprintf(name, sizeof(name), "sdfthip::user_rows_kernel<%s>", type_name<FD>());
+    hipFunction_t fn = nullptr;
+    if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
+    const size_t total = channels * rows * nbins;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+    fdx* a0 = mat; size_t a1 = stride, a2 = rows; unsigned a3 = (unsigned)nbins, a4 = (unsigned)channels; size_t a5 = op.t0; const FD* a6 = op.gain;
+    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6};
+    SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+    return true;
   }
 
   // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)

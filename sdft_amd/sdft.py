@@ -202,14 +202,16 @@ class SDFT:
 
 
     def process(self, x, op="identity", gain=None, shift=0, out=None, dfts=None, hop=0, threshold=0.0, floor=0.0,
-                exponent=1.0, scale=1.0):
+                exponent=1.0, scale=1.0, expr=None, expr_params=()):
         """Fused analysis -> spectral operation -> synthesis (``sdft_hip_process_n``): returns the
         processed samples; the DFT matrix is not materialised unless ``dfts`` (a CUDA tensor of shape
         (n, dftsize) [(channels, n, dftsize)]) asks for a copy of the processed spectrum.
 
         ``op``: "identity", "gain" (``gain`` = real array of dftsize factors), "cgain" (``gain`` = complex array),
         "shift" (``shift`` bins), "gain_rows" / "cgain_rows" (``gain`` = (rows, dftsize) array, row r for the call's samples
-        [r*hop, (r+1)*hop), the last row for the rest), "gate" (``threshold``, ``floor``) or "power" (``exponent``, ``scale``).
+        [r*hop, (r+1)*hop), the last row for the rest), "gate" (``threshold``, ``floor``), "power" (``exponent``, ``scale``) or
+        "expr" (``expr`` = HIP C++ statements on ``re``, ``im`` of bin ``k`` at sample ``t`` of channel ``ch`` with the
+        parameters ``p[i]`` = ``expr_params``; compiled into the kernel at run time, see sdft_hip.h).
         """
         kind = OPS[op] if isinstance(op, str) else int(op)
         params = None
@@ -229,6 +231,14 @@ class SDFT:
             class _Table(C.Structure):
                 _fields_ = [("gains", C.c_void_p), ("rows", C.c_size_t), ("hop", C.c_size_t)]
             keep = (_Table(gptr, rows, int(hop)), keep_rows)
+            params = C.cast(C.byref(keep[0]), C.c_void_p)
+        elif kind == OPS["expr"]:
+            pv = np.ascontiguousarray(expr_params, dtype=self.fd).reshape(-1)
+            text = C.c_char_p(str(expr).encode())
+
+            class _Expr(C.Structure):
+                _fields_ = [("expr", C.c_char_p), ("params", C.c_void_p), ("nparams", C.c_size_t)]
+            keep = (_Expr(text, pv.ctypes.data if pv.size else None, int(pv.size)), pv, text)
             params = C.cast(C.byref(keep[0]), C.c_void_p)
         elif kind in (OPS["gate"], OPS["power"]):
             vals = (threshold, floor) if kind == OPS["gate"] else (exponent, scale)

@@ -202,3 +202,29 @@ def test_relay_form_is_what_it_claims(hip_library):
     d = disassemble("f32f64", hip_library)
     dbl = "\n".join(d["carry_relay_kernel<double, 64, false>"])
     assert len(re.findall(r"v_mov_b32_dpp v1[23], v\d+ row_newbcast:\d+", dbl)) >= 128 and "scratch_" not in dbl
+
+
+def test_expression_operation_compiles_without_a_gpu(hip_library):
+    """sdft_hip_op_expr: the library carries the text of its kernels and compiles a host's statements into them at run time
+    (hiprtc).  No GPU is needed to compile: good statements give a code object for the two-pass kernel (both bin types) and
+    the fused kernel, bad ones the compiler's words through sdft_hip_last_error()."""
+    import ctypes
+    try:
+        ctypes.CDLL("libhiprtc.so")
+    except OSError:
+        try:
+            ctypes.CDLL("/opt/rocm/lib/libhiprtc.so")
+        except OSError:
+            pytest.skip("no libhiprtc.so here")
+    from sdft_amd import capi
+    lib = capi.load()
+    lib.sdft_hip_clear_error()
+    good = b"const sdft_fd_t m2 = re * re + im * im; const sdft_fd_t g = m2 / (m2 + p[0] * (1 + k)) * cos((sdft_fd_t)t * p[1]) * (1 + ch); re *= g; im *= g;"
+    assert lib.sdft_hip_check_expr(good, None) == 0, lib.sdft_hip_last_error()
+    assert lib.sdft_hip_check_expr(good, b"gfx942") == 0, lib.sdft_hip_last_error()       # the target is the device's, whatever it is
+    assert lib.sdft_hip_check_expr(b"re = no_such_thing;", None) == -1
+    text = lib.sdft_hip_last_error().decode()
+    assert "does not compile" in text and "no_such_thing" in text and "sdft_user_expr.inc:1" in text
+    lib.sdft_hip_clear_error()
+    assert lib.sdft_hip_check_expr(b"", None) == -1 and lib.sdft_hip_check_expr(None, None) == -1
+    lib.sdft_hip_clear_error()

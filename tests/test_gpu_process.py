@@ -428,3 +428,81 @@ def test_many_channels_long_call_takes_the_fused_kernel():
         for c in range(C):
             ref = O.best(m, "hann", 1.0, "f32f64")
             assert rel_err(got[c], ref.isdft(ref.sdft(x[c]))) <= 1e-6
+
+
+EXPR = ("const sdft_fd_t m2 = re * re + im * im;"
+        "const sdft_fd_t g = m2 / (m2 + p[0] * (sdft_fd_t)(1 + k)) * (p[1] + p[2] * cos((sdft_fd_t)t * p[3])) * (sdft_fd_t)(1 + ch);"
+        "re *= g; im *= g;")
+
+
+def expr_reference(ref, x, pv, ch=0, t0=0):
+    """EXPR in numpy on the oracle's spectrum (a smooth function of the bin: no threshold a rounding could cross)."""
+    d = ref.sdft(x)
+    k = np.arange(d.shape[1])[None, :]
+    t = (t0 + np.arange(d.shape[0]))[:, None]
+    m2 = d.real.astype(np.float64) ** 2 + d.imag.astype(np.float64) ** 2
+    g = m2 / (m2 + pv[0] * (1 + k)) * (pv[1] + pv[2] * np.cos(t * pv[3])) * (1 + ch)
+    out = (d * g).astype(d.dtype)
+    return ref.isdft(out), out
+
+
+@pytest.mark.parametrize("combo,m,window", [("f32f64", 1024, "hann"), ("f32f32", 512, "hamming"), ("f64f64", 100, "blackman"), ("f32f64", 2048, "boxcar"),
+                                            ("f32f64", 2500, "hann"), ("f64f32", 64, "hann")])
+def test_operation_handed_in_as_code(combo, m, window):
+    """sdft_hip_op_expr: the host's statements run on every windowed bin inside the fused kernel (compiled at run time), or on
+    the stored rows where no workgroup holds a row / the call is one time chunk; against oracle-sdft -> numpy -> oracle-isdft."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    n = 9000
+    x = (noise(n, seed=21, dtype=td) * 0.5 + sine_sweep(n, dtype=td) * 0.5).astype(td)
+    pv = [0.3, 0.8, 0.2, 0.01]
+    tol = TOL[combo[3:]]
+    ref = O.best(m, window, 1.0, combo)
+    want, dwant = expr_reference(ref, x, pv)
+    with make(m, window, 1.0, combo) as p:
+        got = p.process(torch.from_numpy(x).cuda(), "expr", expr=EXPR, expr_params=pv).cpu().numpy()
+        assert p.get_option("last_process_path") == (1 if m <= 2048 else 3), p.get_option("last_process_path")
+        assert rel_err(got, want) <= tol, (combo, m, rel_err(got, want))
+        # a hop-sized call (one time chunk: analysis -> expression on the rows -> synthesis), host pointers
+        hop = (x[:150] * 0.7).astype(td)
+        wh, _ = expr_reference(ref, hop, pv)
+        assert rel_err(p.process(hop, "expr", expr=EXPR, expr_params=pv), wh) <= tol
+        assert p.get_option("last_process_path") == 2
+    # the processed spectrum on request; other parameters with the same (cached) code
+    ref = O.best(m, window, 1.0, combo)
+    pv2 = [0.05, 1.0, 0.5, 0.002]
+    want, dwant = expr_reference(ref, x, pv2)
+    with make(m, window, 1.0, combo) as p:
+        dd = torch.empty((n, m), dtype=getattr(torch, np.dtype(fdx).name), device="cuda")
+        got = p.process(torch.from_numpy(x).cuda(), "expr", expr=EXPR, expr_params=pv2, dfts=dd).cpu().numpy()
+        assert rel_err(got, want) <= tol and rel_err(dd.cpu().numpy(), dwant) <= tol
+
+
+def test_operation_handed_in_as_code_batched_and_errors():
+    import torch
+    from sdft_amd.capi import SdftHipError
+    C, m, n = 3, 256, 7000
+    x = np.stack([noise(n, seed=400 + c) for c in range(C)])
+    pv = [0.2, 1.0, 0.1, 0.02]
+    with make(m, "hann", 1.0, "f32f64", C) as p:
+        got = p.process(torch.from_numpy(x).cuda(), "expr", expr=EXPR, expr_params=pv).cpu().numpy()
+        for c in range(C):
+            ref = O.best(m, "hann", 1.0, "f32f64")
+            want, _ = expr_reference(ref, x[c], pv, ch=c)
+            assert rel_err(got[c], want) <= 1e-6, (c, rel_err(got[c], want))
+    # reference order of the sum (fused_exact = 1) with an expression that is exact in any arithmetic: bit-identical at FD float
+    m, n = 512, 6000
+    x1 = noise(n, seed=410)
+    ref = O.best(m, "hamming", 1.0, "f32f32")
+    d = ref.sdft(x1)
+    d[:, 1::2] = 0
+    want = ref.isdft(d)
+    with make(m, "hamming", 1.0, "f32f32", fused_exact=1) as p:
+        got = p.process(x1, "expr", expr="if (k & 1) { re = 0; im = 0; }")
+        assert np.array_equal(got, want)
+        # statements that do not compile: the compiler's words, and the plan goes on
+        with pytest.raises(SdftHipError) as e:
+            p.process(x1, "expr", expr="re = nonsense(im);")
+        assert "does not compile" in str(e.value) and "nonsense" in str(e.value)
+        ref.reset(); p.reset()
+        assert np.array_equal(p.sdft(x1[:3000]), ref.sdft(x1[:3000]))
