@@ -67,7 +67,8 @@ Rtc g_rtc;
 bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std::string& lowered_name, std::vector<char>& code)
 {
   if (!g_rtc.open()) { set_error("sdft_hip_process_n (expression)", "libhiprtc.so could not be opened (the operation is compiled at run time)"); return false; }
-  const std::string source = std::string("#define SDFT_USER_EXPR 1\n") + kKernelSource;
+  // (SDFT_FIXED_OP: the kernel serves OP_USER only -- the dispatch on the operation and the other operations' code go)
+  const std::string source = std::string("#define SDFT_USER_EXPR 1\n#define SDFT_FIXED_OP 6\n") + kKernelSource;
   const std::string body = std::string(expr) + "\n";
   const char* headers[] = {body.c_str()};
   const char* include_names[] = {"sdft_user_expr.inc"};

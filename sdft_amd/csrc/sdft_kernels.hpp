@@ -3017,6 +3017,12 @@ template <typename FD> struct SpectralOp
   FD p0, p1;                  // OP_GATE: threshold, floor; OP_POWER: exponent, scale
 };
 template <typename FD> SDFT_HD bool op_is_linear(int kind) { return kind <= OP_CGAIN; }
+// the operation a kernel serves: the library's own build dispatches on SpectralOp::kind at run time; a run-time
+// compilation (the host's statements) is for one operation, and every other branch leaves the code
+#ifndef SDFT_FIXED_OP
+#define SDFT_FIXED_OP -1
+#endif
+template <typename FD> SDFT_D int op_kind_of(const SpectralOp<FD>& op) { return SDFT_FIXED_OP >= 0 ? SDFT_FIXED_OP : op.kind; }
 // the gain vector of row t of the launch
 template <typename FD> SDFT_D const FD* gain_row(const SpectralOp<FD>& op, size_t t, unsigned nbins)
 {
@@ -3315,7 +3321,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const unsigned term_bins = (unsigned)(nv * kWave * BPL);
   const unsigned term_stride = term_bins + 16u / (unsigned)sizeof(FD);
   GainCursor<FD> gcur;                                     // SYN: the gain vector of the sample being finished
-  if constexpr (SYN != 0) gcur.start(fz.op, t0, a.nbins); else gcur.g = nullptr;
+  const int opk = op_kind_of(fz.op);
+  const bool op_has_rows = opk == OP_GAIN || opk == OP_CGAIN;
+  gcur.g = nullptr; gcur.left = 0;
+  if constexpr (SYN != 0) { if (op_has_rows) gcur.start(fz.op, t0, a.nbins); }
   size_t gtime = t0;                                       // time of the next sample finish() sees
 
   auto publish = [&](const cx<FD> (&x)[S][BPL], int buf, int u)
@@ -3339,7 +3348,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   auto finish = [&](const cx<FD> (&xin)[S][BPL], int buf, int u)
   {
-    if constexpr (SYN != 0) { gcur.seek(gtime); ++gtime; }
+    if constexpr (SYN != 0) { if (op_has_rows) gcur.seek(gtime); ++gtime; }
 #pragma unroll
     for (int q = 0; q < S; ++q)
     {
@@ -3391,13 +3400,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
         for (int b = 0; b < BPL; ++b)
         {
           const unsigned k = off_elems[q] + (unsigned)b;
-          if (fz.op.kind == OP_GAIN) y[b] = cscale(y[b], gcur.g[keep[q][b] ? k : 0]);
-          else if (fz.op.kind == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(gcur.g)[keep[q][b] ? k : 0]);
+          if (opk == OP_GAIN) y[b] = cscale(y[b], gcur.g[keep[q][b] ? k : 0]);
+          else if (opk == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(gcur.g)[keep[q][b] ? k : 0]);
 #ifdef SDFT_USER_EXPR
-          else if (fz.op.kind == OP_USER) { if (keep[q][b]) y[b] = user_op(y[b], k, a.nbins, gtime - 1, ch, fz.op.gain); }
+          else if (opk == OP_USER) y[b] = user_op(y[b], k < a.nbins ? k : 0u, a.nbins, gtime - 1, ch, fz.op.gain);
 #endif
-          else if (fz.op.kind >= OP_GATE) y[b] = op_pointwise(y[b], fz.op);
-          SpectralOp<FD> shift_only = fz.op; shift_only.kind = fz.op.kind == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
+          else if (opk >= OP_GATE) y[b] = op_pointwise(y[b], fz.op);
+          SpectralOp<FD> shift_only = fz.op; shift_only.kind = opk == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
           shift_only.gain = nullptr;
           const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
           terms[((size_t)buf * G + (size_t)u) * term_stride + k] = keep[q][b] ? term : (FD)0;

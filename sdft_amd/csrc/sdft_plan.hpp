@@ -1606,6 +1606,19 @@ class Plan
     return synchronize();
   }
 
+  // calls whose kernels read and wrote the caller's host memory in place (map_host): always complete on return, and
+  // through the stream's own synchronisation -- the point at which the runtime promises the host sees what the device
+  // wrote over PCIe (a stream query that reports "done" first keeps the wait short; the synchronisation then returns at once)
+  bool finish_mapped(size_t work)
+  {
+    const bool saved = async; async = false;
+    const bool ok = finish(work);
+    async = saved;
+    if (!ok) return false;
+    SDFT_TRY(hipStreamSynchronize(stream));
+    return true;
+  }
+
   // Pointer classification, cached per distinct pointer value: hosts that stream through the same
   // buffers call after call pay hipPointerGetAttributes once per buffer.  (A cached answer would
   // be stale only if a device allocation were freed and the very same address handed out again as
@@ -1730,10 +1743,7 @@ class Plan
       if (xm && om)
       {
         const bool ok = forward_device(n, xm, n, om, n * nbins, nullptr);
-        const bool saved = async; async = false;           // host memory: complete on return, through the stream
-        const bool done = ok && finish(channels * n * nbins);
-        async = saved;
-        return done;
+        return ok && finish_mapped(channels * n * nbins);   // host memory: complete on return, through the stream
       }
     }
     // staged path (host pointers): time segments so that the staging matrix stays bounded;
@@ -1851,10 +1861,7 @@ class Plan
           const hipError_t e = hipMemcpyAsync(y, ym, channels * n * sizeof(TD), hipMemcpyDeviceToHost, stream);
           if (e != hipSuccess) { set_error("hipMemcpyAsync", hipGetErrorString(e)); ok = false; }
         }
-        const bool saved = async; async = false;
-        const bool done = ok && finish(channels * n * nbins);
-        async = saved;
-        return done;
+        return ok && finish_mapped(channels * n * nbins);
       }
     }
     const size_t row_bytes = channels * nbins * sizeof(fdx);

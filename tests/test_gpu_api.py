@@ -424,21 +424,21 @@ def test_host_buffers_mapped_in_place():
         x2 = noise(3000, seed=22)
         big = np.zeros((x2.size, m), dtype=np.complex128)
         p.api.sdft_n(p._p, x2.size, C.c_void_p(x2.ctypes.data), C.c_void_p(big.ctypes.data))
-        assert rel(big, ref.sdft(x2)) <= 1e-11
+        assert rel(big, ref.sdft(x2)) <= 1e-11, ("registered 48 MB buffer", rel(big, ref.sdft(x2)), p.get_option("host_register_misses"))
         y2 = np.zeros(x2.size, dtype=np.float32)
         p.api.isdft_n(p._p, x2.size, C.c_void_p(big.ctypes.data), C.c_void_p(y2.ctypes.data))
         assert np.array_equal(y2, ref.isdft(big))
         # memory the host pinned itself
         small = np.zeros((7, m), dtype=np.complex128)              # below 1 MiB: staged (heap neighbours share pages)
         p.api.sdft_n(p._p, 7, C.c_void_p(x.ctypes.data), C.c_void_p(small.ctypes.data))
-        assert rel(small, ref.sdft(x[:7])) <= 1e-11               # (the 3000-sample call was chunk-parallel: no longer bit for bit)
+        assert rel(small, ref.sdft(x[:7])) <= 1e-11, "small buffer (staged)"   # (the 3000-sample call was chunk-parallel: no longer bit for bit)
         pinned = torch.empty((hop, m), dtype=torch.complex128).pin_memory()
         p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data), C.c_void_p(pinned.data_ptr()))
-        assert rel(pinned.numpy(), ref.sdft(x[:hop])) <= 1e-11
+        assert rel(pinned.numpy(), ref.sdft(x[:hop])) <= 1e-11, "memory pinned by the host"
         # off: the staged path, same bits
         p.set_option("host_register", 0)
         p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 400), C.c_void_p(buf.ctypes.data))
-        assert rel(buf, ref.sdft(x[100:200])) <= 1e-11
+        assert rel(buf, ref.sdft(x[100:200])) <= 1e-11, "option off again: staged"
         assert p.api.last_error() is None
 
 

@@ -212,6 +212,12 @@ def test_stream_filter_example(tmp_path, hip_library):
     f = np.fft.rfftfreq(n - 4000, 1.0 / rate)
     low, high = spec[np.abs(f - 500.0).argmin()], spec[np.abs(f - 8000.0).argmin()]
     assert high < 1e-4 * low, (low, high)
+    # the same mask handed in as code from C (sdft_hip_op_expr; sdft_hip_expr_t crosses the C-ABI): the same samples
+    r = subprocess.run([str(exe), str(m), str(hop), str(cutoff), str(tmp_path / "in.wav"), str(tmp_path / "out2.wav"), "code"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    got2 = np.frombuffer(open(tmp_path / "out2.wav", "rb").read()[44:], dtype=np.float32)
+    assert got2.size == n and np.abs(got2 - want).max() <= 1e-6 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("rccl", [True, False], ids=["rccl", "no_rccl"])
