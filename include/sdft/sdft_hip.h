@@ -137,6 +137,9 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        coefficients, sum over bins by a tree), 1 = bins summed in the reference's order by the
                        fastest route that gives those bits, 2 = in that order by the fused kernel,
                        -1 (default) = 1 when the host set carry = 1 at FD double, else 0
+                       (float samples from double bins: the reference's bits are proven from the tree sum and a bound on
+                       what any summation order can differ by; only samples whose bound straddles a rounding boundary of the
+                       float are summed in order -- get_option "ordered_walks" counts them)
    "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
    "fuse_delta"    1 (default) = chunk-parallel calls form the sample differences inside the carry kernel
    "pointers"      0 = classify each distinct pointer once (the last 8 are cached; sdft_reset, sdft_hip_set_state and

@@ -3134,6 +3134,7 @@ template <typename TD, typename FD> struct FuseArgs
   FD sweight;
   SpectralOp<FD> op;
   int store;                  // also write the processed rows to ForwardArgs::out
+  unsigned* walked;           // SYN = 2, float samples: counts the samples whose sum had to be walked in order (or nullptr)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -3461,7 +3462,43 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     {
       TD* yo = fz.y + ch * fz.y_stride + gt;
       const FD* tbase = terms + (size_t)tb * G * term_stride;
-      if constexpr (SYN == 2)
+      if constexpr (SYN == 2 && sizeof(TD) == 4 && sizeof(FD) == 8)
+      {
+        // The reference's bits without the reference's order, where the output sample is a float: y = (float)(sum * w) is a
+        // monotone function of the double sum, ANY order of the n additions is within g = n*2^-53/(1 - n*2^-53) times
+        // sum|term| of the exact sum (the reference's order too), so the reference's sum lies within e = 2*g*sum|term| of
+        // the tree sum -- and when both ends of that interval round to the same float, that float is the reference's
+        // sample.  Otherwise (the interval straddles a rounding boundary of the float: a fraction of a percent of the
+        // samples) the wave walks the terms in ascending order as the reference does (sdft.h:641-651).  NaNs fail the
+        // comparison and take the walk.
+        for (int u = wave; u < gm; u += nwaves)
+        {
+          const FD* tr = tbase + (size_t)u * term_stride;
+          FD part = (FD)0, mag = (FD)0;
+          for (unsigned k = lane; k < term_bins; k += kWave) { const FD v = tr[k]; part += v; mag += __builtin_fabs(v); }
+          const FD sum = wave_sum_f(part), all = wave_sum_f(mag);
+          const FD e = all * ((FD)2.5e-16 * (FD)term_bins);               // 2*g*sum|term| with 12 % to spare (g ~ n * 1.11e-16)
+          const TD ylo = (TD)((sum - e) * fz.sweight), yhi = (TD)((sum + e) * fz.sweight);
+          TD out = ylo;
+          if (!(ylo == yhi))                                                // wave-uniform: every lane holds the same sums
+          {
+            typedef FD tvec __attribute__((ext_vector_type(2)));
+            FD ordered = (FD)0;
+            for (unsigned k0 = 0; k0 < term_bins; k0 += 16)                 // term_bins is a multiple of 64
+            {
+              tvec tv[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const tvec*>(tr + k0 + i * 2);     // broadcast reads
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { ordered += tv[i][0]; ordered += tv[i][1]; }
+            }
+            out = (TD)(ordered * fz.sweight);                                  // sdft.h:654-656
+            if (lane == 0 && fz.walked) atomicAdd(fz.walked, 1u);
+          }
+          if (lane == 0) yo[u] = out;
+        }
+      }
+      else if constexpr (SYN == 2)
       {
         // the reference's order (sdft.h:641-651): lane u of wave 0 adds sample u's terms bin by bin
         if (wave == 0 && lane < gm)
@@ -4527,6 +4564,12 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
   const bool vec_ok = (BPL == 1) || ((a.nbins % 2 == 0) && (((uintptr_t)row & 15) == 0));
 
   FD sum = (FD)0;
+  // float samples from double bins, rows of one LDS block: the rounding-interval test of forward_rows_kernel<SYN = 2> --
+  // the tree sum and 2*n*2^-53*sum|term| bound the reference's ordered sum; when both ends of the interval round to the
+  // same float the N dependent additions are not needed (most rows), else they are made as before.  Same bits either way.
+  constexpr bool kInterval = sizeof(TD) == 4 && sizeof(FD) == 8;
+  bool decided = false;
+  TD decided_y = (TD)0;
   for (unsigned k0 = 0; k0 < a.nbins; k0 += TB)
   {
     cx<FD> v[NL][BPL];
@@ -4561,6 +4604,21 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
         const unsigned k = k0 + kl;
         terms[kl] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins, grow);
       }
+    if constexpr (kInterval)
+    {
+      if (a.nbins <= (unsigned)TB)                           // (wave-uniform; bins past N-1 park +0)
+      {
+        FD part = (FD)0, mag = (FD)0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) { const FD tv = terms[(unsigned)(i * kWave + lane) * BPL + b]; part += tv; mag += __builtin_fabs(tv); }
+        const FD tree = wave_sum_f(part), all = wave_sum_f(mag);
+        const FD e = all * ((FD)2.5e-16 * (FD)TB);
+        const TD ylo = (TD)((tree - e) * a.sweight), yhi = (TD)((tree + e) * a.sweight);
+        if (ylo == yhi) { decided = true; decided_y = ylo; break; }
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const unsigned cnt = (a.nbins - k0 < (unsigned)TB) ? a.nbins - k0 : (unsigned)TB;
@@ -4586,7 +4644,7 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
   }
   if (lane == 0)
   {
-    a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);                                 // sdft.h:654-656
+    a.y[ch * a.y_stride + t] = decided ? decided_y : (TD)(sum * a.sweight);           // sdft.h:654-656
     signal_done(a.done);
   }
 }

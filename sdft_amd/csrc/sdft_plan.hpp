@@ -265,7 +265,7 @@ class Plan
     forget_host_buffers();
     if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
     d_ready.release();
-    d_done_count.release();
+    d_done_count.release(); d_walked.release();
     d_run_acc[0].release(); d_run_acc[1].release(); d_run_fid[0].release(); d_run_fid[1].release();
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
@@ -1171,6 +1171,25 @@ class Plan
   unsigned* h_done_flag = nullptr;
   unsigned* d_done_flag = nullptr;
   DevBuf<unsigned> d_done_count;
+  // fused call in the reference's order with float samples: samples whose sum was walked bin by bin (the others were
+  // proven by the rounding interval of the tree sum: forward_rows_kernel<SYN = 2>); get_option "ordered_walks"
+  DevBuf<unsigned> d_walked;
+  unsigned* walked_counter()
+  {
+    if (!d_walked.p)
+    {
+      if (!d_walked.reserve(1)) { (void)hipGetLastError(); return nullptr; }
+      if (hipMemsetAsync(d_walked.p, 0, sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return d_walked.p;
+  }
+  long ordered_walks() const
+  {
+    if (!d_walked.p) return 0;
+    unsigned v = 0;
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&v, d_walked.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (long)v;
+  }
   unsigned flag_seq = 0;
   bool flag_pending = false, flag_wanted = false;
   bool ensure_flag()
@@ -2061,8 +2080,9 @@ class Plan
     else if ((fuse_ok() || (linear && op.rows <= 65535u && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && nbins <= (size_t)4 * kWave * kRowWavesMax))
              && (chunks > 1 || n > (size_t)kHopMax) && !walk_loses)       // (many channels: one chunk per channel, however long)
     {
-      FuseArgs<TD, FD> fz;
+      FuseArgs<TD, FD> fz{};
       fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
+      fz.walked = walked_counter();
       if (!dfts) { if (!fold_coefficients(op)) return false; } else coeff_ready = false;
       last_process_path = 1;
       flag_wanted = xd && yd;

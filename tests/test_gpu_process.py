@@ -506,3 +506,28 @@ def test_operation_handed_in_as_code_batched_and_errors():
         assert "does not compile" in str(e.value) and "nonsense" in str(e.value)
         ref.reset(); p.reset()
         assert np.array_equal(p.sdft(x1[:3000]), ref.sdft(x1[:3000]))
+
+
+def test_reference_bits_by_rounding_interval():
+    """fused_exact with float samples and double bins: the tree sum of a sample's terms plus the bound on what ANY summation
+    order can differ by (2 * n * 2^-53 * sum|term|) pins the float the reference's ordered sum rounds to, unless the interval
+    straddles a rounding boundary -- then the terms are walked in order.  Bit-identical either way; both ways must occur."""
+    import torch
+    for m, window, n in ((1024, "hann", 60000), (2048, "blackman", 24000), (300, "hamming", 40000)):
+        x = (noise(n, seed=61) * 0.3 + sine_sweep(n) * 0.7).astype(np.float32)
+        ref = O.best(m, window, 1.0, "f32f64")
+        gain = np.linspace(1.0, 0.2, m)
+        d = ref.sdft(x)
+        want = ref.isdft((d * gain[None, :]).astype(d.dtype))
+        with make(m, window, 1.0, "f32f64", carry=1, fused_exact=2) as p:
+            got = p.process(torch.from_numpy(x).cuda(), "gain", gain=gain).cpu().numpy()
+            assert p.get_option("last_fused_exact") == 1 and p.get_option("last_process_path") == 1
+            assert np.array_equal(got, want), (m, int((got != want).sum()))
+            walks = p.get_option("ordered_walks")
+            assert 0 < walks < n // 20, (m, walks, n)              # a fraction of a percent to a few percent of the samples
+        # double samples have no rounding to hide behind: every sample is walked, same bits
+    x = noise(6000, seed=62, dtype=np.float64)
+    ref = O.best(256, "hann", 1.0, "f64f64")
+    with make(256, "hann", 1.0, "f64f64", carry=1, fused_exact=2) as p:
+        assert np.array_equal(p.process(x, "identity"), ref.isdft(ref.sdft(x)))
+        assert p.get_option("ordered_walks") == 0                    # (the counter belongs to the interval test)
