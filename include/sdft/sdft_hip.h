@@ -115,8 +115,10 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        twice the speed and land closer to the double-precision result than the reference's float
                        arithmetic does, but NOT within 1e-4 of the float reference (which itself drifts about 2e-4
                        of the largest bin per 262144 samples); the state then differs from the reference's by the same
-   "exact_inverse" 1 (default) = synthesis adds the bins of a row in the reference's order
-                       (bit-identical), 0 = wave-parallel tree sum
+   "exact_inverse" 1 (default) = synthesis gives the reference's bits (bins of a row added in the reference's order, or --
+                       float samples from double bins, option "inverse_verify" = 1 (default), up to "inverse_verify_max"
+                       rows -- a tree sum whose rounding interval proves the reference's float, rows it cannot prove
+                       added in order), 0 = wave-parallel tree sum, unverified
    "chunk"         samples per time chunk (0 = heuristic)
    "segments"      time segments of the exact carry pass overlapped with the forward launches
    "rows_kernel"   1 (default) = row-group forward kernel when the row fits, 0 = independent tiles

@@ -4393,9 +4393,13 @@ template <typename TD, typename FD> struct InverseArgs
   DoneSignal done;            // inverse_row_kernel only: total = rows
 };
 
-template <typename TD, typename FD, bool LAT1, bool OPS = false>
+// VERIFY (float samples from double bins): the reference's bits from the tree sum -- the rounding-interval test of
+// forward_rows_kernel<SYN = 2>; a row whose interval straddles a rounding boundary of the float is read again (it is in
+// cache) and added in ascending bin order, lane by lane.
+template <typename TD, typename FD, bool LAT1, bool OPS = false, bool VERIFY = false>
 __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 {
+  static_assert(!VERIFY || (sizeof(TD) == 4 && sizeof(FD) == 8), "the interval test needs a rounding to hide behind");
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
@@ -4408,15 +4412,39 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
     const size_t r = rows - 1 - ri;
     const size_t ch = r / a.n, t = r - ch * a.n;
     const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
-    FD part = (FD)0;
+    FD part = (FD)0, mag = (FD)0;
     const FD* grow = OPS ? gain_row(a.op, t, a.nbins) : nullptr;
 #pragma unroll 4
     for (unsigned k = lane; k < a.nbins; k += kWave)
     {
-      part += synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins, grow);
+      const FD tv = synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins, grow);
+      part += tv;
+      if constexpr (VERIFY) mag += __builtin_fabs(tv);
     }
     const FD sum = wave_sum(part);
-    if (lane == 0) a.y[ch * a.y_stride + t] = (TD)(sum * a.sweight);
+    TD out = (TD)(sum * a.sweight);
+    if constexpr (VERIFY)
+    {
+      const FD all = wave_sum(mag);
+      const FD e = all * ((FD)2.5e-16 * (FD)(a.nbins + kWave));
+      const TD ylo = (TD)((sum - e) * a.sweight), yhi = (TD)((sum + e) * a.sweight);
+      out = ylo;
+      if (!(ylo == yhi))                                   // wave-uniform (every lane holds the wave's sums)
+      {
+        FD ordered = (FD)0;
+        for (unsigned k0 = 0; k0 < a.nbins; k0 += kWave)
+        {
+          const unsigned k = k0 + (unsigned)lane;
+          const FD tv = k < a.nbins ? synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins, grow) : (FD)0;
+          const int lo = __double2loint(tv), hi = __double2hiint(tv);
+          const unsigned cnt = a.nbins - k0 < (unsigned)kWave ? a.nbins - k0 : (unsigned)kWave;
+          for (unsigned j = 0; j < cnt; ++j)               // sdft.h:641-651: one accumulator, ascending bins
+            ordered += __hiloint2double(__builtin_amdgcn_readlane(hi, (int)j), __builtin_amdgcn_readlane(lo, (int)j));
+        }
+        out = (TD)(ordered * a.sweight);
+      }
+    }
+    if (lane == 0) a.y[ch * a.y_stride + t] = out;
   }
 }
 

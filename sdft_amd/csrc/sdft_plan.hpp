@@ -133,7 +133,8 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
-  std::string user_expr;                                   // sdft_hip_process_expr_n: the statements of the call in flight
+  long opt_inverse_verify = 1, opt_inverse_verify_max = 500000, last_inverse_form = 0;   // launch_inverse
+  std::string user_expr;                                   // sdft_hip_process_n with an expression: the statements of the call in flight
   template <typename T> static const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
   // FD float plans take the chunk-parallel carries too: 2x faster on long calls and closer to the double-precision
   // result than the reference's float arithmetic is, but not within 1e-4 of it (the float reference itself drifts
@@ -1486,6 +1487,7 @@ class Plan
     if (!opt_exact_inverse)
     {
       hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+      last_inverse_form = 0;
       return;
     }
     // the reference's summation order.  Measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16:
@@ -1493,6 +1495,19 @@ class Plan
     // with 16 rows and one tile of look-ahead is a chain of N/16 memory round trips (~70 us whatever
     // n is): 4 rows with an 8-deep ring (n = 12000: 33 us against 79, n = 48000: 153 against 178,
     // n = 131072: 397 against 355); short calls (a hop of 100 rows): one wave per row
+    // float samples from double bins, medium calls: the tree-sum kernel with the rounding-interval test gives the same bits
+    // without the chain of dependent additions (n = 4096: 22.5 -> 11.8 us, 48000: 145 -> 132 us, 200000: 585 -> 550 us;
+    // from about half a million rows on the streaming kernel below is the faster one: 2.64 against 2.78 ms at n = 1e6)
+    if constexpr (sizeof(TD) == 4 && sizeof(FD) == 8)
+    {
+      if (opt_inverse_verify && opt_inverse_rows <= 0 && total_rows > 1024 && total_rows <= (size_t)opt_inverse_verify_max)
+      {
+        hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
+        last_inverse_form = 2;
+        return;
+      }
+    }
+    last_inverse_form = 1;
     long rw = opt_inverse_rows > 0 ? opt_inverse_rows
                                    : (total_rows <= 1024 ? 1 : total_rows < 65536 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
     if (OPS && rw != 1) rw = 16;                                                 // one streaming instantiation with the operation built in

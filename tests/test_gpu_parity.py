@@ -367,6 +367,28 @@ def test_inverse_is_bit_identical(combo, latency):
         assert np.array_equal(yb[c], refs[c].isdft(db[c]))
 
 
+@pytest.mark.parametrize("m,n,latency,channels", [(1024, 30000, 1.0, 1), (1000, 12000, 0.5, 1), (77, 50000, 1.0, 1), (2050, 3000, 1.0, 1), (256, 9000, 0.7, 3)])
+def test_inverse_bits_by_rounding_interval(m, n, latency, channels):
+    """Medium calls, float samples from double bins: the synthesis sums a row by a tree and proves the reference's float from
+    the bound on what any summation order can differ by; rows it cannot prove are added in ascending bin order.  Spectra
+    of any kind (not only what the analysis produces), the streaming kernel with the reference's order as the second witness."""
+    import torch
+    rng = np.random.default_rng(m + n)
+    d = (rng.standard_normal((channels, n, m)) * np.exp(rng.standard_normal((channels, n, 1)) * 3) + 1j * rng.standard_normal((channels, n, m))).astype(np.complex128)
+    d[:, ::7, :] *= 1e-9                                              # rows near zero, rows of mixed magnitude
+    d[:, 5::11, ::2] = 0
+    refs = [O.best(m, "hamming", latency, "f32f64") for _ in range(channels)]
+    want = np.stack([r.isdft(d[c]) for c, r in enumerate(refs)])
+    dd = torch.from_numpy(d if channels > 1 else d[0]).cuda()
+    with make(m, "hamming", latency, "f32f64", channels) as p:
+        got = p.isdft(dd).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 2
+        assert np.array_equal(got if channels > 1 else got[None], want), int((got != want).sum())
+        p.set_option("inverse_verify", 0)
+        old = p.isdft(dd).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 1 and np.array_equal(old, got)
+
+
 @pytest.mark.parametrize("combo,m,opts", [("f32f64", 2500, {"carry": 0, "chunk": 256}), ("f32f64", 2500, {"carry": 1, "chunk": 96, "segments": 3}),
                                           ("f32f32", 4100, {"chunk": 160, "segments": 4}), ("f64f64", 2049, {"carry": 0}),
                                           ("f32f32", 4096, {"rows_kernel": 0, "chunk": 128, "segments": 2})])
