@@ -1694,7 +1694,7 @@ class Plan
   size_t opt_host_register_max = (size_t)256 << 20;
   // registered page ranges [lo, hi) never overlap each other: a buffer inside a registered range uses that registration
   // (two registrations sharing a page would lose it when the first of them is dropped)
-  struct HostReg { uintptr_t lo, hi; char* dev; unsigned long long used; bool owned; };
+  struct HostReg { uintptr_t lo, hi; char* dev; unsigned long long used; bool owned, writable; };
   HostReg host_regs[8] = {};
   unsigned long long host_reg_clock = 0;
   long host_reg_hits = 0, host_reg_misses = 0;
@@ -1705,13 +1705,17 @@ class Plan
   }
   void forget_host_buffers() { for (HostReg& e : host_regs) drop_host(e); }
   // device-side address of a host buffer of `bytes` bytes, or nullptr (not used / not possible: take the staged path)
-  void* map_host(const void* p, size_t bytes)
+  void* map_host(const void* p, size_t bytes, bool will_write = false)
   {
     if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > opt_host_register_max) return nullptr;
     const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p);
     const uintptr_t lo = a & ~(page - 1), hi = (a + bytes + page - 1) & ~(page - 1);
     for (HostReg& e : host_regs)
-      if (e.hi && lo >= e.lo && hi <= e.hi) { e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.lo); }
+      if (e.hi && lo >= e.lo && hi <= e.hi)
+      {
+        if (will_write && !e.writable && e.owned) { drop_host(e); break; }   // registered for reading: again, with its pages made writable first
+        e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.lo);
+      }
     // anything that overlaps without covering goes first (its pages would be shared)
     for (HostReg& e : host_regs)
       if (e.hi && lo < e.hi && e.lo < hi) drop_host(e);
@@ -1723,16 +1727,25 @@ class Plan
     // memory the host pinned itself (hipHostMalloc, its own hipHostRegister) is mapped already
     if (hipHostGetDevicePointer(&dev, const_cast<void*>(p), 0) == hipSuccess && dev)
     {
-      *slot = HostReg{a, a + bytes, static_cast<char*>(dev), ++host_reg_clock, false};
+      *slot = HostReg{a, a + bytes, static_cast<char*>(dev), ++host_reg_clock, false, true};
       return dev;
     }
     (void)hipGetLastError();
+    if (will_write)
+    {
+      // an output buffer the host has never written (calloc, numpy.zeros) may still be mapped to the kernel's shared zero
+      // page, copy on write: every page gets its own writable frame BEFORE it is pinned (writing a byte back to itself --
+      // the buffer is ours to overwrite for the duration of the call), so that what the device writes is what the host reads
+      volatile char* q = reinterpret_cast<volatile char*>(a);
+      for (uintptr_t off = 0; off < bytes; off += page) q[off] = q[off];
+      q[bytes - 1] = q[bytes - 1];
+    }
     if (hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipHostGetDevicePointer(&dev, reinterpret_cast<void*>(lo), 0) != hipSuccess || !dev)
     {
       (void)hipGetLastError(); (void)hipHostUnregister(reinterpret_cast<void*>(lo)); (void)hipGetLastError(); return nullptr;
     }
-    *slot = HostReg{lo, hi, static_cast<char*>(dev), ++host_reg_clock, true};
+    *slot = HostReg{lo, hi, static_cast<char*>(dev), ++host_reg_clock, true, will_write};
     return static_cast<char*>(dev) + (a - lo);
   }
 
@@ -1766,7 +1779,7 @@ class Plan
       // (a hop's samples are a different slice of the host's signal every call: a few hundred bytes go through the
       // staging buffer, only buffers beyond 64 KiB are worth a registration)
       const bool small_x = channels * n * sizeof(TD) <= kSmallHostBytes;
-      fdx* om = od ? dfts : static_cast<fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
+      fdx* om = od ? dfts : static_cast<fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx), true));
       const TD* xm = xd ? x : ((x_class == 0 || small_x) ? nullptr : static_cast<const TD*>(map_host(x, channels * n * sizeof(TD))));
       if (om && !xm && !xd && small_x)
       {
@@ -1885,7 +1898,7 @@ class Plan
     {
       const bool small_y = channels * n * sizeof(TD) <= kSmallHostBytes;
       const fdx* im = id ? dfts : static_cast<const fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
-      TD* ym = yd ? y : (small_y ? nullptr : static_cast<TD*>(map_host(y, channels * n * sizeof(TD))));
+      TD* ym = yd ? y : (small_y ? nullptr : static_cast<TD*>(map_host(y, channels * n * sizeof(TD), true)));
       if (im && !ym && !yd && small_y) { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; }
       if (im && ym)
       {
