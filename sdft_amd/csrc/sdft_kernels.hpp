@@ -3023,6 +3023,7 @@ template <typename FD> SDFT_HD bool op_is_linear(int kind) { return kind <= OP_C
 #define SDFT_FIXED_OP -1
 #endif
 template <typename FD> SDFT_D int op_kind_of(const SpectralOp<FD>& op) { return SDFT_FIXED_OP >= 0 ? SDFT_FIXED_OP : op.kind; }
+template <int V> struct OpTag { static constexpr int value = V; };   // an operation known where the code is generated (-1: not)
 // the gain vector of row t of the launch
 template <typename FD> SDFT_D const FD* gain_row(const SpectralOp<FD>& op, size_t t, unsigned nbins)
 {
@@ -3051,14 +3052,14 @@ template <typename FD> struct GainCursor
   }
 };
 // the operations that are not linear in the spectrum, on one windowed bin
-template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>& op)
+template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>& op, int kind)
 {
-  if (op.kind == OP_GATE)
+  if (kind == OP_GATE)
   {
     const FD mag2 = v.re * v.re + v.im * v.im;
     return (mag2 < op.p0 * op.p0) ? cscale(v, op.p1) : v;
   }
-  if (op.kind == OP_POWER)
+  if (kind == OP_POWER)
   {
     const FD mag2 = v.re * v.re + v.im * v.im;
     // (FD float: |v| below 1e-19 -- a denormal square, which v_log_f32 would flush -- counts as zero)
@@ -3118,7 +3119,7 @@ SDFT_D FD synth_term(cx<FD> v, unsigned k, const SpectralOp<FD>& op, const cx<FD
       ko += op.shift;
       if (ko < 0 || ko >= (long)nbins) return (FD)0;
     }
-    else if (op.kind >= OP_GATE) v = op_pointwise(v, op);
+    else if (op.kind >= OP_GATE) v = op_pointwise(v, op, op.kind);
   }
   if constexpr (LAT1) return v.re * ((ko & 1) ? (FD)(-1) : (FD)(+1));               // sdft.h:643
   else { const cx<FD> sy = syn[ko < (long)nbins ? ko : 0]; return v.re * sy.re - v.im * sy.im; }   // re of :650
@@ -3347,8 +3348,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     }
   };
 
-  auto finish = [&](const cx<FD> (&xin)[S][BPL], int buf, int u)
+  // (optag: the operation as a compile-time constant -- the group loop below is generated once per operation and entered
+  // through one switch per group, so the per-sample code carries no dispatch and none of the other operations)
+  auto finish = [&](auto optag, const cx<FD> (&xin)[S][BPL], int buf, int u)
   {
+    constexpr int kOp = decltype(optag)::value;
+    const int opk = kOp >= 0 ? kOp : op_kind_of(fz.op);
+    const bool op_has_rows = opk == OP_GAIN || opk == OP_CGAIN;
     if constexpr (SYN != 0) { if (op_has_rows) gcur.seek(gtime); ++gtime; }
 #pragma unroll
     for (int q = 0; q < S; ++q)
@@ -3406,8 +3412,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 #ifdef SDFT_USER_EXPR
           else if (opk == OP_USER) y[b] = user_op(y[b], k < a.nbins ? k : 0u, a.nbins, gtime - 1, ch, fz.op.gain);
 #endif
-          else if (opk >= OP_GATE) y[b] = op_pointwise(y[b], fz.op);
-          SpectralOp<FD> shift_only = fz.op; shift_only.kind = opk == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
+          else if (opk >= OP_GATE) y[b] = op_pointwise(y[b], fz.op, opk);
+          SpectralOp<FD> shift_only = fz.op; shift_only.kind = op_kind_of(fz.op) == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
           shift_only.gain = nullptr;
           const FD term = synth_term<FD, LAT1, true>(y[b], k, shift_only, fz.syn, a.nbins);
           terms[((size_t)buf * G + (size_t)u) * term_stride + k] = keep[q][b] ? term : (FD)0;
@@ -3588,17 +3594,32 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     }
     __syncthreads();
     // phase B
-    if (m == G)
+    auto phase_b = [&](auto optag)
     {
+      if (m == G)
+      {
 #pragma unroll
-      for (int u = 0; u < G; ++u) finish(xs[u], buf, u);
-    }
-    else
+        for (int u = 0; u < G; ++u) finish(optag, xs[u], buf, u);
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          if (u < m) finish(optag, xs[u], buf, u);
+      }
+    };
+    if constexpr (SYN != 0 && SDFT_FIXED_OP < 0)
     {
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-        if (u < m) finish(xs[u], buf, u);
+      switch (opk)
+      {
+        case OP_GAIN:  phase_b(OpTag<OP_GAIN>{}); break;
+        case OP_CGAIN: phase_b(OpTag<OP_CGAIN>{}); break;
+        case OP_GATE:  phase_b(OpTag<OP_GATE>{}); break;
+        case OP_POWER: phase_b(OpTag<OP_POWER>{}); break;
+        default:       phase_b(OpTag<OP_IDENTITY>{}); break;          // identity and shift (the shift acts in synth_term)
+      }
     }
+    else phase_b(OpTag<(SYN != 0 && SDFT_FIXED_OP >= 0) ? SDFT_FIXED_OP : OP_IDENTITY>{});
     if constexpr (SYN != 0)
     {
       // phase C runs one group behind: the terms image is double-buffered, group g's terms are
@@ -4374,7 +4395,7 @@ __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t 
     const FD* g = gain_row(op, t, nbins);
     if (op.kind == OP_GAIN) *p = cscale(*p, g[k]);
     else if (op.kind == OP_CGAIN) *p = cmul(*p, reinterpret_cast<const cx<FD>*>(g)[k]);
-    else if (op.kind >= OP_GATE) *p = op_pointwise(*p, op);
+    else if (op.kind >= OP_GATE) *p = op_pointwise(*p, op, op.kind);
   }
 }
 
