@@ -76,7 +76,7 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
                            { expr, params, nparams }.  expr is a string of HIP C++ statements applied to every windowed
                            bin; in scope are  re, im  (sdft_fd_t; read and assign them: the value of bin k),  k, nbins
                            (unsigned),  t  (size_t: index of the sample within the call),  ch  (size_t: channel),
-                           p  (const sdft_fd_t*: the call's nparams parameters, copied from host memory with the call)
+                           p[i]  (sdft_fd_t, read-only: the call's nparams parameters, copied from host memory with the call)
                            and HIP's math functions.  Example (a gate with a frequency-dependent threshold):
                                "if (re * re + im * im < p[0] * p[0] * (1 + k)) { re = 0; im = 0; }"
                            The statements are compiled into the fused kernel at run time (hiprtc: libhiprtc.so is opened

@@ -94,6 +94,13 @@ bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std:
   if (ok) { lowered_name = low; ok = g_rtc.code_size(prog, &bytes) == HIPRTC_SUCCESS && bytes > 0; }
   if (ok) { code.resize(bytes); ok = g_rtc.code(prog, code.data()) == HIPRTC_SUCCESS; }
   g_rtc.destroy(&prog);
+  if (ok)
+    if (const char* dir = getenv("SDFT_HIP_RTC_DUMP"))       // development aid: the code object, for llvm-objdump / llvm-readelf
+    {
+      static int serial = 0;
+      const std::string path = std::string(dir) + "/sdft_rtc_" + std::to_string(serial++) + ".co";
+      if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    }
   if (!ok && !g_has_error) set_error("sdft_hip_process_n (expression)", "run-time compilation failed");
   return ok;
 }

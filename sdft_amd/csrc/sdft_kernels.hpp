@@ -3125,8 +3125,10 @@ template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>
 // In scope: re, im (sdft_fd_t, read and assign: the windowed value of bin k), k, nbins (unsigned), t (size_t: sample index
 // within the call), ch (size_t: channel), p (const sdft_fd_t*: the call's parameters, device memory), and HIP's math.
 #ifdef SDFT_USER_EXPR
-template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbins, size_t t, size_t ch, const FD* p)
+template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbins, size_t t, size_t ch, const FD* params)
 {
+  // (the parameters through the constant address space: scalar loads that nothing in the kernel can alias, so they leave the loop)
+  const SDFT_CONSTANT FD* p = as_uniform(params);
   typedef FD sdft_fd_t;
   FD re = v.re, im = v.im;
   {
