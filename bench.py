@@ -515,6 +515,9 @@ def main():
             wf = (time.perf_counter() - tf) / 5
             fp[label + "_msamples_s"] = round(count * n / wf / 1e6, 1)
             fp[label + "_ms"] = round(wf * 1e3, 3)
+            if fe:
+                # float samples: the reference's float is proven from the tree sum for most samples; the rest are walked in order
+                fp["reference_order_walked_frac"] = round(plan.get_option("ordered_walks") / (6.0 * count * n), 5)
         plan.set_option("fused_exact", -1)
         # round 3: gains that change every 512 samples (one launch: the folded coefficients of all gain vectors come from one
         # small launch in front), and a spectral gate (not linear: the windowed rows in LDS, tree sum)
