@@ -389,6 +389,54 @@ def test_inverse_bits_by_rounding_interval(m, n, latency, channels):
         assert p.get_option("last_inverse_form") == 1 and np.array_equal(old, got)
 
 
+@pytest.mark.parametrize("m,latency", [(1024, 1.0), (1000, 0.5), (64, 1.0)])
+def test_rows_on_a_rounding_boundary(m, latency):
+    """Adversarial rows for the rounding-interval test: bin 0 of a random row is bisected (with the CPU reference) to the
+    value at which the reference's float sample flips to its neighbour, and the row is offered at that value and a few
+    units in the last place around it -- sums that sit on a rounding boundary of the float, where only the reference's own
+    order decides.  Every form of the synthesis (row kernel, verified tree sum, streaming kernel) and the fused call in
+    the reference's order must reproduce the reference's choice."""
+    import torch
+    rng = np.random.default_rng(7 * m)
+    ref = O.best(m, "hann", latency, "f32f64")
+    rows = []
+    for _ in range(40):
+        row = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex128) * 10.0 ** rng.integers(-3, 4)
+        lo, hi = row[0].real - 1.0, row[0].real + 1.0
+        def y_at(v):
+            r = row.copy(); r[0] = complex(v, row[0].imag)
+            return ref.isdft(r[None, :])[0]
+        ylo, yhi = y_at(lo), y_at(hi)
+        if ylo == yhi:
+            continue
+        target = ylo
+        for _ in range(80):                                          # the largest v that still gives ylo
+            mid = 0.5 * (lo + hi)
+            if mid == lo or mid == hi:
+                break
+            if y_at(mid) == target: lo = mid
+            else: hi = mid
+        for steps in range(-3, 4):
+            v = lo
+            for _ in range(abs(steps)):
+                v = np.nextafter(v, np.inf if steps > 0 else -np.inf)
+            r = row.copy(); r[0] = complex(v, row[0].imag)
+            rows.append(r)
+    d = np.stack(rows)
+    n = d.shape[0]
+    assert n >= 100
+    want = ref.isdft(d)
+    assert len(np.unique(want)) > n // 8                              # the rows do straddle boundaries
+    reps = (2000 + n - 1) // n                                        # enough rows for the tree-sum and the streaming kernels
+    big = np.tile(d, (reps, 1)); wbig = np.tile(want, reps)
+    with make(m, "hann", latency, "f32f64") as p:
+        assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want)            # row kernel (<= 1024 rows)
+        got = p.isdft(torch.from_numpy(big).cuda()).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 2 and np.array_equal(got, wbig)                # verified tree sum
+        p.set_option("inverse_verify", 0)
+        assert np.array_equal(p.isdft(torch.from_numpy(big).cuda()).cpu().numpy(), wbig)           # streaming kernel
+
+
 @pytest.mark.parametrize("combo,m,opts", [("f32f64", 2500, {"carry": 0, "chunk": 256}), ("f32f64", 2500, {"carry": 1, "chunk": 96, "segments": 3}),
                                           ("f32f32", 4100, {"chunk": 160, "segments": 4}), ("f64f64", 2049, {"carry": 0}),
                                           ("f32f32", 4096, {"rows_kernel": 0, "chunk": 128, "segments": 2})])
