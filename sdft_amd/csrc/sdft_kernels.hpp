@@ -3219,12 +3219,16 @@ constexpr int kRowGroup = SDFT_ROW_GROUP;                 // samples per lockste
 // lockstep group shrinks to kRowGroup/S samples so that registers and LDS stay constant.
 constexpr int kRowSlotsMax = 2;      // 4 slots spill at the 128-VGPR cap of a 16-wave group
 // samples per lockstep group of the fused synthesis path (the plan sizes the terms image with it)
+#ifndef SDFT_SYN_GROUP_S2D
+#define SDFT_SYN_GROUP_S2D 4
+#endif
 #ifndef SDFT_SYN_GROUP_TREE
 #define SDFT_SYN_GROUP_TREE 8
 #endif
 constexpr int syn_group(int S, int BPL, int SYN)
 {
-  return (S == 2 && BPL == 2 && SYN == 1) ? SDFT_SYN_GROUP_S2F : (SYN == 1 && S == 1) ? SDFT_SYN_GROUP_TREE : kRowGroup / S;
+  return (S == 2 && BPL == 2 && SYN == 1) ? SDFT_SYN_GROUP_S2F : (SYN == 1 && S == 1) ? SDFT_SYN_GROUP_TREE
+       : (S == 2 && BPL == 1) ? SDFT_SYN_GROUP_S2D : kRowGroup / S;
 }
 
 // SYN (fused analysis -> operation -> synthesis): 0 = rows are stored (the
