@@ -14,7 +14,7 @@ host-side mirror used by tests and benchmarks:
 __version__ = "0.1.0"
 
 def __getattr__(name):
-    if name in ("SDFT", "plan_tables"):
+    if name in ("SDFT", "plan_tables", "check_expr"):
         from . import sdft as _s
         return getattr(_s, name)
     if name in ("COMBOS", "WINDOWS", "SdftHipError"):

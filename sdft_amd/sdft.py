@@ -295,3 +295,15 @@ def plan_tables(dftsize: int, latency: float = 1.0, combo: str = "f32f64"):
     w = np.empty(2, dtype=fd)
     api.plan_tables(dftsize, latency, tw.ctypes.data, syn.ctypes.data, wtab.ctypes.data, w.ctypes.data)
     return tw, syn, wtab, w
+
+
+def check_expr(expr: str, arch: str | None = None) -> None:
+    """Compiles the statements of an ``op="expr"`` operation without running them (``sdft_hip_check_expr``; needs no GPU).
+    Raises :class:`SdftHipError` with the compiler's words when they do not compile."""
+    from . import capi
+    lib = capi.load()
+    lib.sdft_hip_clear_error()
+    if lib.sdft_hip_check_expr(str(expr).encode(), arch.encode() if arch else None) != 0:
+        e = lib.sdft_hip_last_error()
+        lib.sdft_hip_clear_error()
+        raise SdftHipError(e.decode() if e else "the expression does not compile")

@@ -228,3 +228,7 @@ def test_expression_operation_compiles_without_a_gpu(hip_library):
     lib.sdft_hip_clear_error()
     assert lib.sdft_hip_check_expr(b"", None) == -1 and lib.sdft_hip_check_expr(None, None) == -1
     lib.sdft_hip_clear_error()
+    import sdft_amd
+    sdft_amd.check_expr("re = im; im = 0;")
+    with pytest.raises(sdft_amd.SdftHipError):
+        sdft_amd.check_expr("this is not C++")
