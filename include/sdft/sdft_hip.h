@@ -153,7 +153,7 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        read and write them over PCIe: 139 -> 111 us per 100-sample hop of the reference's test driver.
                        ONLY for hosts that keep their buffers allocated while the plan lives (like test/test.c:62-64 of the
                        reference): a registration does not survive free() + malloc() handing the same address out again.
-   "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize a power of two (<= 4096) run as ONE
+   "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
                        launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
                        0 = carries by a pre-pass (two more launches); "self_carry_max" = longest call that takes it
    "stage_bytes"   segment size of the host-pointer staging path
