@@ -155,6 +155,11 @@ class Api:
         e = self.lib.sdft_hip_last_error()
         return e.decode() if e else None
 
+    def clear(self):
+        """Forget an error recorded by an earlier call on this thread (the reference's signatures return void: the error
+        channel is the only way a failure shows, so every wrapped call starts from a clean slate)."""
+        self.lib.sdft_hip_clear_error()
+
     def check(self):
         """Raise if the library recorded an error on this thread (the C API itself never aborts)."""
         e = self.last_error()

@@ -1692,15 +1692,19 @@ class Plan
   // its buffers once, like the reference's driver, sets option "host_register" = 1.
   long opt_host_register = 0;
   size_t opt_host_register_max = (size_t)256 << 20;
-  // registered page ranges [lo, hi) never overlap each other: a buffer inside a registered range uses that registration
-  // (two registrations sharing a page would lose it when the first of them is dropped)
-  struct HostReg { uintptr_t lo, hi; char* dev; unsigned long long used; bool owned, writable; };
+  // A registration covers exactly the caller's bytes [a, b) -- NOT the whole pages around them: a long-lived process gets
+  // its megabyte buffers from the heap (glibc raises its mmap threshold as buffers are freed), where the neighbours share
+  // the first and last page; with whole pages registered, a later copy from or to such a neighbour -- inside the
+  // registered range at one end, outside at the other -- fails in the runtime ("invalid argument": seen in the test
+  // suite, never in a fresh process).  Our own registrations still never share a page with each other ([plo, phi) are the
+  // page ranges: two registrations sharing a page would lose it when the first of them is dropped).
+  struct HostReg { uintptr_t a, b, plo, phi; char* dev; unsigned long long used; bool owned, writable; };
   HostReg host_regs[8] = {};
   unsigned long long host_reg_clock = 0;
   long host_reg_hits = 0, host_reg_misses = 0;
   void drop_host(HostReg& e)
   {
-    if (e.hi && e.owned) { (void)hipHostUnregister(reinterpret_cast<void*>(e.lo)); (void)hipGetLastError(); }
+    if (e.b && e.owned) { (void)hipHostUnregister(reinterpret_cast<void*>(e.a)); (void)hipGetLastError(); }
     e = HostReg{};
   }
   void forget_host_buffers() { for (HostReg& e : host_regs) drop_host(e); }
@@ -1708,26 +1712,26 @@ class Plan
   void* map_host(const void* p, size_t bytes, bool will_write = false)
   {
     if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > opt_host_register_max) return nullptr;
-    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p);
-    const uintptr_t lo = a & ~(page - 1), hi = (a + bytes + page - 1) & ~(page - 1);
+    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p), b = a + bytes;
+    const uintptr_t plo = a & ~(page - 1), phi = (b + page - 1) & ~(page - 1);
     for (HostReg& e : host_regs)
-      if (e.hi && lo >= e.lo && hi <= e.hi)
+      if (e.b && a >= e.a && b <= e.b)
       {
         if (will_write && !e.writable && e.owned) { drop_host(e); break; }   // registered for reading: again, with its pages made writable first
-        e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.lo);
+        e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.a);
       }
-    // anything that overlaps without covering goes first (its pages would be shared)
+    // anything of ours that shares a page with the new range goes first
     for (HostReg& e : host_regs)
-      if (e.hi && lo < e.hi && e.lo < hi) drop_host(e);
+      if (e.b && plo < e.phi && e.plo < phi) drop_host(e);
     HostReg* slot = &host_regs[0];
-    for (HostReg& e : host_regs) { if (!e.hi) { slot = &e; break; } if (e.used < slot->used) slot = &e; }
+    for (HostReg& e : host_regs) { if (!e.b) { slot = &e; break; } if (e.used < slot->used) slot = &e; }
     drop_host(*slot);
     ++host_reg_misses;
     void* dev = nullptr;
     // memory the host pinned itself (hipHostMalloc, its own hipHostRegister) is mapped already
     if (hipHostGetDevicePointer(&dev, const_cast<void*>(p), 0) == hipSuccess && dev)
     {
-      *slot = HostReg{a, a + bytes, static_cast<char*>(dev), ++host_reg_clock, false, true};
+      *slot = HostReg{a, b, plo, phi, static_cast<char*>(dev), ++host_reg_clock, false, true};
       return dev;
     }
     (void)hipGetLastError();
@@ -1740,13 +1744,13 @@ class Plan
       for (uintptr_t off = 0; off < bytes; off += page) q[off] = q[off];
       q[bytes - 1] = q[bytes - 1];
     }
-    if (hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipHostGetDevicePointer(&dev, reinterpret_cast<void*>(lo), 0) != hipSuccess || !dev)
+    if (hipHostRegister(reinterpret_cast<void*>(a), bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(&dev, reinterpret_cast<void*>(a), 0) != hipSuccess || !dev)
     {
-      (void)hipGetLastError(); (void)hipHostUnregister(reinterpret_cast<void*>(lo)); (void)hipGetLastError(); return nullptr;
+      (void)hipGetLastError(); (void)hipHostUnregister(reinterpret_cast<void*>(a)); (void)hipGetLastError(); return nullptr;
     }
-    *slot = HostReg{lo, hi, static_cast<char*>(dev), ++host_reg_clock, true, will_write};
-    return static_cast<char*>(dev) + (a - lo);
+    *slot = HostReg{a, b, plo, phi, static_cast<char*>(dev), ++host_reg_clock, true, will_write};
+    return dev;
   }
 
   // one strip per channel; per-channel async copies (no pitch limits, works for any size)

@@ -78,6 +78,7 @@ class SDFT:
         self.close()
 
     def reset(self):
+        self.api.clear()
         self.api.reset(self._p)
         self.api.check()
 
@@ -158,6 +159,7 @@ class SDFT:
 
         State persists across calls exactly like the reference's plan (endless streaming).
         """
+        self.api.clear()
         if _is_tensor(x):
             torch = _torch()
             n = self._shape_x(x.shape)
@@ -180,6 +182,7 @@ class SDFT:
 
     def isdft(self, dfts, out=None):
         """Synthesise samples from a DFT matrix (n, dftsize) [(channels, n, dftsize)]."""
+        self.api.clear()
         batched = (len(dfts.shape) == 3)
         n = dfts.shape[-2]
         assert dfts.shape[-1] == self.dftsize and (not batched or dfts.shape[0] == self.channels)
@@ -213,6 +216,7 @@ class SDFT:
         "expr" (``expr`` = HIP C++ statements on ``re``, ``im`` of bin ``k`` at sample ``t`` of channel ``ch`` with the
         parameters ``p[i]`` = ``expr_params``; compiled into the kernel at run time, see sdft_hip.h).
         """
+        self.api.clear()
         kind = OPS[op] if isinstance(op, str) else int(op)
         params = None
         keep = None

