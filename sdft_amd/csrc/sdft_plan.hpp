@@ -1681,7 +1681,7 @@ class Plan
   // than its kernels (round 1: 191 us for a 1.6 MB hop); registering the caller's buffer once (hipHostRegister: the
   // pages are pinned and mapped, the driver follows the mapping with MMU notifiers) lets the kernels read and write it
   // over PCIe directly -- no staging copy, one synchronisation.  Buffers of 1 MiB and more only (smaller ones share
-  // pages with their heap neighbours), whole pages, at most 8 ranges that never overlap; anything the runtime refuses
+  // pages with their heap neighbours), at most 8 ranges that never share a page; anything the runtime refuses
   // falls back to the staged path.  Option "host_register" = 1 turns it on, "host_register_max" bounds the
   // bytes of one buffer (default 256 MiB: longer calls run at PCIe speed through the staged path anyway).
   static constexpr size_t kSmallHostBytes = (size_t)64 << 10;
