@@ -146,13 +146,14 @@ def test_kernels_contain_no_fused_multiply_add(hip_library, combo):
         params = [a.strip() for a in args.group(1).split(",")] if args else []
         deliberately_fused = name.startswith("chunk_sum_kernel") or \
             (name.startswith(("forward_rows_kernel", "process_rows_kernel")) and params[3] == "true")
-        # round 3: the magnitude power law of sdft_hip_process_n calls pow(), whose library code is built on fused
-        # multiply-adds; it is inlined into the kernels that apply spectral operations to windowed bins -- the fused-synthesis
+        # round 3: the magnitude power law of sdft_hip_process_n evaluates |X|^(p-1) by polynomials in fused multiply-adds
+        # (pow_positive); it is inlined into the kernels that apply spectral operations to windowed bins -- the fused-synthesis
         # instantiations of the row-group kernel (SYN != 0), the OPS instantiations of the synthesis kernels and
         # scale_rows_kernel.  Their reference arithmetic is the same source as their SYN = 0 / OPS = false twins', which stay
         # under the zero-FMA rule below (and the bit-exact GPU tests cover the fused ones: tests/test_gpu_process.py).
         carries_pow = (name.startswith("forward_rows_kernel") and len(params) > 5 and params[5] != "0") or \
-            (name.startswith(("inverse_kernel", "inverse_exact_kernel", "inverse_row_kernel")) and params[-1] == "true") or \
+            (name.startswith(("inverse_kernel", "inverse_row_kernel")) and params[3] == "true") or \
+            (name.startswith("inverse_exact_kernel") and params[5] == "true") or \
             name.startswith("scale_rows_kernel")
         if carries_pow and not deliberately_fused:
             continue
