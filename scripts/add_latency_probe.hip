@@ -72,8 +72,31 @@ template <typename T, bool PREFETCH> __global__ void chain_lds(T* out, unsigned 
   out[threadIdx.x] = sum;
   if (threadIdx.x == 0) *cyc = t1 - t0;
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ void chain_pk(f2* out, unsigned long long* cyc, f2 seed)
+{
+  f2 s = seed; f2 a = seed * 1.5f, b = seed * 0.25f;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i)
+  {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s += a; s += b; }
+    asm volatile("" : "+v"(s));
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = s;
+  if (threadIdx.x == 0) *cyc = t1 - t0;
+}
 int main()
 {
+  {
+    f2* o2; unsigned long long* c2;
+    hipMalloc(&o2, 64 * 8); hipHostMalloc(&c2, 8);
+    f2 sd; sd.x = 1.0f; sd.y = 2.0f;
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(chain_pk, dim3(1), dim3(64), 0, 0, o2, c2, sd); hipDeviceSynchronize(); }
+    printf("registers, packed float2 (v_pk_add_f32), 64 lanes: raw %llu per 4096 adds\n", *c2);
+  }
   double* out; unsigned long long* cyc;
   hipMalloc(&out, 1024 * 8); hipHostMalloc(&cyc, 8);
   for (int lanes : {8, 64})
