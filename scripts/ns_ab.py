@@ -7,7 +7,7 @@ from sdft_amd.signals import sine_sweep
 n, m = 48000, 1024
 x = torch.from_numpy(sine_sweep(n)).cuda()
 out = torch.empty((n, m), dtype=torch.complex128, device="cuda")
-variants = [("default", {}), ("chunk=192 (250 chunks)", {"chunk": 192}), ("chunk=184 (261)", {"chunk": 184}), ("chunk=96 (500)", {"chunk": 96}), ("chunk=376 (128)", {"chunk": 376}),
+variants = [("default", {}), ("chunk=192 (250 chunks)", {"chunk": 192}), ("chunk=184 (261)", {"chunk": 184}), ("chunk=96 (500)", {"chunk": 96}), ("chunk=376 (128)", {"chunk": 376}), ("chunk=48 (1000)", {"chunk": 48}), ("chunk=64 (750)", {"chunk": 64}), ("chunk=128 (375)", {"chunk": 128}),
             ("pre-pass", {"self_carry": 0})]
 b = n * (m * 16 + 4)
 for rnd in range(3):
