@@ -123,7 +123,10 @@ def test_random_fused_call_parity(seed):
         latency = float(rng.choice([1.0, 0.5, 0.3]))
         ch = int(rng.choice([1, 1, 2, 3]))
         lens = [int(rng.integers(1, max(2, min(5000, 2_000_000 // max(m * ch, 1))))), int(rng.integers(1, 511)), int(rng.integers(1, 300))]
-        op = ("identity", "gain", "shift", "cgain")[int(rng.integers(0, 4))]
+        op = ("identity", "gain", "shift", "cgain", "expr")[int(rng.integers(0, 5))]
+        # the host's own statements (compiled at run time): a factor that depends on the bin, the sample and the channel
+        expr = "const sdft_fd_t g = p[0] + p[1] * (sdft_fd_t)k / (sdft_fd_t)nbins + p[2] * cos(p[3] * (sdft_fd_t)t) + p[4] * (sdft_fd_t)ch; re *= g; im *= g;"
+        ep = [0.8, 0.5, 0.2, 0.01, 0.1]
         shift = int(rng.integers(-6, 7))
         gain = (rng.random(m) * 2.0).astype(fd)
         cgain = (gain.astype(np.float64) * np.exp(1j * rng.random(m) * 6.28)).astype(fdx)
@@ -147,6 +150,10 @@ def test_random_fused_call_parity(seed):
                         e.real = d.real * cgain.real[None, :] - d.imag * cgain.imag[None, :]
                         e.imag = d.real * cgain.imag[None, :] + d.imag * cgain.real[None, :]
                         d = e
+                    elif op == "expr":
+                        kk = np.arange(m)[None, :].astype(np.float64); tt = np.arange(n)[:, None].astype(np.float64)
+                        g_e = ep[0] + ep[1] * kk / m + ep[2] * np.cos(ep[3] * tt) + ep[4] * c
+                        d = (d * g_e.astype(d.real.dtype)).astype(d.dtype)
                     elif op == "shift":
                         s = np.zeros_like(d)
                         if shift >= 0:
@@ -158,14 +165,14 @@ def test_random_fused_call_parity(seed):
                 want = np.stack(want)
                 xin = xb if ch > 1 else xb[0]
                 g = cgain if op == "cgain" else gain
-                got = p.process(torch.from_numpy(xin).cuda(), op, gain=g, shift=shift).cpu().numpy() if i % 2 == 0 else \
-                    p.process(xin, op, gain=g, shift=shift)
+                got = p.process(torch.from_numpy(xin).cuda(), op, gain=g, shift=shift, expr=expr, expr_params=ep).cpu().numpy() if i % 2 == 0 else \
+                    p.process(xin, op, gain=g, shift=shift, expr=expr, expr_params=ep)
                 got = got if ch > 1 else got[None, :]
                 # bits: reference order asked for (or implied by carry = 1 at FD double) AND the analysis exact
                 exact_analysis = bit_identical and (combo[3:] == "f32" or opts["carry"] == 1 or p.get_option("last_chunks") == 1)
                 bit_identical = exact_analysis                      # a chunk-parallel FD double call leaves a state off by rounding
                 ordered = opts["fused_exact"] == 1 or (opts["fused_exact"] < 0 and opts["carry"] == 1 and combo[3:] == "f64")
-                if ordered and exact_analysis:
+                if ordered and exact_analysis and op != "expr":            # (the device's cos is not numpy's to the last bit)
                     assert np.array_equal(got, want), (tag, i)
                 gots.append(got); wants.append(want)
             x3 = noise(60, seed=seed + 77, dtype=td)
