@@ -2132,6 +2132,9 @@ template <typename TD, typename FD> struct SelfArgs
   const cx<FD>* acc_in;       // [channels][N] accumulator before the call (ForwardArgs::acc_state receives the new one)
   unsigned log2m;             // 2N = 1 << log2m, or 0: 2N = product of rl's radices (2, 3, 4, 5), Stockham between two buffers
   unsigned lds_deltas;        // fused kernel: samples of a chunk whose differences are staged in dynamic LDS (0: formed in the loop)
+#ifdef SDFT_SELF_STAMPS
+  unsigned long long* stamps; // development build: cycle stamps of the last chunk's workgroup (scripts/self_stamps.py)
+#endif
   RadixList rl;
 };
 
@@ -2294,9 +2297,23 @@ SDFT_D cx<FD>* self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, 
     }
   }
   if (t0 == 0) return nullptr;
+#ifdef SDFT_SELF_STAMPS
+  const bool st_on = sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0;
+  if (st_on) sa.stamps[1] = __builtin_readcyclecounter();
+#endif
   self_fold<CP, QB>(sa, cells, m, a.cursor0, ch, t0);
   __syncthreads();
-  if (sa.log2m) { lds_fft_dif(cells, sa.log2m, a.wtab); return cells; }
+#ifdef SDFT_SELF_STAMPS
+  if (st_on) sa.stamps[2] = __builtin_readcyclecounter();
+#endif
+  if (sa.log2m)
+  {
+    lds_fft_dif(cells, sa.log2m, a.wtab);
+#ifdef SDFT_SELF_STAMPS
+    if (st_on) sa.stamps[3] = __builtin_readcyclecounter();
+#endif
+    return cells;
+  }
   return lds_fft_mixed(cells, m, sa.rl, a.wtab);
 }
 
@@ -3263,6 +3280,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   const int nv = nwaves * S;
   unsigned chunk; size_t ch;
   flow_position(a, chunk, ch);
+#ifdef SDFT_SELF_STAMPS
+  if constexpr (SELF) { if (sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0) sa.stamps[0] = __builtin_readcyclecounter(); }
+#endif
   if (!flow_wait(a, chunk, ch)) return;                    // flow mode: the chunk's carries (a time-out ends the workgroup)
 
   const long nbins = (long)a.nbins;
@@ -3275,7 +3295,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // SELF: carry-in by fold + FFT of everything before this chunk (dynamic LDS: 2N cells)
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
   cx<FD>* dft = nullptr;                                   // the chunk's carry-in minus acc(0), bin k at self_slot(k)
-  if constexpr (SELF) dft = self_carry<4, 8>(sa, a, cells, chunk, ch, t0);
+  if constexpr (SELF) dft = self_carry<2, 16>(sa, a, cells, chunk, ch, t0);
 
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
   BinState<FD> s[S][BPL];
@@ -3599,8 +3619,14 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   int buf = 0;
   size_t t = t0;
+#ifdef SDFT_SELF_STAMPS
+  if constexpr (SELF) { if (sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0) sa.stamps[4] = __builtin_readcyclecounter(); }
+#endif
   while (t < t1)                       // all waves of the group take identical trip counts
   {
+#ifdef SDFT_SELF_STAMPS
+    if constexpr (SELF) { if (sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0 && t == t0 + (size_t)G) sa.stamps[5] = __builtin_readcyclecounter(); }
+#endif
     const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
     cx<FD> xs[G][S][BPL];
     // phase A
@@ -3699,6 +3725,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           a.fid_state[ch * a.nbins + k] = s[q][b].fid;
         }
   }
+#ifdef SDFT_SELF_STAMPS
+  if constexpr (SELF) { if (sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0) sa.stamps[6] = __builtin_readcyclecounter(); }
+#endif
   signal_done_workgroup(a.done);
 }
 

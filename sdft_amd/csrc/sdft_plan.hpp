@@ -133,6 +133,7 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
+  long opt_self_stamps = 0;                                // development builds (SDFT_SELF_STAMPS): device address of 8 stamp words
   long opt_inverse_verify = 1, opt_inverse_verify_max = 500000, last_inverse_form = 0;   // launch_inverse
   std::string user_expr;                                   // sdft_hip_process_n with an expression: the statements of the call in flight
   template <typename T> static const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
@@ -1029,6 +1030,9 @@ class Plan
     if ((span & (span - 1)) == 0) while (((size_t)1 << sa.log2m) < span) ++sa.log2m;
     else sa.rl = smooth_radices(span);
     sa.lds_deltas = 0;
+#ifdef SDFT_SELF_STAMPS
+    sa.stamps = reinterpret_cast<unsigned long long*>(opt_self_stamps);
+#endif
     ForwardArgs<FD> fa{};
     fa.delta = nullptr; fa.tw = d_tw.p; fa.wtab = d_wtab.p; fa.carry = nullptr; fa.seed = nullptr; fa.fseed = nullptr; fa.fseed_L = 0;
     fa.out = out; fa.out_stride = out_stride; fa.out_rows = nullptr;
