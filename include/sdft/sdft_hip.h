@@ -81,8 +81,9 @@ sdft_size_t sdft_hip_channels(const sdft_t* sdft) SDFT_HIP_SYMBOL(channels);
                                "if (re * re + im * im < p[0] * p[0] * (1 + k)) { re = 0; im = 0; }"
                            The statements are compiled into the fused kernel at run time (hiprtc: libhiprtc.so is opened
                            on first use; about a second per new expression and kernel shape, then cached for the life of
-                           the process), so the call still moves no matrix; rows beyond the row-group kernel and calls of
-                           one time chunk run analysis -> expression on the rows -> synthesis as three launches.
+                           the process), so the call still moves no matrix; a hop (one time chunk) runs the hop kernel and
+                           the row synthesis with the statements built in (two launches), rows beyond the row-group
+                           kernel run analysis -> expression on the rows -> synthesis.
                            What sdft.h leaves to the host between sdft_sdft_n and sdft_isdft_n (README.md:42-47), on the GPU.
    dfts: NULL, or device memory of shape (nsamples, dftsize) that receives the processed spectrum
    (not with the shift).  Batched plans: samples / out [channels][nsamples].

@@ -326,10 +326,11 @@ int sdft_hip_check_expr(const char* expr, const char* arch)
   if (!expr || !*expr) { sdfthip::set_error("sdft_hip_check_expr", "no statements"); return -1; }
   std::string lowered; std::vector<char> code;
   const char* target = arch && *arch ? arch : "gfx950";
-  // (both bin types on the two-pass route, and the fused kernel of the headline shape)
+  // (both bin types on the two-pass route, the fused kernel of the headline shape, the row synthesis of a hop)
   return sdfthip::rtc_compile(expr, "sdfthip::user_rows_kernel<double>", target, lowered, code) &&
          sdfthip::rtc_compile(expr, "sdfthip::user_rows_kernel<float>", target, lowered, code) &&
-         sdfthip::rtc_compile(expr, "sdfthip::forward_rows_kernel<double, 1, 1, true, 1, 1, true, float, false>", target, lowered, code) ? 0 : -1;
+         sdfthip::rtc_compile(expr, "sdfthip::forward_rows_kernel<double, 1, 1, true, 1, 1, true, float, false>", target, lowered, code) &&
+         sdfthip::rtc_compile(expr, "sdfthip::inverse_row_kernel<float, double, true, true>", target, lowered, code) ? 0 : -1;
 }
 
 }  // extern "C"

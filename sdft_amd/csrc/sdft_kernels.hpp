@@ -3032,6 +3032,7 @@ template <typename FD> struct SpectralOp
   size_t hop;                 // samples per gain vector
   size_t t0;                  // index, within the host's call, of the first row a launch sees (two-pass segments)
   FD p0, p1;                  // OP_GATE: threshold, floor; OP_POWER: exponent, scale
+  FD pv[8];                   // OP_USER: up to eight parameters travel with the kernel arguments (more: `gain` points at them)
 };
 template <typename FD> SDFT_HD bool op_is_linear(int kind) { return kind <= OP_CGAIN; }
 // the operation a kernel serves: the library's own build dispatches on SpectralOp::kind at run time; a run-time
@@ -3142,10 +3143,17 @@ template <typename FD> SDFT_D cx<FD> op_pointwise(cx<FD> v, const SpectralOp<FD>
 // In scope: re, im (sdft_fd_t, read and assign: the windowed value of bin k), k, nbins (unsigned), t (size_t: sample index
 // within the call), ch (size_t: channel), p (const sdft_fd_t*: the call's parameters, device memory), and HIP's math.
 #ifdef SDFT_USER_EXPR
-template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbins, size_t t, size_t ch, const FD* params)
+// p[i]: the call's parameters -- out of the kernel arguments (up to eight: no copy, no launch in front of the kernel; a
+// pageable 8-byte hipMemcpyAsync in front of every hop cost a synchronous host 110 us) or out of device memory through
+// the constant address space (scalar loads that nothing in the kernel can alias, so they leave the loop)
+template <typename FD> struct UserParams
 {
-  // (the parameters through the constant address space: scalar loads that nothing in the kernel can alias, so they leave the loop)
-  const SDFT_CONSTANT FD* p = as_uniform(params);
+  const FD* small; const SDFT_CONSTANT FD* big;
+  SDFT_D FD operator[](size_t i) const { return big ? big[i] : small[i]; }
+};
+template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbins, size_t t, size_t ch, const SpectralOp<FD>& op)
+{
+  const UserParams<FD> p{op.pv, op.gain ? as_uniform(op.gain) : nullptr};
   typedef FD sdft_fd_t;
   FD re = v.re, im = v.im;
   {
@@ -3155,7 +3163,7 @@ template <typename FD> SDFT_D cx<FD> user_op(cx<FD> v, unsigned k, unsigned nbin
 }
 // rows[ch][t][k] = user_op(rows[ch][t][k]): the two-pass route (rows that no workgroup holds, one-chunk calls)
 template <typename FD>
-__global__ __launch_bounds__(256) void user_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, size_t t0, const FD* p)
+__global__ __launch_bounds__(256) void user_rows_kernel(cx<FD>* mat, size_t stride, size_t rows, unsigned nbins, unsigned channels, SpectralOp<FD> op)
 {
   const size_t per = rows * nbins, total = per * channels;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
@@ -3163,7 +3171,7 @@ __global__ __launch_bounds__(256) void user_rows_kernel(cx<FD>* mat, size_t stri
     const size_t ch = i / per, r = i - ch * per;
     const size_t t = r / nbins, k = r - t * nbins;
     cx<FD>* q = mat + ch * stride + r;
-    *q = user_op(*q, (unsigned)k, nbins, t0 + t, ch, p);
+    *q = user_op(*q, (unsigned)k, nbins, op.t0 + t, ch, op);
   }
 }
 #endif
@@ -3480,7 +3488,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           if (opk == OP_GAIN) y[b] = cscale(y[b], gcur.g[keep[q][b] ? k : 0]);
           else if (opk == OP_CGAIN) y[b] = cmul(y[b], reinterpret_cast<const cx<FD>*>(gcur.g)[keep[q][b] ? k : 0]);
 #ifdef SDFT_USER_EXPR
-          else if (opk == OP_USER) y[b] = user_op(y[b], k < a.nbins ? k : 0u, a.nbins, gtime - 1, ch, fz.op.gain);
+          else if (opk == OP_USER) y[b] = user_op(y[b], k < a.nbins ? k : 0u, a.nbins, gtime - 1, ch, fz.op);
 #endif
           else if (opk >= OP_GATE) y[b] = op_pointwise(y[b], fz.op, opk);
           SpectralOp<FD> shift_only = fz.op; shift_only.kind = op_kind_of(fz.op) == OP_SHIFT ? OP_SHIFT : OP_IDENTITY;
@@ -4730,6 +4738,10 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
       {
         const unsigned kl = (unsigned)(i * kWave + lane) * BPL + b;
         const unsigned k = k0 + kl;
+#ifdef SDFT_USER_EXPR
+        // (run-time compilation for the host's own statements: they act on the bin before the synthesis term is formed)
+        if constexpr (OPS) { if (k < a.nbins) v[i][b] = user_op(v[i][b], k, a.nbins, a.op.t0 + t, ch, a.op); }
+#endif
         terms[kl] = synth_term<FD, LAT1, OPS>(v[i][b], k, a.op, a.syn, a.nbins, grow);
       }
     if constexpr (kInterval)

@@ -135,6 +135,7 @@ class Plan
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
   long opt_self_stamps = 0;                                // development builds (SDFT_SELF_STAMPS): device address of 8 stamp words
   long opt_inverse_verify = 1, opt_inverse_verify_max = 500000, last_inverse_form = 0;   // launch_inverse
+  bool rtc_failed = false;                                 // launch_inverse returns void: a failed run-time compilation is reported here
   std::string user_expr;                                   // sdft_hip_process_n with an expression: the statements of the call in flight
   template <typename T> static const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
   // FD float plans take the chunk-parallel carries too: 2x faster on long calls and closer to the double-precision
@@ -1522,6 +1523,17 @@ class Plan
     {
       InverseArgs<TD, FD> ir = ia;
       ir.done = arm_flag((unsigned)total_rows);
+      if (OPS && ia.op.kind == OP_USER)
+      {
+        // the host's own statements inside the row synthesis of a hop: this instantiation, compiled at run time
+        char name[160];
+        snprintf(name, sizeof(name), "sdfthip::inverse_row_kernel<%s, %s, %s, true>", type_name<TD>(), type_name<FD>(), LAT1 ? "true" : "false");
+        hipFunction_t fn = nullptr;
+        if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) { rtc_failed = true; return; }
+        void* args[] = {&ir};
+        if (hipModuleLaunchKernel(fn, (unsigned)total_rows, 1, 1, kWave, 1, 1, 0, stream, args, nullptr) != hipSuccess) rtc_failed = true;
+        return;
+      }
       hipLaunchKernelGGL((inverse_row_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ir);
     }
     else if (rw >= 32)
@@ -1553,6 +1565,7 @@ class Plan
     if (ops) { if (lat1) launch_inverse<true, true>(ia, total_rows); else launch_inverse<false, true>(ia, total_rows); }
     else     { if (lat1) launch_inverse<true, false>(ia, total_rows); else launch_inverse<false, false>(ia, total_rows); }
     SDFT_TRY(hipGetLastError());
+    if (rtc_failed) { rtc_failed = false; return false; }    // (the compiler's words are in the error channel already)
     if (!prof_end(ST_INVERSE)) return false;
     return true;
   }
@@ -2073,9 +2086,18 @@ class Plan
       const expr_t* ex = static_cast<const expr_t*>(params);
       if (!ex->expr || !*ex->expr) { set_error("sdft_hip_process_n", "expression: no statements"); return false; }
       user_expr = ex->expr;
-      if (!d_gain.reserve(std::max<size_t>(ex->np, 1))) return false;
-      if (ex->np) SDFT_TRY(hipMemcpyAsync(d_gain.p, ex->p, ex->np * sizeof(FD), hipMemcpyHostToDevice, stream));
-      op.gain = d_gain.p;
+      if (ex->np <= 8)
+      {
+        // up to eight parameters ride in the kernel arguments (SpectralOp::pv)
+        for (size_t i = 0; i < ex->np; ++i) op.pv[i] = static_cast<const FD*>(ex->p)[i];
+        op.gain = nullptr;
+      }
+      else
+      {
+        if (!d_gain.reserve(ex->np)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_gain.p, ex->p, ex->np * sizeof(FD), hipMemcpyHostToDevice, stream));
+        op.gain = d_gain.p;
+      }
     }
     const bool linear = op_is_linear<FD>(op_kind);
     const bool one_vector = op.rows <= 1;
@@ -2156,7 +2178,13 @@ class Plan
         fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
         const size_t mstride = dfts ? n * nbins : m * nbins;
         SpectralOp<FD> ops = op; ops.t0 = t;                  // gain vectors count from the start of the call
-        if (op_kind == OP_USER)                               // the host's operation rewrites the rows in place, then plain synthesis
+        if (op_kind == OP_USER && opt_exact_inverse && opt_inverse_rows <= 0 && channels * m <= 1024)
+        {
+          // a hop: the statements run inside the row synthesis (two launches); a copy of the spectrum is processed afterwards
+          ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &ops);
+          if (ok && dfts) ok = user_rows(mat, mstride, m, ops);
+        }
+        else if (op_kind == OP_USER)                          // the host's operation rewrites the rows in place, then plain synthesis
           ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && user_rows(mat, mstride, m, ops) && inverse_device(m, mat, mstride, nullptr, ys + t, n, nullptr);
         else
         {
@@ -2183,8 +2211,8 @@ class Plan
     if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
     const size_t total = channels * rows * nbins;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
-    fdx* a0 = mat; size_t a1 = stride, a2 = rows; unsigned a3 = (unsigned)nbins, a4 = (unsigned)channels; size_t a5 = op.t0; const FD* a6 = op.gain;
-    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6};
+    fdx* a0 = mat; size_t a1 = stride, a2 = rows; unsigned a3 = (unsigned)nbins, a4 = (unsigned)channels; SpectralOp<FD> a5 = op;
+    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5};
     SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
     return true;
   }

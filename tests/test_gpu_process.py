@@ -490,6 +490,22 @@ def test_operation_handed_in_as_code_batched_and_errors():
             ref = O.best(m, "hann", 1.0, "f32f64")
             want, _ = expr_reference(ref, x[c], pv, ch=c)
             assert rel_err(got[c], want) <= 1e-6, (c, rel_err(got[c], want))
+    # more than eight parameters travel through device memory instead of the kernel arguments; a parameter picked by a run-time index
+    m, n = 128, 3000
+    x1 = noise(n, seed=405)
+    pv = np.linspace(0.2, 1.4, 12)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    d = ref.sdft(x1)
+    want = ref.isdft((d * pv[np.arange(m) % 12][None, :]).astype(d.dtype))
+    for params, code in ((pv, "const sdft_fd_t g = p[k % 12]; re *= g; im *= g;"), (pv[:8], "const sdft_fd_t g = p[k % 8]; re *= g; im *= g;")):
+        with make(m, "hann", 1.0, "f32f64") as p:
+            got = p.process(x1, "expr", expr=code, expr_params=params)
+            w = want if len(params) == 12 else ref.isdft((d * pv[np.arange(m) % 8][None, :]).astype(d.dtype))
+            assert rel_err(got, w) <= 1e-6, (len(params), rel_err(got, w))
+            hop = x1[:120]
+            ref2 = O.best(m, "hann", 1.0, "f32f64"); d2 = ref2.sdft(hop)
+            p.reset()
+            assert rel_err(p.process(hop, "expr", expr=code, expr_params=params), ref2.isdft((d2 * pv[np.arange(m) % len(params)][None, :]).astype(d2.dtype))) <= 1e-6
     # reference order of the sum (fused_exact = 1) with an expression that is exact in any arithmetic: bit-identical at FD float
     m, n = 512, 6000
     x1 = noise(n, seed=410)
