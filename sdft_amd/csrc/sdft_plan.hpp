@@ -133,6 +133,7 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
+  long opt_flag_max = (long)1 << 24;                       // bin-samples up to which a row-group analysis call signals its own completion
   long opt_self_stamps = 0;                                // development builds (SDFT_SELF_STAMPS): device address of 8 stamp words
   long opt_inverse_verify = 1, opt_inverse_verify_max = 500000, last_inverse_form = 0;   // launch_inverse
   bool rtc_failed = false;                                 // launch_inverse returns void: a failed run-time compilation is reported here
@@ -945,7 +946,7 @@ class Plan
     // short synchronous calls: the row-group kernels report their own completion (a word in pinned host memory
     // reaches the host before the stream does).  Worth it while the kernel has little to write back: n = 4096,
     // N = 1024: 49.7 -> 46.7 us per sdft_sdft_n, 40.4 -> 35.8 us per fused call; nothing at n = 48000.
-    if ((use_rows || fuse) && segments == 1 && channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)1 << 24))
+    if ((use_rows || fuse) && segments == 1 && channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)opt_flag_max))
       fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
     last_segments = segments;
     for (long sg = 0; sg < segments; ++sg)
@@ -1046,7 +1047,7 @@ class Plan
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
     if (!grid_fits(channels * (size_t)chunks)) return false;
-    if (channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)1 << 24)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
+    if (channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)opt_flag_max)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
     const unsigned blocks = (unsigned)(channels * (size_t)chunks);
     const bool fused = opt_fused != 0;
     last_fused = fused; last_segments = 1; last_chain = 0;
