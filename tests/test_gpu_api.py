@@ -119,6 +119,42 @@ def test_independent_plans_in_threads():
         assert np.array_equal(got, want)
 
 
+def test_threads_through_the_chunk_parallel_and_run_time_compiled_paths():
+    """Three host threads, each with its own plan: self-carried chunk-parallel analysis, the synthesis that proves its floats,
+    and the fused call with the same statements handed in as code (one run-time compilation shared through the library's
+    cache, requested by all three at once)."""
+    m, n = 256, 9000
+    code = "const sdft_fd_t g = p[0] + p[1] * (sdft_fd_t)k / (sdft_fd_t)nbins; re *= g; im *= g;"
+    results, errors = {}, []
+
+    def work(tag, seed):
+        try:
+            x = noise(n, seed=seed)
+            ref = O.best(m, "hann", 1.0, "f32f64")
+            d = ref.sdft(x)
+            y = ref.isdft(d)
+            g = 0.5 + 0.25 * tag + 0.5 * np.arange(m) / m
+            ye = ref.isdft((d * g[None, :]).astype(d.dtype))
+            with make(m, "hann", 1.0, "f32f64") as p:
+                got_d = p.sdft(x)
+                got_y = p.isdft(got_d)
+                p.reset()
+                got_e = p.process(x, "expr", expr=code, expr_params=[0.5 + 0.25 * tag, 0.5])
+            results[tag] = (rel(got_d, d), bool(np.array_equal(got_y, ref.isdft(got_d))), rel(got_e, ye), rel(got_y, y))
+        except Exception as e:                                      # noqa: BLE001 -- surfaces in the main thread below
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i, 50 + i)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 3
+    for dd, same, ee, yy in results.values():
+        assert dd <= 1e-11 and same and ee <= 1e-6 and yy <= 1e-6, (dd, same, ee, yy)
+
+
 def test_corner_arguments():
     from sdft_amd.capi import Api
     api = Api("f32f64")
