@@ -172,7 +172,7 @@ def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz
             res["launches_per_call"] = 1 if p.get_option("last_self") == 1 else 3
             res["self_carried_chunks"] = bool(p.get_option("last_self") == 1)
         p.close()
-    res["path"] = "default: pointers classified by the library (cached per buffer), no options set"
+    res["path"] = "default: pointers classified by the library on every call, no options set"
     res["note"] = "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache"
     return res
 
@@ -288,6 +288,126 @@ def reference_bench_shape(torch, np, SDFT, device, with_cpu=True):
     return res
 
 
+def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True):
+    """The other single-GPU BASELINE.json configs at full size and the single-sample entry points, so that
+    the driver's record carries them: configs[2] (round trip, m = 4096, Blackman, FD float, latency 1, n = 262144) and
+    configs[3] (64 channels x 48000, m = 2048, Hann, TD float / FD double).  Outside the contract's timed region.  Every
+    fraction = algorithmic bytes (dftsize * sizeof(fdx) + sizeof(td) per sample and direction) / time / 8 TB/s; `*_ms_wall`
+    is the wall clock of one synchronous call through the C-ABI, `*_kernel_ms` the stage's HIP events (asynchronous calls)."""
+    res = {}
+
+    def timed(fn, sync, reps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps
+
+    # ---- configs[2] ----
+    m, n, combo, window = 4096, 262144, "f32f32", "blackman"
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * m * 8 * 1.1:
+        res["config2"] = {"skipped": f"needs {n * m * 8 / 1e9:.1f} GB of free HBM, {free / 1e9:.1f} GB free"}
+    else:
+        x = torch.from_numpy(sine_sweep(n, dtype=np.float32)).cuda()
+        d = torch.empty((n, m), dtype=torch.complex64, device="cuda")
+        y = torch.empty(n, dtype=torch.float32, device="cuda")
+        p = SDFT(m, window, 1.0, combo, device=device)
+        for _ in range(2):
+            p.sdft(x, d); p.isdft(d, y)
+        fwd = timed(lambda: p.sdft(x, d), p.synchronize, 5)
+        inv = timed(lambda: p.isdft(d, y), p.synchronize, 5)
+        p.set_option("async", 1)
+        pair = timed(lambda: (p.sdft(x, d), p.isdft(d, y)), p.synchronize, 5)
+        p.set_option("profile", 1)
+        for _ in range(5):
+            p.sdft(x, d); p.isdft(d, y)
+        pr = p.profile()
+        calls = max(pr["forward"][1], 1)
+        b = n * (m * 8 + 4)
+        res["config2"] = {
+            "workload": f"BASELINE configs[2]: round trip, n={n}, m={m}, {window}, TD float / FD float, latency 1 (exact carries: bit-identical to the reference)",
+            "forward_ms_wall": round(fwd * 1e3, 4), "inverse_ms_wall": round(inv * 1e3, 4), "round_trip_ms_wall_async_pair": round(pair * 1e3, 4),
+            "forward_gbs": round(b / fwd / 1e9, 1), "forward_frac_of_peak": round(b / fwd / 1e9 / HBM_PEAK_GBS, 4),
+            "inverse_gbs": round(b / inv / 1e9, 1), "inverse_frac_of_peak": round(b / inv / 1e9 / HBM_PEAK_GBS, 4),
+            "round_trip_gbs": round(2 * b / pair / 1e9, 1), "round_trip_frac_of_peak": round(2 * b / pair / 1e9 / HBM_PEAK_GBS, 4),
+            "carry_kernel_ms": round((pr["delta"][0] + pr["carry"][0]) / calls, 4),
+            "forward_kernel_ms": round(pr["forward"][0] / calls, 4), "inverse_kernel_ms": round(pr["inverse"][0] / max(pr["inverse"][1], 1), 4),
+            "carry_form": {0: "serial pass", 1: "chain", 2: "ring", 3: "relay"}.get(p.get_option("last_chain"), "?") + (" + flow mode" if p.get_option("last_flow") == 1 else ""),
+            "algorithmic_bytes_per_direction": b, "msamples_s_round_trip": round(n / pair / 1e6, 2),
+            "note": "carry and forward stages overlap (the relay runs beside the forward launch): their kernel times do not add up to the wall time",
+        }
+        p.close(); del x, d, y
+        torch.cuda.empty_cache()
+
+    # ---- configs[3] ----
+    chs, n, m, combo, window = 64, 48000, 2048, "f32f64", "hann"
+    need = chs * n * m * 16
+    free, _ = torch.cuda.mem_get_info()
+    if free < need * 1.03:
+        res["config3"] = {"skipped": f"needs {need / 1e9:.1f} GB of free HBM, {free / 1e9:.1f} GB free"}
+    else:
+        x = torch.from_numpy(np.stack([sine_sweep(n, channel=c, channels=chs, dtype=np.float32) for c in range(chs)])).cuda()
+        d = torch.empty((chs, n, m), dtype=torch.complex128, device="cuda")
+        p = SDFT(m, window, 1.0, combo, channels=chs, device=device)
+        y = None
+        for _ in range(2):
+            p.sdft(x, d); y = p.isdft(d, y)
+        fwd = timed(lambda: p.sdft(x, d), p.synchronize, 3)
+        inv = timed(lambda: p.isdft(d, y), p.synchronize, 3)
+        b = chs * n * (m * 16 + 4)
+        res["config3"] = {
+            "workload": f"BASELINE configs[3]: {chs} independent channels (one batched plan), n={n} each, m={m}, {window}, TD float / FD double",
+            "forward_ms_wall": round(fwd * 1e3, 3), "inverse_ms_wall": round(inv * 1e3, 3),
+            "forward_gbs": round(b / fwd / 1e9, 1), "forward_frac_of_peak": round(b / fwd / 1e9 / HBM_PEAK_GBS, 4),
+            "inverse_gbs": round(b / inv / 1e9, 1), "inverse_frac_of_peak": round(b / inv / 1e9 / HBM_PEAK_GBS, 4),
+            "analysis_msamples_s": round(chs * n / fwd / 1e6, 2), "synthesis_msamples_s": round(chs * n / inv / 1e6, 2),
+            "algorithmic_bytes_per_direction": b,
+        }
+        p.close(); del x, d, y
+        torch.cuda.empty_cache()
+
+    # ---- single-sample entry points (sdft.h:562, :635): one launch and one completion per call ----
+    m, combo = 1024, "f32f64"
+    p = SDFT(m, "hann", 1.0, combo, device=device)
+    row = torch.empty(m, dtype=torch.complex128, device="cuda")
+    xs = sine_sweep(4000, dtype=np.float32)
+    rp = C.c_void_p(row.data_ptr())
+    for i in range(200):
+        p.api.sdft(p._p, float(xs[i]), rp)
+    t0 = time.perf_counter()
+    for i in range(200, 2200):
+        p.api.sdft(p._p, float(xs[i]), rp)
+    t1 = time.perf_counter()
+    for i in range(2000):
+        p.api.isdft(p._p, rp)
+    t2 = time.perf_counter()
+    hrow = np.zeros(m, dtype=np.complex128)
+    hp = C.c_void_p(hrow.ctypes.data)
+    for i in range(100):
+        p.api.sdft(p._p, float(xs[i]), hp)
+    t3 = time.perf_counter()
+    for i in range(1000):
+        p.api.sdft(p._p, float(xs[i]), hp)
+    t4 = time.perf_counter()
+    p.close()
+    one = {"shape": f"sdft_sdft / sdft_isdft, one sample per call, m={m}, hann, {combo}, synchronous (the sample comes back by value)",
+           "sdft_us_per_call_device_row": round((t1 - t0) / 2000 * 1e6, 2), "isdft_us_per_call_device_row": round((t2 - t1) / 2000 * 1e6, 2),
+           "sdft_us_per_call_host_row": round((t4 - t3) / 1000 * 1e6, 2)}
+    if with_cpu:
+        from oracle import oracle as O
+        ref = O.best(m, "hann", 1.0, combo)
+        buf = np.zeros((2000, m), dtype=np.complex128)
+        ref.sdft(xs[:2000], buf)
+        ta = time.perf_counter(); ref.sdft(xs[:2000], buf); tb = time.perf_counter(); ref.isdft(buf); tc = time.perf_counter()
+        one.update({"cpu_sdft_us_per_sample": round((tb - ta) / 2000 * 1e6, 2), "cpu_isdft_us_per_sample": round((tc - tb) / 2000 * 1e6, 2),
+                    "cpu_kind": ref.kind, "cpu_cores": 1,
+                    "note": "per sample, the drop-in costs a launch and a completion: at best on a par with one host core -- hosts that have the samples call sdft_sdft_n"})
+    res["single_sample"] = one
+    return res
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -378,6 +498,7 @@ def main():
 
     units = float(count * n * args.steps)
     rate, secs = shard.job_throughput(units, elapsed, local_rank)
+    local_elapsed = elapsed
 
     # the same step one at a time (SURVEY.md 8d asks for a median): wall clock around one synchronised call each, and the
     # kernel's own HIP events launch by launch; outside the contract's timed region above
@@ -426,6 +547,9 @@ def main():
     except Exception:
         pass
 
+    # N > 1: what makes the record checkable without logs -- how many ranks the collectives saw, on how many distinct GPUs,
+    # and the spread of the per-rank step time and roofline fraction (every rank runs the same shape on its own channels)
+    census = shard.run_census(local_elapsed / args.steps * 1e3, achieved / HBM_PEAK_GBS, local_rank) if distributed else None
     kernel_names = {1: "forward_kernel", 2: "forward_rows_kernel", 3: "forward_hop_kernel"}
     result = {
         "metric": "Msamples/s analysis+synthesis, m=1024 Hann fp64; achieved HBM GB/s vs peak",
@@ -457,6 +581,13 @@ def main():
             "chunk_len": plan.get_option("last_chunk_len"),
             "carry_mode": "exact" if plan.get_option("carry") else "fast",
         },
+        "ranks": None if census is None else {
+            "collective_backend": census["backend"], "ranks_in_collectives": census["ranks"], "world_size": census["world_size"],
+            "distinct_local_devices": census["distinct_local_devices"],
+            "ms_per_step_min_over_ranks": round(census["seconds_min"], 4), "ms_per_step_max_over_ranks": round(census["seconds_max"], 4),
+            "roofline_frac_min_over_ranks": round(census["roofline_frac_min"], 4), "roofline_frac_max_over_ranks": round(census["roofline_frac_max"], 4),
+            "per_gpu_msamples_s": round(rate / 1e6 / max(n_gpus, 1), 3),
+        },
         "roofline": {
             "bound": "hbm",
             "kernel": kernel_names.get(plan.get_option("last_kernel"), "?"),
@@ -465,6 +596,8 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_source": ("profiles/hbm_traffic.json (PMC passes of this workload taken with rocprofv3 --pmc in the builder's session and "
+                               "replayed here; this run measured no counters)") if traffic is not None else None,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(f_avg_ms, 4),
             "median_launch_ms": round(float(np.median(kern_ms)), 4) if kern_ms else None,
@@ -634,6 +767,7 @@ def main():
                         share["cpu_baseline_all_cores"] = {"error": r.stderr[-300:]}
                 result["batch_share"] = share
             plan = None
+            result["configs"] = baseline_configs(torch, np, SDFT, sine_sweep, local_rank, with_cpu=not args.no_cpu_baseline)
         result["extras"] = extras
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

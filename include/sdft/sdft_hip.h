@@ -21,6 +21,11 @@ extern "C" {
    text of the first failing HIP call is recorded per thread.  Never aborts. */
 const char* sdft_hip_last_error(void);       /* NULL if nothing is recorded */
 void        sdft_hip_clear_error(void);
+/* A call that SUCCEEDED but has something to tell -- a poll loop of the exact-carry kernels timed out and the call was
+   re-run with the serial carry pass (get_option "ring_recoveries" counts them) -- leaves a warning, never an error:
+   its outputs and the stream state are valid and the host must not repeat it. */
+const char* sdft_hip_last_warning(void);     /* NULL if nothing is recorded */
+void        sdft_hip_clear_warning(void);
 
 /* ---- device selection (one process per GPU is the intended multi-GPU model) ----------------- */
 int         sdft_hip_device_count(void);
@@ -145,10 +150,9 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        float are summed in order -- get_option "ordered_walks" counts them)
    "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
    "fuse_delta"    1 (default) = chunk-parallel calls form the sample differences inside the carry kernel
-   "pointers"      0 = classify each distinct pointer once (the last 8 are cached; sdft_reset, sdft_hip_set_state and
-                       sdft_hip_set_stream forget them), 1 = all device, 2 = all host, 3 = query on every call.
-                       With 0 a host must not free a buffer it has passed to a plan and pass the same address
-                       again as the other kind of memory (host <-> device) without one of those calls in between.
+   "pointers"      0 (default) = every call asks the runtime what each pointer is (hipPointerGetAttributes: 0.06-0.16 us,
+                       nothing is cached -- a buffer that was freed and whose address came back as the other kind of memory
+                       is classified as what it is now), 1 = all device, 2 = all host (no query)
    "host_register" 0 (default) = host buffers are copied through staging buffers; 1 = host buffers of 1 MiB and more are
                        registered in place once (hipHostRegister, the last 8 page ranges are remembered) and the kernels
                        read and write them over PCIe: 139 -> 111 us per 100-sample hop of the reference's test driver.
@@ -164,7 +168,7 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
    "last_chain", "last_fused_exact", "last_fused_fold", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
    "last_self", "cursor", "device", "ring_recoveries" (calls re-run with the serial carry pass after a poll loop of
-   the ring form timed out: results stay valid, sdft_hip_last_error() reports it), "flag_fallbacks". */
+   the exact-carry kernels timed out: results stay valid, sdft_hip_last_warning() reports it), "flag_fallbacks". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);
 

@@ -93,7 +93,7 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
     # soname than /opt/rocm's.  The host decides: a C program links -lamdhip64 itself
     # (INTEGRATION.md), capi.load() binds to the runtime already loaded in the interpreter.
     tmp = LIB + f".tmp{os.getpid()}"
-    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lm"],
+    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lm", "-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

@@ -58,6 +58,8 @@ def typed_signatures(combo: str):
 UNTYPED = {
     "sdft_hip_last_error": (C.c_char_p, []),
     "sdft_hip_clear_error": (None, []),
+    "sdft_hip_last_warning": (C.c_char_p, []),
+    "sdft_hip_clear_warning": (None, []),
     "sdft_hip_device_count": (C.c_int, []),
     "sdft_hip_set_device": (C.c_int, [C.c_int]),
     "sdft_hip_get_device": (C.c_int, []),
@@ -154,6 +156,15 @@ class Api:
     def last_error(self):
         e = self.lib.sdft_hip_last_error()
         return e.decode() if e else None
+
+    def last_warning(self):
+        """What a call that succeeded had to tell (a recovered time-out of the exact-carry kernels), or None; cleared by reading."""
+        w = self.lib.sdft_hip_last_warning()
+        if not w:
+            return None
+        text = w.decode()
+        self.lib.sdft_hip_clear_warning()
+        return text
 
     def clear(self):
         """Forget an error recorded by an earlier call on this thread (the reference's signatures return void: the error

@@ -4,8 +4,11 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <set>
 
 namespace sdfthip {
 
@@ -16,6 +19,15 @@ void set_error(const char* what, const char* detail)
 {
   g_error = std::string(what ? what : "?") + ": " + (detail ? detail : "?");
   g_has_error = true;
+}
+
+// calls that succeeded but have something to tell (a poll loop timed out and the call was re-run): never an error
+static thread_local std::string g_warning;
+static thread_local bool g_has_warning = false;
+void set_warning(const char* what, const char* detail)
+{
+  g_warning = std::string(what ? what : "?") + ": " + (detail ? detail : "?");
+  g_has_warning = true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -41,18 +53,24 @@ struct Rtc
   decltype(&hiprtcGetLoweredName) lowered = nullptr;
   decltype(&hiprtcGetCodeSize) code_size = nullptr;
   decltype(&hiprtcGetCode) code = nullptr;
-  bool tried = false;
+  std::once_flag once;
   std::map<std::string, hipFunction_t> kernels;            // device | expression | name expression -> function
+  std::set<std::string> in_flight;                         // keys some thread is compiling right now (outside the lock)
   std::mutex mu;
+  std::condition_variable cv;
 
+  // host threads may arrive together (sdft_hip_check_expr takes no lock): the library is opened exactly once
   bool open()
   {
-    if (tried) return lib != nullptr;
-    tried = true;
+    std::call_once(once, [this]() { if (!open_once()) lib = nullptr; });
+    return lib != nullptr;
+  }
+  bool open_once()
+  {
     for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"})
       if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
     if (!lib) return false;
-#define SDFT_RTC_SYM(field, symbol) field = reinterpret_cast<decltype(field)>(dlsym(lib, #symbol)); if (!field) { lib = nullptr; return false; }
+#define SDFT_RTC_SYM(field, symbol) field = reinterpret_cast<decltype(field)>(dlsym(lib, #symbol)); if (!field) return false;
     SDFT_RTC_SYM(create, hiprtcCreateProgram) SDFT_RTC_SYM(destroy, hiprtcDestroyProgram) SDFT_RTC_SYM(add_name, hiprtcAddNameExpression)
     SDFT_RTC_SYM(compile, hiprtcCompileProgram) SDFT_RTC_SYM(log_size, hiprtcGetProgramLogSize) SDFT_RTC_SYM(log, hiprtcGetProgramLog)
     SDFT_RTC_SYM(lowered, hiprtcGetLoweredName) SDFT_RTC_SYM(code_size, hiprtcGetCodeSize) SDFT_RTC_SYM(code, hiprtcGetCode)
@@ -97,8 +115,8 @@ bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std:
   if (ok)
     if (const char* dir = getenv("SDFT_HIP_RTC_DUMP"))       // development aid: the code object, for llvm-objdump / llvm-readelf
     {
-      static int serial = 0;
-      const std::string path = std::string(dir) + "/sdft_rtc_" + std::to_string(serial++) + ".co";
+      static std::atomic<int> serial{0};
+      const std::string path = std::string(dir) + "/sdft_rtc_" + std::to_string(serial.fetch_add(1)) + ".co";
       if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
     }
   if (!ok && !g_has_error) set_error("sdft_hip_process_n (expression)", "run-time compilation failed");
@@ -108,23 +126,42 @@ bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std:
 // the kernel `name_expr` with the host's statements, loaded on `device` (compiled once per process, expression and kernel)
 bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn)
 {
-  std::lock_guard<std::mutex> lock(g_rtc.mu);
+  // The second-long compilation runs OUTSIDE the cache lock (other plans' expression calls go on); a key being compiled is
+  // marked in flight, and a thread that wants the same key waits for that compilation instead of starting its own.
   const std::string key = std::to_string(device) + "|" + expr + "|" + name_expr;
-  auto it = g_rtc.kernels.find(key);
-  if (it != g_rtc.kernels.end()) { *fn = it->second; return true; }
-  hipDeviceProp_t prop;
-  SDFT_TRY(hipGetDeviceProperties(&prop, device));
-  std::string arch = prop.gcnArchName;                     // "gfx950:sramecc+:xnack-"
-  arch = arch.substr(0, arch.find(':'));
-  std::string lowered; std::vector<char> code;
-  if (!rtc_compile(expr, name_expr, arch.c_str(), lowered, code)) return false;
-  hipModule_t module = nullptr;
-  SDFT_TRY(hipModuleLoadData(&module, code.data()));
+  {
+    std::unique_lock<std::mutex> lock(g_rtc.mu);
+    for (;;)
+    {
+      auto it = g_rtc.kernels.find(key);
+      if (it != g_rtc.kernels.end()) { *fn = it->second; return true; }
+      if (!g_rtc.in_flight.count(key)) break;
+      g_rtc.cv.wait(lock);
+    }
+    g_rtc.in_flight.insert(key);
+  }
   hipFunction_t f = nullptr;
-  SDFT_TRY(hipModuleGetFunction(&f, module, lowered.c_str()));
-  g_rtc.kernels[key] = f;
-  *fn = f;
-  return true;
+  const bool ok = [&]() -> bool
+  {
+    hipDeviceProp_t prop;
+    SDFT_TRY(hipGetDeviceProperties(&prop, device));
+    std::string arch = prop.gcnArchName;                     // "gfx950:sramecc+:xnack-"
+    arch = arch.substr(0, arch.find(':'));
+    std::string lowered; std::vector<char> code;
+    if (!rtc_compile(expr, name_expr, arch.c_str(), lowered, code)) return false;
+    hipModule_t module = nullptr;
+    SDFT_TRY(hipModuleLoadData(&module, code.data()));
+    SDFT_TRY(hipModuleGetFunction(&f, module, lowered.c_str()));
+    return true;
+  }();
+  {
+    std::lock_guard<std::mutex> lock(g_rtc.mu);
+    g_rtc.in_flight.erase(key);
+    if (ok) g_rtc.kernels[key] = f;
+  }
+  g_rtc.cv.notify_all();
+  if (ok) *fn = f;
+  return ok;
 }
 
 __global__ void lane_selftest_kernel(int* out)
@@ -298,6 +335,9 @@ double sdft_hip_load_ceiling(const void* src, size_t bytes, int reps)
 // NULL when no error has been recorded on this thread since the last clear
 const char* sdft_hip_last_error(void) { return sdfthip::g_has_error ? sdfthip::g_error.c_str() : nullptr; }
 void sdft_hip_clear_error(void) { sdfthip::g_has_error = false; sdfthip::g_error.clear(); }
+// NULL when no call on this thread has left a warning since the last clear (a warning never changes a return code)
+const char* sdft_hip_last_warning(void) { return sdfthip::g_has_warning ? sdfthip::g_warning.c_str() : nullptr; }
+void sdft_hip_clear_warning(void) { sdfthip::g_has_warning = false; sdfthip::g_warning.clear(); }
 
 int sdft_hip_device_count(void)
 {

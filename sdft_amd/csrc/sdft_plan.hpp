@@ -22,6 +22,7 @@ namespace sdfthip {
 
 // ---- error channel (the reference has none: void returns, sdft.h:413-687) -----------------
 void set_error(const char* what, const char* detail);   // sdft_common.hip
+void set_warning(const char* what, const char* detail); // sdft_common.hip: something the host may want to know about a call that succeeded
 bool lane_selftest();                                   // sdft_common.hip
 // run-time compilation of a host's own spectral operation (sdft_common.hip)
 bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn);
@@ -150,7 +151,7 @@ class Plan
   size_t stage_bytes = kDefaultStageBytes;   // host-pointer path: staging segment size
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
-  long opt_pointers = 0;         // 0 = detect per call (hipPointerGetAttributes), 1 = all device, 2 = all host
+  long opt_pointers = 0;         // 0 = ask the runtime on every call (hipPointerGetAttributes, ~0.1 us), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
@@ -291,7 +292,6 @@ class Plan
   bool reset()
   {
     cursor = 0; hist_cur = 0; st_cur = 0; fid_canonical = true;
-    forget_pointers();
     if (nbins == 0) return true;
     if (!bind()) return false;
     const size_t nb = nbins, span = 2 * nbins;
@@ -307,7 +307,6 @@ class Plan
   {
     if (stream) SDFT_TRY(hipStreamSynchronize(stream));
     if (own_stream && stream) (void)hipStreamDestroy(stream);
-    forget_pointers();
     stream = s; own_stream = false;
     return true;
   }
@@ -639,7 +638,13 @@ class Plan
     const size_t cursor0 = cursor;
     const int st0 = st_cur, hist0 = hist_cur;
     const bool canon0 = fid_canonical;
-    if (!forward_launch(n, x, x_stride, out, out_stride, rows, fuse)) return false;
+    if (!forward_launch(n, x, x_stride, out, out_stride, rows, fuse))
+    {
+      // a launch that failed half-way (a host expression that does not compile, a grid that does not fit, an allocation)
+      // must not leave the stream half-advanced: what was queued wrote the OTHER buffer set and the workspace only
+      cursor = cursor0; st_cur = st0; hist_cur = hist0; fid_canonical = canon0;
+      return false;
+    }
     if (last_chain < 2 || async) return true;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (aux) SDFT_TRY(hipStreamSynchronize(aux));
@@ -650,8 +655,14 @@ class Plan
     const bool ok = forward_launch(n, x, x_stride, out, out_stride, rows, fuse) && (hipStreamSynchronize(stream) == hipSuccess);
     opt_chain = saved;
     ++ring_recoveries;
-    set_error("carry_ring_kernel", ok ? "a poll loop timed out; the call was re-run with the serial carry pass (results are valid)"
-                                      : "a poll loop timed out and the re-run with the serial carry pass failed");
+    // a recovered call is a valid call: it goes to the warning channel (and the counter), not to the error channel, so a
+    // host that checks sdft_hip_last_error() after every call does not feed the samples twice
+    if (ok) set_warning("carry_relay_kernel", "a poll loop timed out; the call was re-run with the serial carry pass (results are valid)");
+    else
+    {
+      cursor = cursor0; st_cur = st0; hist_cur = hist0; fid_canonical = canon0;
+      set_error("carry_relay_kernel", "a poll loop timed out and the re-run with the serial carry pass failed");
+    }
     return ok;
   }
 
@@ -1325,7 +1336,12 @@ class Plan
       hipFunction_t fn = nullptr;
       if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
       if (syn_lds(SYN) > (size_t)64 * 1024)
-        SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
+      {
+        // a module function is not a host-side kernel symbol: hipFuncSetAttribute may refuse the handle (the launch below
+        // then says so itself if the image does not fit); hipModule functions take what the launch asks for on this runtime
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)) != hipSuccess)
+          (void)hipGetLastError();
+      }
       ForwardArgs<FD> a1 = fa; FuseArgs<TD, FD> f1 = fz; SelfArgs<TD, FD> s1{};
       void* args[] = {&a1, &f1, &s1};
       SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, threads, 1, 1, (unsigned)syn_lds(SYN), stream, args, nullptr));
@@ -1671,26 +1687,17 @@ class Plan
     return true;
   }
 
-  // Pointer classification, cached per distinct pointer value: hosts that stream through the same
-  // buffers call after call pay hipPointerGetAttributes once per buffer.  (A cached answer would
-  // be stale only if a device allocation were freed and the very same address handed out again as
-  // host memory; option "pointers" = 3 queries on every call, 1 / 2 declare all device / all host.)
-  // The hazard that remains with the default: an address classified once, freed by the host and handed out again as
-  // the other kind of memory between two calls on the same plan.  reset(), set_state() and set_stream() forget the
-  // cache; a host that recycles buffers between calls sets option "pointers" to 3 (or declares them with 1 / 2).
-  struct PtrClass { const void* p; bool dev; };
-  PtrClass ptr_cache[8] = {};
-  unsigned ptr_cache_next = 0;
-  void forget_pointers() { for (PtrClass& e : ptr_cache) e = PtrClass{nullptr, false}; ptr_cache_next = 0; }
+  // Pointer classification: every call asks the runtime (hipPointerGetAttributes).  Measured on MI355X / ROCm 7
+  // (scripts/pointer_query_probe.hip, profiles/r04_pointer_query_cost.txt): 0.06-0.10 us per query for device and pinned
+  // memory, 0.16 us for pageable host memory, with 2 or 2000 live allocations -- two orders of magnitude below a launch,
+  // so nothing is cached and a buffer that was freed and whose address came back as the other kind of memory (hipMalloc
+  // does hand a freed address out again) is classified as what it is now.  Option "pointers" = 1 / 2 declares every
+  // pointer device / host memory (no query).
   bool on_device(const void* p)
   {
     if (opt_pointers == 1) return true;
     if (opt_pointers == 2) return false;
-    if (opt_pointers == 3 || !p) return is_device_pointer(p);
-    for (const PtrClass& e : ptr_cache) if (e.p == p) return e.dev;
-    const bool dev = is_device_pointer(p);
-    ptr_cache[ptr_cache_next++ % 8] = PtrClass{p, dev};
-    return dev;
+    return is_device_pointer(p);
   }
 
   // ---- host buffers, mapped in place --------------------------------------------------------------------------
@@ -2114,6 +2121,19 @@ class Plan
     }
     TD* ys = y;
     if (!yd) { if (!d_stage_y.reserve(channels * n)) return false; ys = d_stage_y.p; }
+    // In place (out == samples) or overlapping device buffers: the two reference calls read every sample before the first
+    // output sample is written, the one-launch forms do not (workgroups read the samples of earlier chunks -- fold, delay
+    // line, differences -- while others write their outputs).  The samples are copied aside first: 4-8 bytes per sample.
+    if (xs == x && yd)
+    {
+      const uintptr_t xa = reinterpret_cast<uintptr_t>(xs), ya = reinterpret_cast<uintptr_t>(ys), bytes = channels * n * sizeof(TD);
+      if (xa < ya + bytes && ya < xa + bytes)
+      {
+        if (!d_stage_td.reserve(channels * n)) return false;
+        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, xs, bytes, hipMemcpyDeviceToDevice, stream));
+        xs = d_stage_td.p;
+      }
+    }
 
     bool ok;
     long chunks, len;
@@ -2172,6 +2192,27 @@ class Plan
       if (!dfts && !d_stage_fdx.reserve(row_elems * seg)) return false;
       last_process_path = (chunks == 1) ? 2 : 3;
       last_fused_exact = 0; last_fused_fold = 0;
+      if (op_kind == OP_USER)
+      {
+        // every run-time-compiled kernel the segments below will ask for is resolved BEFORE the first launch: statements
+        // that do not compile must not leave the stream advanced by an analysis whose synthesis then fails
+        const size_t m_first = std::min(seg, n), m_last = n - ((n - 1) / seg) * seg;
+        const bool hop_form = opt_exact_inverse && opt_inverse_rows <= 0;
+        const bool any_hop = hop_form && (channels * m_first <= 1024 || channels * m_last <= 1024);
+        const bool any_rows = !hop_form || channels * m_first > 1024 || channels * m_last > 1024 || dfts != nullptr;
+        hipFunction_t fn = nullptr;
+        char name[160];
+        if (any_hop)
+        {
+          snprintf(name, sizeof(name), "sdfthip::inverse_row_kernel<%s, %s, %s, true>", type_name<TD>(), type_name<FD>(), latency == 1 ? "true" : "false");
+          if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
+        }
+        if (any_rows)
+        {
+          snprintf(name, sizeof(name), "sdfthip::user_rows_kernel<%s>", type_name<FD>());
+          if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
+        }
+      }
       ok = true;
       for (size_t t = 0; t < n && ok; t += seg)
       {
@@ -2234,7 +2275,6 @@ class Plan
   {
     if (!bind()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
-    forget_pointers();
     if (nbins)
     {
       if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }

@@ -63,6 +63,44 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    dev = f"cuda:{device}" if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
+def run_census(local_seconds: float, local_frac: float, device=None) -> dict:
+    """What a multi-GPU record needs to be checked without reading logs: how many ranks took part in the collectives
+    of which backend on how many distinct devices, and the spread of the per-rank step time and roofline fraction."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "ranks": 1, "world_size": 1}
+    backend = dist.get_backend()
+    on_gpu = backend == "nccl"
+    dev_index = int(device) if device is not None else 0
+    # one-hot of the device index, summed: the number of non-zero slots is the number of distinct GPUs the ranks sit on
+    dev = f"cuda:{device}" if (device is not None and on_gpu) else "cpu"
+    hot = torch.zeros(64, dtype=torch.float64, device=dev)
+    hot[dev_index % 64] = 1.0
+    dist.all_reduce(hot, op=dist.ReduceOp.SUM)
+    return {
+        "backend": "rccl (torch.distributed nccl)" if on_gpu else backend,
+        "ranks": int(round(sum_over_ranks(1.0, device))),
+        "world_size": dist.get_world_size(),
+        "distinct_local_devices": int((hot > 0).sum().item()),
+        "seconds_min": min_over_ranks(local_seconds, device),
+        "seconds_max": max_over_ranks(local_seconds, device),
+        "roofline_frac_min": min_over_ranks(local_frac, device),
+        "roofline_frac_max": max_over_ranks(local_frac, device),
+    }
+
+
 def job_throughput(local_units: float, local_seconds: float, device=None) -> Tuple[float, float]:
     """(total units over all ranks) / (max seconds over ranks) -> (units per second, seconds)."""
     total = sum_over_ranks(local_units, device)

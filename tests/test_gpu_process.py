@@ -547,3 +547,63 @@ def test_reference_bits_by_rounding_interval():
     with make(256, "hann", 1.0, "f64f64", carry=1, fused_exact=2) as p:
         assert np.array_equal(p.process(x, "identity"), ref.isdft(ref.sdft(x)))
         assert p.get_option("ordered_walks") == 0                    # (the counter belongs to the interval test)
+
+
+@pytest.mark.parametrize("combo,m,n", [("f32f64", 1024, 48000),      # self-carried chunks (one launch, workgroups read earlier chunks' samples)
+                                       ("f32f64", 1000, 20000),      # pre-pass route, 2N = 2/3/5-smooth
+                                       ("f32f64", 256, 100),         # a hop: the one-launch hop kernel
+                                       ("f32f64", 1024, 100000),     # beyond the self-carried form's limit for the fused call
+                                       ("f32f32", 512, 30000),       # exact carries (relay + flow mode)
+                                       ("f64f64", 256, 9000)])
+def test_in_place_and_overlapping_calls(combo, m, n):
+    """out == samples on the device, and out overlapping samples: the two reference calls read every sample before they
+    write the first output sample (sdft.h:607-613 then :666-672), so the fused call must give what it gives out of place
+    -- the one-launch forms read earlier chunks' samples while other workgroups write their outputs (round-3 advisor
+    finding); the library copies the samples aside when the ranges overlap."""
+    import torch
+    td = np.float32 if combo.startswith("f32") else np.float64
+    x = noise(n + 64, seed=900 + m).astype(td)
+    gain = (0.5 + 0.5 * np.cos(np.arange(m) * 0.01)).astype(np.float64)
+    ref = O.best(m, "hann", 1.0, combo)
+    want_ref, _ = reference(ref, x[:n], "gain", gain.astype(ref.fd if hasattr(ref, "fd") else np.float64), 0)
+    x2 = noise(700, seed=901).astype(td)
+    with make(m, "hann", 1.0, combo) as a, make(m, "hann", 1.0, combo) as b, make(m, "hann", 1.0, combo) as c:
+        g = gain.astype(a.fd)
+        xa = torch.from_numpy(x[:n]).cuda()
+        want = a.process(xa, "gain", gain=g)                                  # out of place
+        assert rel_err(want.cpu().numpy(), want_ref) <= TOL[combo[3:]]
+        xb = xa.clone()
+        got = b.process(xb, "gain", gain=g, out=xb)                           # in place
+        assert got.data_ptr() == xb.data_ptr()
+        assert torch.equal(want, got), rel_err(got.cpu().numpy(), want.cpu().numpy())
+        buf = torch.from_numpy(x).cuda()                                      # out starts 64 samples into the input
+        xc, yc = buf[:n], buf[64:64 + n]
+        got_c = c.process(xc, "gain", gain=g, out=yc)
+        assert torch.equal(want, got_c), rel_err(got_c.cpu().numpy(), want.cpu().numpy())
+        # the stream state (delay line included) all three calls leave is the same
+        t2 = torch.from_numpy(x2).cuda()
+        w2 = a.process(t2, "gain", gain=g)
+        assert torch.equal(w2, b.process(t2, "gain", gain=g)) and torch.equal(w2, c.process(t2, "gain", gain=g))
+
+
+@pytest.mark.parametrize("m,n,opts", [(512, 6000, {}),                          # fused kernel: the compilation fails at the K1 launch
+                                      (512, 6000, {"carry": 1}),                # ... with the carry launches already queued
+                                      (256, 120, {}),                           # a hop: analysis, then the row synthesis with the statements
+                                      (6000, 3000, {})])                        # rows no workgroup holds: analysis -> statements -> synthesis
+def test_failed_expression_leaves_the_stream_where_it_was(m, n, opts):
+    """Statements that do not compile: rc = -1 AND the plan's stream state is untouched, so a host that fixes the typo and
+    sends the same samples again gets what a fresh plan gives (round-3 advisor finding: the delay line was flipped, or the
+    whole analysis had advanced the state, before the compilation failed)."""
+    from sdft_amd.capi import SdftHipError
+    x0, x1 = noise(2500, seed=77), noise(n, seed=78)
+    good = "re *= p[0]; im *= p[0];"
+    with make(m, "hann", 1.0, "f32f64", **opts) as p, make(m, "hann", 1.0, "f32f64", **opts) as q:
+        p.process(x0); q.process(x0)                                           # some history and a cursor
+        before = p.state()
+        with pytest.raises(SdftHipError) as e:
+            p.process(x1, "expr", expr="re *= p[0]; im *= nonsense(p[0]);", expr_params=[0.5])
+        assert "does not compile" in str(e.value)
+        after = p.state()
+        for u, v in zip(before, after):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+        assert np.array_equal(p.process(x1, "expr", expr=good, expr_params=[0.5]), q.process(x1, "expr", expr=good, expr_params=[0.5]))
