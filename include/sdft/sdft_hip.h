@@ -138,9 +138,11 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "spin"          1 (default) = synchronous short calls do not sleep on the stream: calls of one time chunk
                        poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
                        before the stream reports the kernel finished), other short calls poll the stream
-   "chain"         exact carries: 1 (default) = chain form (seed table + producer/consumer waves) while
-                       bins x channels leave SIMDs idle, 0 = always the serial pass, 2 = chain form whenever
-                       the geometry allows ("chain_block" 8|16|32 steps, "chain_producers" 1..7)
+   "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn,
+                       one dependent addition per step on the chain) while bins x channels leave SIMDs idle, 0 = always the
+                       serial pass, 2 = relay form whenever the geometry allows ("chain_block" 8|16|32|64|128 steps,
+                       "relay_waves" 1..8 waves per relay; "relay_flow" 1 (default) = one relay launch beside one forward
+                       launch whose workgroups wait for their chunk's carries)
    "fused_exact"   sdft_hip_process_n: 0 = folded form (window, operation and synthesis folded into per-bin
                        coefficients, sum over bins by a tree), 1 = bins summed in the reference's order by the
                        fastest route that gives those bits, 2 = in that order by the fused kernel,

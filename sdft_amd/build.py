@@ -23,7 +23,9 @@ LIB = os.path.join(OUT_DIR, "libsdft_hip.so")
 ARCH = "gfx950"
 COMBOS = ("f32f64", "f32f32", "f64f64", "f64f32")
 SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
-HEADERS = ["sdft_kernels.hpp", "sdft_plan.hpp", "sdft_capi.inc"]
+KERNEL_FILES = ["sdft_base.hpp", "sdft_carry_fast.hpp", "sdft_carry_exact.hpp", "sdft_forward.hpp", "sdft_forward_hop.hpp", "sdft_ops.hpp",
+                "sdft_forward_rows.hpp", "sdft_fused.hpp", "sdft_inverse.hpp"]      # in include order (sdft_kernels.hpp)
+HEADERS = ["sdft_kernels.hpp", *KERNEL_FILES, "sdft_plan.hpp", "sdft_capi.inc"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -33,6 +35,17 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libsdft_hip.so cannot be built (no CPU fallback exists)")
+
+
+def kernel_source() -> str:
+    """sdft_kernels.hpp with its stage files inlined: what hiprtc compiles a host's statements into."""
+    parts = []
+    for name in KERNEL_FILES:
+        with open(os.path.join(CSRC, name)) as fh:
+            own = tuple(f'#include "{k}"' for k in KERNEL_FILES)         # (not "sdft_user_expr.inc": the host's statements)
+            lines = [l for l in fh.read().split("\n") if not (l.startswith(own) or l.strip() == "#pragma once")]
+        parts.append(f"// ---- {name} ----\n" + "\n".join(lines))
+    return "\n".join(parts)
 
 
 def _stale() -> bool:
@@ -66,9 +79,9 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     # the text of the kernels, for the run-time compilation of a host's own spectral operation (sdft_hip_process_expr_n):
-    # a raw string literal in pieces (compilers bound the length of one literal), included by sdft_common.hip
-    with open(os.path.join(CSRC, "sdft_kernels.hpp")) as fh:
-        text = fh.read()
+    # the stage files in include order with their quoted includes removed (one self-contained source), as a raw string
+    # literal in pieces (compilers bound the length of one literal), included by sdft_common.hip
+    text = kernel_source()
     assert ')SDFTSRC"' not in text
     pieces = [text[i:i + 8000] for i in range(0, len(text), 8000)]
     with open(os.path.join(obj_dir, "sdft_kernels_src.inc"), "w") as fh:

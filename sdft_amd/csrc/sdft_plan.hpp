@@ -196,16 +196,14 @@ class Plan
   // a chunk-parallel call seeded fid from the closed-form table, or after set_state, until the
   // next roll-over puts it back to exactly 1)
   DevBuf<fdx> d_fseed;
-  unsigned fseed_L = 0, chain_P = 0;
+  unsigned fseed_L = 0;
   bool fid_canonical = true;
-  bool chain_attr[3] = {false, false, false};
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
-  long opt_chain_L = 0, opt_chain_P = 0, opt_chain_debug = 0;
+  long opt_chain_L = 0, opt_chain_debug = 0;
   long opt_hop_pipe = 1;         // calls of one time chunk, small launches: two waves per tile (forward_hop2_kernel)
   long last_hop_pipe = 0;
   long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
-  long opt_chain_ring = 1;       // exact carries, chain form: products through an LDS ring (1) or in rounds with a barrier each (0)
   long opt_chain_relay = 1;      // exact carries: relay form (identical waves pass acc on as a token; products stay in registers)
   long opt_relay_waves = 0;      // waves per workgroup of the relay form (0 = default)
   DevBuf<unsigned long long> d_chain_stats;
@@ -457,66 +455,7 @@ class Plan
     return false;
   }
 
-  // ---- exact carries, chain form: block length / producer count / seed table -----------------
-  // L divides 2N (so the roll-over ends a block and every block starts on a tabulated cursor) and is
-  // a multiple of 8; a round of P*L steps keeps two product buffers of 64 lanes within 64 KiB of LDS.
-  static constexpr size_t kChainLdsBytes = (size_t)128 * 1024;      // of the CU's 160 KiB
-  static size_t chain_lds(unsigned L, unsigned P) { return (size_t)2 * kWave * chain_row<FD>((int)(L * P)) * sizeof(FD); }
-  bool chain_geometry(unsigned& L, unsigned& P) const
-  {
-    const size_t span = 2 * nbins;
-    L = 0;
-    if (opt_chain_L > 0)
-    {
-      const bool built = opt_chain_L == 8 || opt_chain_L == 16 || (opt_chain_L == 32 && sizeof(FD) == 4);
-      if (built && span % (size_t)opt_chain_L == 0) L = (unsigned)opt_chain_L;
-    }
-    else
-      for (unsigned cand : {32u, 16u, 8u})                 // 32-step blocks are built for 4-byte products only
-        if ((cand < 32 || sizeof(FD) == 4) && span % cand == 0) { L = cand; break; }
-    if (!L) return false;
-    unsigned pmax = 7;
-    while (pmax > 1 && chain_lds(L, pmax) > kChainLdsBytes) --pmax;
-    if (opt_chain_ring) pmax = 7;                            // the ring's size does not depend on the producer count
-    // measured (ring form): FD float is consumer-bound from 5 producers on, FD double still gains from the 7th
-    P = opt_chain_P > 0 ? std::min((unsigned)opt_chain_P, pmax) : std::min((opt_chain_ring && sizeof(FD) == 8) ? 7u : 6u, pmax);
-    P = std::max(1u, P);
-    return ((span / L) * nbins * sizeof(fdx)) <= ((size_t)256 << 20);      // seed table budget
-  }
-  // ring form: blocks of the LDS ring (about 384 steps of 4-byte products, 192 of 8-byte ones)
-  static unsigned ring_blocks(unsigned L)
-  {
-    const unsigned steps = sizeof(FD) == 4 ? 384u : 192u;
-    return std::max(4u, std::min((unsigned)kRingMaxBlocks, steps / L));
-  }
-  static size_t ring_lds(unsigned L, unsigned NB) { return (size_t)kWave * (NB * L + 16 / sizeof(FD)) * sizeof(FD); }
-  bool ring_attr[4] = {false, false, false, false};
-  template <int L> bool launch_ring(const ChainArgs<FD>& cc, unsigned blocks, hipStream_t on)
-  {
-    bool& raised = ring_attr[L == 8 ? 0 : (L == 16 ? 1 : (L == 32 ? 2 : 3))];
-    if (!raised)
-    {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&carry_ring_kernel<FD, L>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes));
-      raised = true;
-    }
-    hipLaunchKernelGGL((carry_ring_kernel<FD, L>), dim3(blocks), dim3(kWave * (cc.P + 1)), ring_lds(cc.L, cc.NB), on, cc);
-    SDFT_TRY(hipGetLastError());
-    return true;
-  }
-  template <int L> bool launch_chain(const ChainArgs<FD>& cc, unsigned blocks, hipStream_t on)
-  {
-    bool& raised = chain_attr[L == 8 ? 0 : (L == 16 ? 1 : 2)];   // dynamic LDS beyond 64 KiB has to be asked for once (per device)
-    if (!raised)
-    {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&carry_chain_kernel<FD, L>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes));
-      raised = true;
-    }
-    hipLaunchKernelGGL((carry_chain_kernel<FD, L>), dim3(blocks), dim3(kWave * (cc.P + 1)), chain_lds(cc.L, cc.P), on, cc);
-    SDFT_TRY(hipGetLastError());
-    return true;
-  }
+  // ---- exact carries, relay form: block length / seed table -----------------------------------------
   // relay form: block length = seed distance: divides 2N and the chunk length; L products live in L registers per lane
   unsigned relay_block(long len) const
   {
@@ -705,29 +644,20 @@ class Plan
     const bool self = self_form && chunks > 1 && ((span & (span - 1)) == 0 || len > 64);
     last_self = self;
     if (self) return forward_self(n, x, x_stride, out, out_stride, chunks, len, fuse);
-    // exact carries: chain form (seed table + producer/consumer waves) while the serial pass would
-    // leave most SIMDs idle; the plain serial pass when bins x channels already fill the chip
-    unsigned cL = 0, cP = 0;
+    // exact carries: relay form (seed table + identical waves that take the blocks of cL steps in turn, a block's products in
+    // registers) while the serial pass would leave most SIMDs idle; the plain serial pass when bins x channels already
+    // fill the chip.  The chunk grid is shifted so that every chunk but the first starts on a block boundary of the
+    // cursor (chunk j starts at sample j*len - shift; one more chunk may be needed for the tail)
     const size_t serial_waves = ((nb + kWave / 2 - 1) / (kWave / 2)) * channels;
     const bool chain_ok = exact && chunks > 1 && opt_chain && fid_canonical && (opt_chain >= 2 || serial_waves <= 1024);
-    // relay form (default): identical waves, the block's products in registers; same shifted chunk grid as the ring form
-    const unsigned yL = (chain_ok && opt_chain_relay && !(opt_chain_debug & 19) && n < ((size_t)1 << 31)) ? relay_block(len) : 0u;
-    const bool use_relay = yL != 0;
-    const bool use_chain = use_relay || (chain_ok && chain_geometry(cL, cP));
-    // ring form: the chunk grid is shifted so that every chunk but the first starts on a block boundary
-    // of the cursor (chunk j starts at sample j*len - shift); one more chunk may be needed for the tail
-    const bool use_ring = use_relay || (use_chain && opt_chain_ring && !(opt_chain_debug & 19) && (len % (long)cL) == 0 && n < ((size_t)1 << 31));
-    // the ring form's cost per block (flag, slot, chunk counter) is paid half as often with blocks twice as long
-    unsigned rL = cL;
-    if (use_ring && opt_chain_L <= 0 && cL == (sizeof(FD) == 4 ? 32u : 16u) && span % (2 * cL) == 0 && len % (long)(2 * cL) == 0) rL = 2 * cL;
-    if (use_relay) rL = yL;
-    if (use_ring) cL = rL;
-    const unsigned shift = use_ring ? (unsigned)(cursor % cL) : 0u;
+    const unsigned cL = (chain_ok && opt_chain_relay && n < ((size_t)1 << 31)) ? relay_block(len) : 0u;
+    const bool use_chain = cL != 0;
+    const unsigned shift = use_chain ? (unsigned)(cursor % cL) : 0u;
     if (shift) { chunks = (long)((n + shift + (size_t)len - 1) / (size_t)len); last_chunks = chunks; }
 
     if (!d_delta.reserve(channels * n + 128)) return false;     // + slack: the exact pass prefetches bursts past a run
     if (!d_carry.reserve(channels * (size_t)chunks * nb)) return false;
-    last_chain = use_chain ? (use_relay ? 3 : (use_ring ? 2 : 1)) : 0;
+    last_chain = use_chain ? 3 : 0;
     if ((exact || chunks == 1) && !use_chain && !d_seed.reserve(channels * (size_t)chunks * nb)) return false;
     if (use_chain && !ensure_fseed(cL)) return false;
 
@@ -786,7 +716,7 @@ class Plan
       // once the relays are through.  The forward launch is held back (hipStreamWaitValue32 on a word every relay workgroup
       // bumps at its start) until the relays are resident: a forward workgroup that waits for a relay which cannot start
       // would be a deadlock -- every wait in the kernels is bounded all the same, and a time-out re-runs the call (forward_device).
-      flow = use_relay && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && wait_value_ok();
+      flow = use_chain && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && wait_value_ok();
       if (flow) segments = 1;
       if (flow && started_target > (1u << 30))
       {
@@ -839,9 +769,9 @@ class Plan
         cc.acc_state = sg == 0 ? acc_p() : d_run_acc[(sg - 1) & 1].p;
         cc.acc_next = segments > 1 ? d_run_acc[sg & 1].p : nullptr;
         cc.n = n; cc.nbins = (unsigned)nb; cc.chunks = (unsigned)chunks; cc.chunk_len = (unsigned)len; cc.cursor0 = (unsigned)cursor;
-        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = cP; cc.NB = use_ring ? ring_blocks(cL) : 0u; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & (47u | 128u); cc.stats = nullptr;
+        cc.chunk0 = (unsigned)j0; cc.launch_chunks = (unsigned)(j1 - j0); cc.L = cL; cc.P = 0; cc.chunk_shift = shift; cc.debug = (unsigned)opt_chain_debug & (47u | 128u); cc.stats = nullptr;
         if (opt_chain_debug & (16 | 64 | 128)) { if (!d_chain_stats.reserve(64 + 3 * 1024)) return false; cc.stats = d_chain_stats.p; }
-        cc.status = (use_ring && ensure_status()) ? d_status : nullptr;
+        cc.status = ensure_status() ? d_status : nullptr;
         if (cc.status) status_armed = true;
         cc.ready = nullptr; cc.ready_seq = 0; cc.started = nullptr; cc.chunks_channels = (unsigned)channels;
         if (flow)
@@ -859,28 +789,14 @@ class Plan
         }
         const unsigned cblocks = eblocks * (unsigned)channels;
         bool ok = true;
-        if (use_relay)
+        switch (cL)
         {
-          switch (rL)
-          {
-            case 128: ok = launch_relay<128>(cc, cblocks, carry_stream); break;
-            case 64:  ok = launch_relay<64>(cc, cblocks, carry_stream); break;
-            case 32:  ok = launch_relay<32>(cc, cblocks, carry_stream); break;
-            case 16:  ok = launch_relay<16>(cc, cblocks, carry_stream); break;
-            default:  ok = launch_relay<8>(cc, cblocks, carry_stream); break;
-          }
+          case 128: ok = launch_relay<128>(cc, cblocks, carry_stream); break;
+          case 64:  ok = launch_relay<64>(cc, cblocks, carry_stream); break;
+          case 32:  ok = launch_relay<32>(cc, cblocks, carry_stream); break;
+          case 16:  ok = launch_relay<16>(cc, cblocks, carry_stream); break;
+          default:  ok = launch_relay<8>(cc, cblocks, carry_stream); break;
         }
-        else if (use_ring)
-        {
-          // ring form: blocks of 64 (FD float) / 32 (FD double) steps where the geometry allows
-          if (rL == 64) { if constexpr (sizeof(FD) == 4) ok = launch_ring<64>(cc, cblocks, carry_stream); }
-          else if (rL == 32) ok = launch_ring<32>(cc, cblocks, carry_stream);
-          else if (rL == 16) ok = launch_ring<16>(cc, cblocks, carry_stream);
-          else ok = launch_ring<8>(cc, cblocks, carry_stream);
-        }
-        else if (cL == 32) { if constexpr (sizeof(FD) == 4) ok = launch_chain<32>(cc, cblocks, carry_stream); }
-        else if (cL == 16) ok = launch_chain<16>(cc, cblocks, carry_stream);
-        else ok = launch_chain<8>(cc, cblocks, carry_stream);
         if (!ok) return false;
         if (segments > 1 || flow) SDFT_TRY(hipEventRecord(seg_events[sg], aux));
         if (flow)
@@ -1180,7 +1096,7 @@ class Plan
     return true;
   }
 
-  // fused call, one time chunk, folded form: one launch (process_hop_kernel); the caller has folded the coefficients
+  // fused call, one time chunk, folded form: one launch (process_hop2_kernel); the caller has folded the coefficients
   DevBuf<double> d_partial;
   DevBuf<unsigned> d_tickets;
   // completion word in pinned host memory: the kernels of short synchronous calls set it (signal_done), finish()
@@ -1256,14 +1172,10 @@ class Plan
     pa.n = n; pa.nbins = (unsigned)nb; pa.tiles = (unsigned)ptiles; pa.cursor0 = (unsigned)cursor; pa.sweight = tab.sweight;
     pa.done = arm_flag((unsigned)channels);                  // every channel's last workgroup reports
     if (!prof_begin(ST_FORWARD)) return false;
-    if (opt_hop_pipe)                                        // two waves per tile (recurrence | coefficients + sums)
-    {
-      if (!coeff_has_beta) hipLaunchKernelGGL((process_hop2_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
-      else                 hipLaunchKernelGGL((process_hop2_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
-    }
-    else if (!coeff_has_beta) hipLaunchKernelGGL((process_hop_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
-    else                      hipLaunchKernelGGL((process_hop_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(kWave), 0, stream, pa);
-    last_hop_pipe = opt_hop_pipe ? 1 : 0;
+    // two waves per tile (recurrence | coefficients + sums)
+    if (!coeff_has_beta) hipLaunchKernelGGL((process_hop2_kernel<TD, FD, false>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
+    else                 hipLaunchKernelGGL((process_hop2_kernel<TD, FD, true>), dim3((unsigned)(channels * ptiles)), dim3(2 * kWave), 0, stream, pa);
+    last_hop_pipe = 1;
     SDFT_TRY(hipGetLastError());
     if (!prof_end(ST_FORWARD)) return false;
     hist_cur ^= 1; st_cur ^= 1;
@@ -1601,14 +1513,6 @@ class Plan
       SDFT_TRY(hipStreamSynchronize(stream));
       SDFT_TRY(hipMemcpy(out32, d_partial.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       hop2_stamps = false;
-      return true;
-    }
-    // ... of the last process_hop_kernel's last workgroup
-    if (d_partial.p && last_partial_elems)
-    {
-      memset(out32, 0, 32 * sizeof(unsigned long long));
-      SDFT_TRY(hipStreamSynchronize(stream));
-      SDFT_TRY(hipMemcpy(out32, d_partial.p + last_partial_elems, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       return true;
     }
 #endif
@@ -2142,7 +2046,7 @@ class Plan
     // by the four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144:
     // 5.7 ms against 4.1 ms for the two passes, which give the same bits); fused_exact = 2 insists on the kernel
     const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
-    // calls of one time chunk: the folded form in one launch (process_hop_kernel) unless the reference's order
+    // calls of one time chunk: the folded form in one launch (process_hop2_kernel) unless the reference's order
     // is wanted -- then the hop kernel + row synthesis pair below, which is bit-identical
     const bool one_chunk_folded = chunks == 1 && n <= (size_t)kHopMax && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel &&
                                   linear && one_vector;

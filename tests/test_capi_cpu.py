@@ -176,11 +176,10 @@ def test_hand_written_sequences_are_in_place(hip_library):
         assert len(re.findall(r"v_mul_f32_dpp v40, v40, v\d+ quad_perm:\[1,0,3,2\]", serial)) >= 32      # 32 steps per trip
         assert len(re.findall(r"v_pk_add_f32 v\[40:41\], v\[42:43\], v\[40:41\]", serial)) >= 32
         assert len(re.findall(r"s_load_dwordx16 s\[(64:79|80:95)\]", serial)) >= 3
-        for L in (8, 16, 32):
-            chain = "\n".join(kernels[f"carry_chain_kernel<float, {L}>"])
-            assert len(re.findall(r"v_mul_f32_dpp v\d+, v\d+, v\d+ quad_perm:\[1,0,3,2\]", chain)) >= L
-            assert "v_pk_mul_f32" not in chain and "v_pk_add_f32" not in chain                 # what the spelling-out prevents
-            assert "ds_write_b128" in chain and "ds_read_b128" in chain
+        for L in (8, 16, 32, 64, 128):                           # every block length of the relay form
+            relay = "\n".join(kernels[f"carry_relay_kernel<float, {L}, false>"])
+            assert len(re.findall(r"v_mul_f32_dpp v\d+, v\d+, v\d+ quad_perm:\[1,0,3,2\]", relay)) >= L
+            assert "v_pk_mul_f32" not in relay and "v_pk_add_f32" not in relay                 # what the spelling-out prevents
 
 
 def test_relay_form_is_what_it_claims(hip_library):

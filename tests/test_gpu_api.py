@@ -393,7 +393,7 @@ def test_ring_timeout_is_reported_and_the_call_recovers():
     rc = 0.  Now the wave that ran out reports it through a word of pinned host memory: a synchronous call restores the
     state it started from, runs again with the serial pass (bit-identical output and state) and leaves a WARNING (the call
     is valid: the error channel stays clean, so wrappers that raise on a recorded error do not make the host feed the samples twice);
-    an asynchronous call is reported by sdft_hip_synchronize.  chain_debug bit 5 makes the producers stop publishing."""
+    an asynchronous call is reported by sdft_hip_synchronize.  chain_debug bit 5 makes a wave keep the token."""
     import ctypes as C
     import torch
     m, n = 256, 40000

@@ -37,16 +37,30 @@ def test_two_rank_bench_shards_channels():
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
     # value = all ranks' samples / max-over-ranks time
     assert abs(res["value"] - 128 * 4096 / (res["ms_per_step"] * 1e-3) / 1e6) <= 0.02 * res["value"]
+    # the census that makes a multi-GPU record checkable without logs
+    rk = res["ranks"]
+    assert rk["ranks_in_collectives"] == 2 and rk["world_size"] == 2
+    assert rk["distinct_local_devices"] == (2 if not backend else 1)
+    assert rk["collective_backend"].startswith("rccl") == (not backend)
+    assert 0 < rk["ms_per_step_min_over_ranks"] <= rk["ms_per_step_max_over_ranks"] <= res["ms_per_step"] * 1.001
+    assert 0 < rk["roofline_frac_min_over_ranks"] <= rk["roofline_frac_max_over_ranks"] < 1
 
 
 def test_single_rank_bench_line_contract():
-    res = run_bench(1, "--steps", "2", "--warmup", "1", "--samples", "65536", "--cpu-samples", "8192")
+    res = run_bench(1, "--steps", "2", "--warmup", "1", "--samples", "65536", "--cpu-samples", "8192", "--no-cpu-all-cores")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in res, key
     assert res["n_gpus"] == 1 and res["vs_baseline"] is None and res["dtype"] == "f64" and res["data"] == "synthetic"
     assert res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0
     assert res["analysis_plus_synthesis_msamples_s"] > 0 and res["analysis_plus_synthesis_msamples_s"] < res["value"]
+    # round 4: every single-GPU BASELINE config and the single-sample entry points ride in the same line
+    cfg = res["configs"]
+    for key in ("config2", "config3"):
+        assert "skipped" in cfg[key] or (0 < cfg[key]["forward_frac_of_peak"] < 1 and 0 < cfg[key]["inverse_frac_of_peak"] < 1), cfg[key]
+    assert cfg["single_sample"]["sdft_us_per_call_device_row"] > 0 and cfg["single_sample"]["cpu_sdft_us_per_sample"] > 0
+    assert res["roofline"]["traffic"] is None or "replayed" in res["roofline"]["traffic_source"]
+    assert res["ranks"] is None                                                    # the census belongs to N > 1 lines
 
 
 def test_eight_rank_bench_plumbing():
@@ -60,6 +74,7 @@ def test_eight_rank_bench_plumbing():
     assert res["scaling"] == "weak" and res["cpu_baseline"] is None
     assert abs(res["value"] - 16 * 4096 / (res["ms_per_step"] * 1e-3) / 1e6) <= 0.02 * res["value"]
     assert "configs[4]" in res["config"]["workload"] and "2/GPU" in res["config"]["workload"]
+    assert res["ranks"]["ranks_in_collectives"] == 8 and res["ranks"]["world_size"] == 8
 
 
 def _hip_rank(rank, world, port, q):
