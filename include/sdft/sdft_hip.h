@@ -42,6 +42,9 @@ int         sdft_hip_check_expr(const char* expr, const char* arch);
    slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave) */
 double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
                                    unsigned chunk_len, int reps);
+/* measurement aid: occupies `cus` CUs (nothing shares them) for `milliseconds` on a stream of its own and returns at once;
+   cus = 0 waits for the release.  What a kernel keeps of its speed beside a kernel that holds part of the chip. */
+int         sdft_hip_hold_cus(unsigned cus, double milliseconds);
 /* the same for a load-only kernel (16-byte loads, four in flight per thread) */
 double      sdft_hip_load_ceiling(const void* src, size_t bytes, int reps);
 

@@ -25,7 +25,7 @@ COMBOS = ("f32f64", "f32f32", "f64f64", "f64f32")
 SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
 KERNEL_FILES = ["sdft_base.hpp", "sdft_carry_fast.hpp", "sdft_carry_exact.hpp", "sdft_forward.hpp", "sdft_forward_hop.hpp", "sdft_ops.hpp",
                 "sdft_forward_rows.hpp", "sdft_fused.hpp", "sdft_inverse.hpp"]      # in include order (sdft_kernels.hpp)
-HEADERS = ["sdft_kernels.hpp", *KERNEL_FILES, "sdft_plan.hpp", "sdft_capi.inc"]
+HEADERS = ["sdft_kernels.hpp", *KERNEL_FILES, "sdft_forward_rows_f32.hpp", "sdft_plan.hpp", "sdft_capi.inc"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

@@ -528,6 +528,20 @@ template <> SDFT_D bool relay_wait<double>(volatile __attribute__((address_space
   return left != 0;
 }
 
+// Holds the forward launch back until the relay workgroups of the call are resident (ChainArgs::started counts them): one
+// wave on the forward stream, a poll of one device word per microsecond, bounded (about 20 ms: the forward kernel's own
+// waits are bounded too, and a call whose relays never came is re-run with the serial pass).
+template <typename FD> __global__ __launch_bounds__(kWave) void relay_gate_kernel(const unsigned* started, unsigned target)   // (a template: one definition per translation unit)
+{
+  if (threadIdx.x != 0) return;
+  for (unsigned polls = 0; polls < (1u << 15); ++polls)
+  {
+    const unsigned now = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(now - target) >= 0) return;
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 // STATS: measurement build (ChainArgs::stats; instantiated for the longest block only)
 // A workgroup may hold TWO relays (ChainArgs::P waves each, 32 bins each): the pass then occupies half as many CUs, and
 // the forward launches of earlier segments -- whose 16-wave workgroups cannot share a CU with it -- keep three quarters

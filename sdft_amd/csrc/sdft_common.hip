@@ -262,9 +262,38 @@ __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t
   }
 }
 
+// measurement aid: holds one CU per workgroup (159 of the 160 KiB of LDS: no workgroup of the library shares the CU) for `ticks` of the 100 MHz clock
+// without touching memory
+__global__ __launch_bounds__(512) void hold_cu_kernel(unsigned long long ticks, unsigned* sink)
+{
+  extern __shared__ char hold_lds[];
+  hold_lds[threadIdx.x] = 1;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (threadIdx.x == 0 && hold_lds[0] == 77) *sink = 1;
+}
+
 }  // namespace sdfthip
 
 extern "C" {
+
+// measurement aid (how much of its speed does a kernel keep when another kernel holds `cus` CUs -- what the relay kernel
+// of the exact-carry route does to the forward launch): occupies `cus` CUs for `milliseconds` on a stream of its own and
+// returns at once; the held CUs are released when the time is up.  0, or -1.
+int sdft_hip_hold_cus(unsigned cus, double milliseconds)
+{
+  using namespace sdfthip;
+  static hipStream_t s = nullptr;
+  static unsigned* sink = nullptr;
+  if (!s)
+  {
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sink, 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  }
+  if (cus == 0) return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;       // wait for the release
+  hipLaunchKernelGGL(hold_cu_kernel, dim3(cus), dim3(512), 159 * 1024, s, (unsigned long long)(milliseconds * 1e5), sink);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // sdft.h:184
 extern const size_t sdft_convolution_kernel_size;

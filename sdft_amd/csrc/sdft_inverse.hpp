@@ -40,6 +40,20 @@ __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t 
   }
 }
 
+// a bin of the matrix; nt: non-temporal load (the matrix is read once: it should not push what the analysis left in the
+// Infinity Cache -- dirty lines of the same matrix's tail -- out to HBM)
+template <typename FD> SDFT_D cx<FD> load_bin(const cx<FD>* p, int nt)
+{
+  if (nt)
+  {
+    using V = typename StoreVec<FD, 1>::type;
+    const V q = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    return cmake<FD>(q.x, q.y);
+  }
+  return *p;
+}
+template <typename V> SDFT_D V load_vec(const V* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+
 template <typename TD, typename FD> struct InverseArgs
 {
   const cx<FD>* in;           // rows: in + ch*in_stride + t*N
@@ -53,6 +67,7 @@ template <typename TD, typename FD> struct InverseArgs
   FD sweight;
   SpectralOp<FD> op;          // applied to every bin on the way in (identity for sdft_isdft_n)
   DoneSignal done;            // inverse_row_kernel only: total = rows
+  int nt;                     // loads of the matrix are non-temporal (streamed past the caches: see Plan::opt_inverse_nt)
 };
 
 // VERIFY (float samples from double bins): the reference's bits from the tree sum -- the rounding-interval test of
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 #pragma unroll 4
     for (unsigned k = lane; k < a.nbins; k += kWave)
     {
-      const FD tv = synth_term<FD, LAT1, OPS>(row[k], k, a.op, a.syn, a.nbins, grow);
+      const FD tv = synth_term<FD, LAT1, OPS>(load_bin(row + k, a.nt), k, a.op, a.syn, a.nbins, grow);
       part += tv;
       if constexpr (VERIFY) mag += __builtin_fabs(tv);
     }
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
           const cx<FD>* rowp = a.in_rows ? a.in_rows[ch * a.n + r] : base + r * (size_t)a.nbins;
           if (BPL == 2 && vec_ok && k + 1 < a.nbins)
           {
-            const V q = *reinterpret_cast<const V*>(rowp + k);
+            const V q = load_vec(reinterpret_cast<const V*>(rowp + k), a.nt);
             v[i][0] = cmake<FD>((FD)q[0], (FD)q[1]);
             if constexpr (BPL == 2) v[i][1] = cmake<FD>((FD)q[2], (FD)q[3]);
           }
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
           {
 #pragma unroll
             for (int b = 0; b < BPL; ++b)
-              if (k + b < a.nbins) v[i][b] = rowp[k + b];
+              if (k + b < a.nbins) v[i][b] = load_bin(rowp + k + b, a.nt);
           }
         }
       }

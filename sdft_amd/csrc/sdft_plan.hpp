@@ -5,6 +5,7 @@
 #pragma once
 
 #include "sdft_kernels.hpp"
+#include "sdft_forward_rows_f32.hpp"      // not part of the run-time-compiled text: plain analysis only
 
 #include <math.h>
 #include <stdio.h>
@@ -152,7 +153,14 @@ class Plan
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
   long opt_pointers = 0;         // 0 = ask the runtime on every call (hipPointerGetAttributes, ~0.1 us), 1 = all device, 2 = all host
-  long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 16, 32, 64)
+  long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 4, 16, 32)
+  // Synthesis reads the matrix with non-temporal loads (-1 = by size, 0 / 1).  The host pattern is analysis -> synthesis of the
+  // same matrix: the analysis leaves the matrix's last 256 MiB dirty in the Infinity Cache, and ordinary loads of the rest
+  // push those lines out to HBM while they read -- streaming loads leave them where the next analysis overwrites them.
+  // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
+  // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
+  long opt_inverse_nt = -1;
+  long opt_inverse_depth = 0;    // ... with 16 rows: tiles in flight per wave (0 = heuristic; 1, 4)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
@@ -473,25 +481,19 @@ class Plan
   long opt_relay_flow = 1, last_flow = 0;
   DevBuf<unsigned> d_ready;
   unsigned ready_seq = 0;
-  unsigned* d_started = nullptr;      // signal memory
+  unsigned* d_started = nullptr;      // device word every relay workgroup bumps when it has started
   unsigned started_target = 0;
-  int wait_value_state = 0;           // 0 unknown, 1 usable, -1 not
-  bool wait_value_ok()
+  // The forward launch must not take CUs the relays still need (a forward workgroup that waits for a relay which cannot
+  // start would be a deadlock until the bounded polls run out): a one-wave gate kernel on the forward stream polls the
+  // word until the relays of the call are resident (round 3 used hipStreamWaitValue32 for this: the runtime's wait packet
+  // took 135 us to notice -- profiles/r04_relay_gate_trace.txt)
+  bool gate_ok()
   {
-    if (wait_value_state == 0)
-    {
-      int can = 0;
-      wait_value_state = -1;
-      if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
-          hipExtMallocWithFlags((void**)&d_started, 8, hipMallocSignalMemory) == hipSuccess)
-      {
-        if (hipMemset(d_started, 0, 8) == hipSuccess) wait_value_state = 1;
-        else { (void)hipFree(d_started); d_started = nullptr; }
-      }
-      (void)hipGetLastError();
-      started_target = 0;
-    }
-    return wait_value_state > 0;
+    if (d_started) return true;
+    if (hipMalloc((void**)&d_started, 8) != hipSuccess) { (void)hipGetLastError(); d_started = nullptr; return false; }
+    if (hipMemset(d_started, 0, 8) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_started); d_started = nullptr; return false; }
+    started_target = 0;
+    return true;
   }
   // relays (32 bins of a channel each), waves per relay; two relays may share a workgroup (FD float, option relay_groups;
   // measured slower: 12 waves of products and two chains on one CU contend for issue -- config 3 shape, 1.5 against 1.05 ms)
@@ -713,10 +715,10 @@ class Plan
       // a 16-wave forward workgroup fills a CU's registers, so the relays of segment s+1 wait until the forward launch of
       // segment s has drained (config 3: chain 0.71 ms alone + forward 1.55 ms alone = 2.2 ms together).  Here the relays
       // hold their CUs from the start, the forward workgroups take whatever is free, in time order, and the whole chip
-      // once the relays are through.  The forward launch is held back (hipStreamWaitValue32 on a word every relay workgroup
+      // once the relays are through.  The forward launch is held back (relay_gate_kernel polls a word every relay workgroup
       // bumps at its start) until the relays are resident: a forward workgroup that waits for a relay which cannot start
       // would be a deadlock -- every wait in the kernels is bounded all the same, and a time-out re-runs the call (forward_device).
-      flow = use_chain && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && wait_value_ok();
+      flow = use_chain && opt_relay_flow && opt_segments <= 0 && (fuse ? true : use_rows) && gate_ok();
       if (flow) segments = 1;
       if (flow && started_target > (1u << 30))
       {
@@ -804,7 +806,8 @@ class Plan
           // the forward launch may go once every relay workgroup of this launch is resident
           const unsigned relays = cblocks, groups = relay_groups(relays);
           started_target += (relays + groups - 1) / groups;
-          SDFT_TRY(hipStreamWaitValue32(stream, d_started, started_target, hipStreamWaitValueGte, 0xffffffffu));
+          hipLaunchKernelGGL((relay_gate_kernel<FD>), dim3(1), dim3(kWave), 0, stream, (const unsigned*)d_started, started_target);
+          SDFT_TRY(hipGetLastError());
         }
       }
       for (long sg = 0; sg < segments && !use_chain; ++sg)
@@ -1208,8 +1211,33 @@ class Plan
       default: launch_forward_rows_ts<FUSED, 2>(fa, blocks, threads); break;
     }
   }
+  // FD float, rows of a multiple of 128 bins, dense aligned output: the bin-pair kernel (sdft_forward_rows_f32.hpp)
+  long opt_rows_f32 = 1;
+  long last_rows_f32 = 0;
+  template <int S> void launch_forward_rows_f32_s(const ForwardArgs<float>& fa, unsigned blocks, unsigned threads)
+  {
+    const dim3 g(blocks), b(threads);
+    constexpr int G = 4;
+    switch (window)
+    {
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HANN, S, G>), g, b, 0, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HAMMING, S, G>), g, b, 0, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BLACKMAN, S, G>), g, b, 0, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BOXCAR, S, G>), g, b, 0, stream, fa); break;
+    }
+  }
   void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads, bool fused)
   {
+    last_rows_f32 = 0;
+    if constexpr (sizeof(FD) == 4)
+    {
+      if (opt_rows_f32 && nbins % (2 * kWave) == 0 && fa.vec_store && !fa.out_rows)
+      {
+        last_rows_f32 = 1;
+        if (row_slots() == 1) launch_forward_rows_f32_s<1>(fa, blocks, threads); else launch_forward_rows_f32_s<2>(fa, blocks, threads);
+        return;
+      }
+    }
     if constexpr (sizeof(FD) == 8) { if (fused) { launch_forward_rows_t<true>(fa, blocks, threads); return; } }
     launch_forward_rows_t<false>(fa, blocks, threads);
   }
@@ -1469,7 +1497,14 @@ class Plan
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 32, 1, false>), g, b, 0, stream, ia);
     }
-    else if (rw >= 16) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
+    else if (rw >= 16)
+    {
+      // medium calls: 16 rows per wave with a ring of 4 tiles in flight (round 4) -- a quarter of the instructions per byte
+      // of the 4-row form, and unlike one tile of look-ahead not a chain of N/16 memory round trips
+      const bool deep = opt_inverse_depth > 0 ? opt_inverse_depth >= 4 : (!OPS && total_rows < (size_t)32 * 8192);
+      if constexpr (!OPS) { if (deep) { hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 4, false>), g, b, 0, stream, ia); return; } }
+      hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
+    }
     else
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>), g, b, 0, stream, ia);
@@ -1487,6 +1522,10 @@ class Plan
     ia.n = n; ia.nbins = (unsigned)nbins; ia.channels = (unsigned)channels; ia.sweight = tab.sweight;
     ia.op = SpectralOp<FD>{}; ia.op.kind = OP_IDENTITY; ia.op.rows = 1;
     ia.done.flag = nullptr; ia.done.count = nullptr; ia.done.seq = 0; ia.done.total = 0;
+    {
+      const size_t matrix_bytes = channels * n * nbins * sizeof(fdx);
+      ia.nt = opt_inverse_nt >= 0 ? (int)(opt_inverse_nt != 0) : (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30));
+    }
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;
     const size_t total_rows = channels * n;
