@@ -48,12 +48,28 @@ def kernel_source() -> str:
     return "\n".join(parts)
 
 
+def _source_hash() -> str:
+    """Identity of what the library is built from: the CONTENTS of every source (a snapshot copied to another machine does
+    not keep modification times in any useful order: the GPU box used to rebuild a library that was up to date)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        h.update(f.encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+STAMP = os.path.join(OUT_DIR, "libsdft_hip.sources.sha256")
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as fh:
+        return fh.read().strip() != _source_hash()
 
 
 def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
@@ -111,6 +127,11 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     os.replace(tmp, LIB)
+    if not extra_flags:                                   # (a development build is never mistaken for the product)
+        with open(STAMP, "w") as fh:
+            fh.write(_source_hash() + "\n")
+    elif os.path.exists(STAMP):
+        os.remove(STAMP)
     return LIB
 
 

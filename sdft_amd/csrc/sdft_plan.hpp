@@ -152,6 +152,7 @@ class Plan
   size_t stage_bytes = kDefaultStageBytes;   // host-pointer path: staging segment size
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_pinned_io = 1;        // small host sample buffers travel through a pinned scratch the kernels access directly
   long opt_pointers = 0;         // 0 = ask the runtime on every call (hipPointerGetAttributes, ~0.1 us), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 4, 16, 32)
   // Synthesis reads the matrix with non-temporal loads (-1 = by size, 0 / 1).  The host pattern is analysis -> synthesis of the
@@ -268,10 +269,11 @@ class Plan
     d_tw.release(); d_syn.release(); d_wtab.release();
     for (int q = 0; q < 2; ++q) { d_accs[q].release(); d_fids[q].release(); }
     d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
-    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_one.release(); d_fseed.release();
+    d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_fseed.release();
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
+    if (h_io) { (void)hipHostFree(h_io); h_io = nullptr; d_io = nullptr; }
     if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
     forget_host_buffers();
     if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
@@ -1729,6 +1731,21 @@ class Plan
     return true;
   }
 
+  // Small host-side sample buffers (a hop of the host's signal, the by-value sample of sdft_sdft, the sample sdft_isdft
+  // returns) do not go through the runtime's pageable copy path (5-10 us per copy): they travel through a pinned scratch
+  // of the plan that the kernels read and write directly over PCIe, and the call completes on the kernel's completion
+  // word.  Single-sample calls on a device row: 21.9 -> see profiles/r04_single_sample.txt.
+  static constexpr size_t kIoBytes = (size_t)64 << 10;      // = kSmallHostBytes: samples in the first half... one direction per call
+  TD* h_io = nullptr;
+  TD* d_io = nullptr;
+  bool ensure_io()
+  {
+    if (h_io) return true;
+    if (hipHostMalloc((void**)&h_io, kIoBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); h_io = nullptr; return false; }
+    if (hipHostGetDevicePointer((void**)&d_io, h_io, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h_io); h_io = nullptr; d_io = nullptr; return false; }
+    return true;
+  }
+
   // ---- public entry points: dense matrices, host or device pointers ---------------------------
   // x: [channels][n], dfts: [channels][n][N]
   // x_class: -1 = classify x, 0 = x is host memory whatever option "pointers" says (by-value sample)
@@ -1746,6 +1763,19 @@ class Plan
       return ok && finish(channels * n * nbins);
     }
 
+    // small host samples, device matrix (hop-wise streaming from a host signal, sdft_sdft on a device row): through the
+    // pinned scratch, completion by the kernel's word -- the call is complete on return like every host-pointer call
+    if (!xd && od && channels * n * sizeof(TD) <= kIoBytes && opt_pinned_io && ensure_io())
+    {
+      memcpy(h_io, x, channels * n * sizeof(TD));
+      const bool saved = async; async = false;
+      flag_wanted = true;
+      const bool ok = forward_device(n, d_io, n, dfts, n * nbins, nullptr);
+      flag_wanted = false;
+      const bool done = ok && finish(channels * n * nbins);
+      async = saved;
+      return done;
+    }
     // host buffers mapped in place (see map_host): the kernels work on the caller's memory
     {
       // (a hop's samples are a different slice of the host's signal every call: a few hundred bytes go through the
@@ -1867,6 +1897,18 @@ class Plan
       flag_wanted = false;
       return ok && finish(channels * n * nbins);
     }
+    // device matrix, small host output: the kernel writes the samples into the pinned scratch
+    if (id && !yd && channels * n * sizeof(TD) <= kIoBytes && opt_pinned_io && ensure_io())
+    {
+      const bool saved = async; async = false;
+      flag_wanted = true;
+      const bool ok = inverse_device(n, dfts, n * nbins, nullptr, d_io, n);
+      flag_wanted = false;
+      const bool done = ok && finish(channels * n * nbins);
+      async = saved;
+      if (done) memcpy(y, h_io, channels * n * sizeof(TD));
+      return done;
+    }
     {
       const bool small_y = channels * n * sizeof(TD) <= kSmallHostBytes;
       const fdx* im = id ? dfts : static_cast<const fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
@@ -1953,23 +1995,12 @@ class Plan
 
   // single-sample synthesis (sdft.h:635): the result comes back by value, so a device-resident
   // row needs a one-element device buffer (owned by the plan, allocated on the plan's device)
-  DevBuf<TD> d_one;
   bool isdft_one(const fdx* dft, TD* y)
   {
     if (nbins == 0) { *y = (TD)0; return true; }           // the reference returns (td)(0 * 2)
     if (!bind()) return false;
     const bool saved = async; async = false;
-    bool ok;
-    if (on_device(dft))
-    {
-      ok = d_one.reserve(1) && inverse_device(1, dft, nbins, nullptr, d_one.p, 1);
-      if (ok) { const hipError_t e = hipMemcpyAsync(y, d_one.p, sizeof(TD), hipMemcpyDeviceToHost, stream); ok = (e == hipSuccess); if (!ok) set_error("hipMemcpyAsync", hipGetErrorString(e)); }
-      ok = ok && synchronize();
-    }
-    else
-    {
-      ok = isdft_n(1, dft, y);
-    }
+    const bool ok = isdft_n(1, dft, y);                      // (a device row: through the pinned scratch, see isdft_n)
     async = saved;
     return ok;
   }

@@ -162,7 +162,7 @@ def test_exact_carry_relay_form_long_blocks(combo, m, chunk, want_l):
         assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid) and np.array_equal(hist, rhist)
     # batched, segments on the auxiliary stream, odd wave counts
     C = 3
-    xb = np.stack([noise(20000, seed=70 + c, dtype=td) for c in range(C)])
+    xb = np.stack([noise(12000, seed=70 + c, dtype=td) for c in range(C)])
     wants = [O.best(m, "hann", 1.0, combo).sdft(xb[c]) for c in range(C)]
     for waves, segments in ((0, 0), (2, 3), (5, 1), (8, 4)):
         with make(m, "hann", 1.0, combo, C, chunk=chunk, carry=1, chain=2, relay_waves=waves, segments=segments) as p:
@@ -487,14 +487,14 @@ def test_very_large_dftsize(combo, m, n):
                                            # 2N = 2/3/5-smooth: mixed-radix FFT in the kernel (N = 1000 is the reference's test size)
                                            ("f32f64", 1000, 0), ("f64f64", 1000, 700), ("f32f64", 96, 256), ("f32f64", 250, 600),
                                            ("f32f64", 1200, 1000), ("f32f64", 45, 100)])
-@pytest.mark.parametrize("window", ["hann", "blackman"])
-def test_self_carried_chunks(combo, m, chunk, window):
+def test_self_carried_chunks(combo, m, chunk):
     """Every workgroup derives its carry-in from the raw samples (fold by cursor + one 2N-point FFT in LDS) and forms its
     own differences: no pre-pass launch.  Against the oracle, against the pre-pass form, over calls that start at
     cursor 0, mid-period and right before the roll-over, followed by a hop that reads the state the call left."""
     td, fd, fdx = O.combo_types(combo)
+    window = "blackman" if (m // 8 + chunk) % 2 else "hann"            # (both windows over the geometries, one per geometry)
     ref = O.best(m, window, 1.0, combo)
-    calls = [noise(20000, seed=31, dtype=td), sine_sweep(7001, dtype=td), noise(2 * m - 1 + 4096, seed=32, dtype=td), noise(3 * m + 700, seed=33, dtype=td)]
+    calls = [noise(12000, seed=31, dtype=td), sine_sweep(7001, dtype=td), noise(2 * m - 1 + 4096, seed=32, dtype=td), noise(3 * m + 700, seed=33, dtype=td)]
     with make(m, window, 1.0, combo, chunk=chunk, carry=0) as p, make(m, window, 1.0, combo, chunk=chunk, carry=0, self_carry=0) as q:
         for x in calls:
             want = ref.sdft(x)
@@ -621,3 +621,51 @@ def test_exact_carry_relay_flow_mode():
         acc, fid, hist, cur = p.state()
         racc, rfid, rhist, rcur = ref.state()
         assert cur == rcur and np.array_equal(acc, racc) and np.array_equal(fid, rfid)
+
+
+@pytest.mark.parametrize("combo,m,window", [("f32f32", 128, "boxcar"), ("f32f32", 128, "blackman"), ("f32f32", 1024, "hann"), ("f64f32", 256, "hamming"),
+                                            ("f32f32", 2048, "blackman"), ("f32f32", 4096, "hann"), ("f32f32", 4096, "blackman"), ("f64f32", 1024, "boxcar")])
+def test_bin_pair_kernel_is_the_generic_kernel_bit_for_bit(combo, m, window):
+    """forward_rows_f32_kernel (round 4: the lane's two adjacent bins are the halves of every packed operand) against
+    forward_rows_kernel<float, 2, ...> (option rows_f32 = 0) and the oracle: calls that cross the roll-over, start
+    mid-block, batched channels, the state they leave, and the chunk-parallel carries (float_carry_parallel), where the
+    two kernels must agree with each other."""
+    td, fd, fdx = O.combo_types(combo)
+    C = 2
+    lens = (6 * m + 4101, 2 * m + 3000 + 7, 4096)
+    xb = np.stack([noise(sum(lens), seed=90 + c, dtype=td) for c in range(C)])
+    refs = [O.best(m, window, 1.0, combo) for _ in range(C)]
+    with make(m, window, 1.0, combo, C) as p, make(m, window, 1.0, combo, C, rows_f32=0) as q:
+        i = 0
+        for n in lens:
+            seg = np.ascontiguousarray(xb[:, i:i + n])
+            got, old = p.sdft(seg), q.sdft(seg)
+            assert p.get_option("last_rows_f32") == 1 and q.get_option("last_rows_f32") == 0 and p.get_option("last_chunks") > 1
+            for c in range(C):
+                assert np.array_equal(got[c], refs[c].sdft(seg[c])), (combo, m, window, n, c)
+            assert np.array_equal(got, old)
+            i += n
+        acc, fid, hist, cur = p.state()
+        for c in range(C):
+            racc, rfid, rhist, rcur = refs[c].state()
+            assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid) and np.array_equal(hist[c], rhist)
+    x = xb[0, :5 * m + 3000]
+    with make(m, window, 1.0, combo, float_carry_parallel=1) as p, make(m, window, 1.0, combo, float_carry_parallel=1, rows_f32=0) as q:
+        assert np.array_equal(p.sdft(x), q.sdft(x)) and p.get_option("last_rows_f32") == 1 and p.get_option("last_chain") == 0
+
+
+@pytest.mark.parametrize("combo,m,n", [("f64f64", 1000, 30000), ("f32f64", 1024, 20000), ("f32f32", 4096, 9000), ("f32f64", 512, 700)])
+def test_streaming_loads_change_no_bit(combo, m, n):
+    """Option inverse_nt (non-temporal loads of the matrix in the synthesis kernels; by default chosen by the matrix size)
+    is a cache policy, not arithmetic: same bits either way, and the oracle's."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    ref = O.best(m, "hann", 0.5, combo)
+    d = ref.sdft(noise(n, seed=5, dtype=td))
+    want = ref.isdft(d)
+    dd = torch.from_numpy(d).cuda()
+    outs = []
+    for nt in (0, 1, -1):
+        with make(m, "hann", 0.5, combo, inverse_nt=nt) as p:
+            outs.append(p.isdft(dd).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], want)
