@@ -55,7 +55,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
         path = f if os.path.isabs(f) else os.path.join(CSRC, f)
-        h.update(f.encode() + b"\0")
+        h.update(os.path.basename(f).encode() + b"\0")             # (the name, not the path: the tree may live anywhere)
         with open(path, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -1878,12 +1878,13 @@ class Plan
     return true;
   }
 
-  bool isdft_n(size_t n, const fdx* dfts, TD* y)
+  // y_class: -1 = classify y, 0 = y is host memory whatever option "pointers" says (the by-value result of sdft_isdft)
+  bool isdft_n(size_t n, const fdx* dfts, TD* y, int y_class = -1)
   {
     if (n == 0) return true;
     if (!bind()) return false;
     const bool id = on_device(dfts);
-    const bool yd = on_device(y);
+    const bool yd = y_class < 0 ? on_device(y) : y_class != 0;
     if (nbins == 0)
     {
       // empty spectrum: the reference returns (td)(0 * 2)
@@ -2000,7 +2001,7 @@ class Plan
     if (nbins == 0) { *y = (TD)0; return true; }           // the reference returns (td)(0 * 2)
     if (!bind()) return false;
     const bool saved = async; async = false;
-    const bool ok = isdft_n(1, dft, y);                      // (a device row: through the pinned scratch, see isdft_n)
+    const bool ok = isdft_n(1, dft, y, 0);                   // (a device row: through the pinned scratch, see isdft_n; y lives on the host stack)
     async = saved;
     return ok;
   }
