@@ -46,8 +46,7 @@ if __name__ == "__main__":
             ("f32 generic kernel,  m=4096 blackman", 4096, "blackman", 131072, "f32f32", {"float_carry_parallel": 1, "rows_f32": 0}),
             ("f32 bin-pair kernel, m=1024 hann", 1024, "hann", 262144, "f32f32", {"float_carry_parallel": 1, "rows_f32": 1}),
             ("f32 generic kernel,  m=1024 hann", 1024, "hann", 262144, "f32f32", {"float_carry_parallel": 1, "rows_f32": 0}),
-            ("f64 kernel (pre-pass carries), m=1024 hann", 1024, "hann", 262144, "f32f64", {"self_carry": 0}),
-            ("f64 kernel, m=2048 hann", 2048, "hann", 131072, "f32f64", {"self_carry": 0})):
+            ("f64 kernel (pre-pass carries), m=1024 hann", 1024, "hann", 262144, "f32f64", {"self_carry": 0})):
         rates = [run(m, window, n, combo, held, **opts) for held in (0, 64, 128, 192)]
         print(f"{label:46s} CUs held 0 / 64 / 128 / 192: " + " / ".join(f"{r:5.0f}" for r in rates) + " GB/s"
               + f"   per free CU at 128 held: {rates[2] / 128:5.1f} GB/s")

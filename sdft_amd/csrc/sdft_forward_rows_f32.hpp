@@ -42,34 +42,43 @@ SDFT_D sdft_f2 f2_splat(float s) { return f2_make(s, s); }
 SDFT_D sdft_f2 pair_from_below(sdft_f2 fill, sdft_f2 v) { return f2_make(from_below_fill(fill.x, v.x), from_below_fill(fill.y, v.y)); }
 SDFT_D sdft_f2 pair_from_above(sdft_f2 fill, sdft_f2 v) { return f2_make(from_above_fill(fill.x, v.x), from_above_fill(fill.y, v.y)); }
 
-// the window on a bin pair: c = the pair, lo1 = (below.b1) and hi1 = (above.b0) complete m1 / p1, m2 / p2 as above;
-// operation order of window_tap (sdft.h:366-399)
-template <int WIN> SDFT_D PairF window_pair(PairF c, PairF m2, PairF p2, float w)
+// keeps a value out of the reach of the SLP vectoriser (which would re-pack scalar operations into v_pk_* plus the
+// v_mov pairs that assemble their operands: a packed instruction costs what two plain ones cost on this VALU --
+// profiles/r04_valu_issue_rates.txt -- so packing pays only where no operand has to be moved)
+SDFT_D float keep_scalar(float v) { asm volatile("" : "+v"(v)); return v; }
+
+// the window on a bin pair, as the 16 bytes the lane stores (b0.re, b0.im, b1.re, b1.im): c = the pair, m2 = (below.b0,
+// below.b1), p2 = (above.b0, above.b1); m1 = (below.b1, b0) and p1 = (b1, above.b0) are read from those.  Operation
+// order of window_tap (sdft.h:366-399).  m1 + p1 and the final scaling are plain operations (their operands / results
+// are not register pairs), everything between runs packed on the pair.
+template <int WIN> SDFT_D sdft_v4f32 window_quad(PairF c, PairF m2, PairF p2, float w)
 {
   // m1 + p1 per bin: b0: below.b1 + b1,  b1: b0 + above.b0
-  const sdft_f2 s1re = f2_make(m2.re.y + c.re.y, c.re.x + p2.re.x);
-  const sdft_f2 s1im = f2_make(m2.im.y + c.im.y, c.im.x + p2.im.x);
-  PairF y;
+  const sdft_f2 s1re = f2_make(keep_scalar(m2.re.y + c.re.y), keep_scalar(c.re.x + p2.re.x));
+  const sdft_f2 s1im = f2_make(keep_scalar(m2.im.y + c.im.y), keep_scalar(c.im.x + p2.im.x));
+  sdft_f2 tre, tim;
   if constexpr (WIN == WIN_HANN)
   {
-    y.re = ((c.re + c.re) - s1re) * w;
-    y.im = ((c.im + c.im) - s1im) * w;
+    tre = (c.re + c.re) - s1re;
+    tim = (c.im + c.im) - s1im;
   }
   else if constexpr (WIN == WIN_HAMMING)
   {
-    y.re = (c.re * 0.54f - s1re * 0.23f) * w;
-    y.im = (c.im * 0.54f - s1im * 0.23f) * w;
+    tre = c.re * 0.54f - s1re * 0.23f;
+    tim = c.im * 0.54f - s1im * 0.23f;
   }
   else if constexpr (WIN == WIN_BLACKMAN)
   {
     const sdft_f2 s2re = m2.re + p2.re, s2im = m2.im + p2.im;
-    y.re = ((c.re * 0.42f - s1re * 0.25f) + s2re * 0.04f) * w;
-    y.im = ((c.im * 0.42f - s1im * 0.25f) + s2im * 0.04f) * w;
+    tre = (c.re * 0.42f - s1re * 0.25f) + s2re * 0.04f;
+    tim = (c.im * 0.42f - s1im * 0.25f) + s2im * 0.04f;
   }
   else
   {
-    y.re = c.re * w; y.im = c.im * w;
+    tre = c.re; tim = c.im;
   }
+  sdft_v4f32 y;
+  y.x = keep_scalar(tre.x * w); y.y = keep_scalar(tim.x * w); y.z = keep_scalar(tre.y * w); y.w = keep_scalar(tim.y * w);
   return y;
 }
 
@@ -201,39 +210,59 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
     }
   };
 
-  auto finish = [&](const PairF (&x)[S], int buf, int u)
+  // phase B of one group: window and store, pair by pair; the edge quads of the NEXT pair are requested before the current
+  // one is worked on (after the barrier every wave of the SIMD would otherwise sit through the same LDS latency together)
+  auto finish_group = [&](const PairF (&x)[G][S], int buf, int m)
   {
+    sdft_v4f32 l = {}, r = {};
+    if constexpr (H >= 1) { l = edge[0][buf][0][wave]; r = edge[1][buf][0][wave]; }
 #pragma unroll
-    for (int q = 0; q < S; ++q)
+    for (int u = 0; u < G; ++u)
     {
-      const int v = q * nwaves + wave;
-      PairF m2 = x[q], p2 = x[q];
-      if constexpr (H >= 1)
+      if (u < m)
       {
-        const sdft_v4f32 l = edge[0][buf][u][v], r = edge[1][buf][u][v];     // broadcast reads
-        m2.re = pair_from_below(f2_make(l.x, l.y), x[q].re);
-        m2.im = pair_from_below(f2_make(l.z, l.w), x[q].im);
-        p2.re = pair_from_above(f2_make(r.x, r.y), x[q].re);
-        p2.im = pair_from_above(f2_make(r.z, r.w), x[q].im);
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+        {
+          sdft_v4f32 ln = {}, rn = {};
+          if constexpr (H >= 1)
+          {
+            const int un = (q + 1 < S) ? u : u + 1, qn = (q + 1 < S) ? q + 1 : 0;
+            if (un < G) { ln = edge[0][buf][un][qn * nwaves + wave]; rn = edge[1][buf][un][qn * nwaves + wave]; }   // (past m: stale, unused)
+          }
+          PairF m2 = x[u][q], p2 = x[u][q];
+          if constexpr (H >= 1)
+          {
+            m2.re = pair_from_below(f2_make(l.x, l.y), x[u][q].re);
+            m2.im = pair_from_below(f2_make(l.z, l.w), x[u][q].im);
+            p2.re = pair_from_above(f2_make(r.x, r.y), x[u][q].re);
+            p2.im = pair_from_above(f2_make(r.z, r.w), x[u][q].im);
+          }
+          store_vec(reinterpret_cast<sdft_v4f32*>(row + off_elems[q]), window_quad<WIN>(x[u][q], m2, p2, w));
+          l = ln; r = rn;
+        }
+        row += a.nbins;
       }
-      const PairF y = window_pair<WIN>(x[q], m2, p2, w);
-      sdft_v4f32 vv; vv.x = y.re.x; vv.y = y.im.x; vv.z = y.re.y; vv.w = y.im.y;
-      store_vec(reinterpret_cast<sdft_v4f32*>(row + off_elems[q]), vv);
     }
-    row += a.nbins;
   };
 
   int buf = 0;
   size_t t = t0;
+  // the differences of the next group are requested a group ahead (past the call's end: the workspace has slack)
+  float dnext[G];
+#pragma unroll
+  for (int u = 0; u < G; ++u) dnext[u] = d[t + u];
   while (t < t1)                       // all waves of the group take identical trip counts
   {
     const int m = (t1 - t < (size_t)G) ? (int)(t1 - t) : G;
     PairF xs[G][S];
+    float dl[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) dl[u] = dnext[u];
+#pragma unroll
+    for (int u = 0; u < G; ++u) dnext[u] = d[t + G + u];
     if (m == G && c + G <= maxc)
     {
-      float dl[G];
-#pragma unroll
-      for (int u = 0; u < G; ++u) dl[u] = d[t + u];
 #pragma unroll
       for (int u = 0; u < G; ++u)
       {
@@ -250,27 +279,16 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
       {
         if (u < m)
         {
-          const float dl = d[t + u];
           const bool wrap = (c == maxc);
 #pragma unroll
-          for (int q = 0; q < S; ++q) xs[u][q] = step(acc[q], fid[q], tw[q], dl, wrap);
+          for (int q = 0; q < S; ++q) xs[u][q] = step(acc[q], fid[q], tw[q], dl[u], wrap);
           c = wrap ? 0 : c + 1;
           publish(xs[u], buf, u);
         }
       }
     }
     __syncthreads();
-    if (m == G)
-    {
-#pragma unroll
-      for (int u = 0; u < G; ++u) finish(xs[u], buf, u);
-    }
-    else
-    {
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-        if (u < m) finish(xs[u], buf, u);
-    }
+    finish_group(xs, buf, m);
     t += m;
     buf ^= 1;
   }

@@ -1216,6 +1216,7 @@ class Plan
   // FD float, rows of a multiple of 128 bins, dense aligned output: the bin-pair kernel (sdft_forward_rows_f32.hpp)
   long opt_rows_f32 = 1;
   long last_rows_f32 = 0;
+  // (samples per lockstep group: 4; 2 measured slower -- 25.5 against 27.9 GB/s per CU, profiles/r04_kernels_beside_held_cus.txt)
   template <int S> void launch_forward_rows_f32_s(const ForwardArgs<float>& fa, unsigned blocks, unsigned threads)
   {
     const dim3 g(blocks), b(threads);
