@@ -81,6 +81,8 @@ if __name__ == "__main__":
     run("reference test shape m=1000", 352800, 1000, "hann", "f32f64")
     run("configs[1] with bit-exact carries (carry=1)", 1_000_000, 1024, "hann", "f32f64", carry=1)
     run("configs[2] with the serial pass instead of the chain form", 262144, 4096, "blackman", "f32f32", chain=0)
+    run("reference bench shape (cpp/examples/bench.cpp): m=1000, 44100 samples, TD = FD = double", 44100, 1000, "hann", "f64f64")
+    run("north-star size with double samples: n=48000, m=1024, f64f64", 48000, 1024, "hann", "f64f64")
     run("FD float, m=1024", 262144, 1024, "hann", "f32f32")
     run("FD float, m=1024, float_carry_parallel=1 (not the float reference's bits)", 262144, 1024, "hann", "f32f32", float_carry_parallel=1)
     run("configs[2] with float_carry_parallel=1 (not the float reference's bits)", 262144, 4096, "blackman", "f32f32", float_carry_parallel=1)
