@@ -1603,7 +1603,9 @@ class Plan
       ++flag_fallbacks;
       return synchronize();                                  // never seen: fall back to the stream
     }
-    if (opt_spin && work)
+    // (calls that stream for longer than ~60 us are better off sleeping on the stream than hammering it with queries:
+    // n = 48000, N = 1024: 169 -> 165 us per call; n <= 4096: 32 against 35 us the other way -- profiles/r04_sync_completion.txt)
+    if (opt_spin && work && (double)work * (double)sizeof(fdx) / 5.0e6 <= 60.0)
     {
       const double est_us = (double)work * (double)sizeof(fdx) / 5.0e6;      // at 5 TB/s
       const auto budget = std::chrono::microseconds((long long)std::min(5000.0, 100.0 + 2.0 * est_us));
