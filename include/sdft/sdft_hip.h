@@ -166,6 +166,13 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
                        launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
                        0 = carries by a pre-pass (two more launches); "self_carry_max" = longest call that takes it
+   "rows_f32"      1 (default) = FD float rows of a multiple of 128 bins are analysed by the bin-pair kernel (a lane's two
+                       adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
+   "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB
+                       and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back), 0 / 1
+   "inverse_depth" exact-order synthesis with 16 rows per wave: tiles in flight per wave (0 = heuristic, 1, 4)
+   "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
+                       result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
    "stage_bytes"   segment size of the host-pointer staging path
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
