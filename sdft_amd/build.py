@@ -26,7 +26,11 @@ SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
 KERNEL_FILES = ["sdft_base.hpp", "sdft_carry_fast.hpp", "sdft_carry_exact.hpp", "sdft_forward.hpp", "sdft_forward_hop.hpp", "sdft_ops.hpp",
                 "sdft_forward_rows.hpp", "sdft_fused.hpp", "sdft_inverse.hpp"]      # in include order (sdft_kernels.hpp)
 HEADERS = ["sdft_kernels.hpp", *KERNEL_FILES, "sdft_forward_rows_f32.hpp", "sdft_plan.hpp", "sdft_capi.inc"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
+# -fno-slp-vectorize: on this VALU a packed f32 instruction costs what two plain ones cost and its operands have to be
+# assembled by moves (profiles/r04_valu_issue_rates.txt); the vectoriser packs scalar float code all the same -- the generic
+# FD float row kernel runs 28.3 -> 33.9 GB/s per CU without it (profiles/r04_kernels_beside_held_cus.txt).  Kernels that
+# want packed operands write them as vector types (sdft_forward_rows_f32.hpp).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 

@@ -95,8 +95,8 @@ bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std:
   { set_error("sdft_hip_process_n (expression)", "hiprtcCreateProgram failed"); return false; }
   bool ok = g_rtc.add_name(prog, name_expr) == HIPRTC_SUCCESS;
   const std::string arch_flag = std::string("--offload-arch=") + arch;
-  const char* opts[] = {arch_flag.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-pragma-once-outside-header"};
-  if (ok && g_rtc.compile(prog, 6, opts) != HIPRTC_SUCCESS)
+  const char* opts[] = {arch_flag.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wno-pragma-once-outside-header"};
+  if (ok && g_rtc.compile(prog, 7, opts) != HIPRTC_SUCCESS)
   {
     // the compiler's words about the host's statements are the useful part of the failure
     size_t n = 0; g_rtc.log_size(prog, &n);

@@ -163,7 +163,7 @@ def test_kernels_contain_no_fused_multiply_add(hip_library, combo):
         assert not fused, (combo, name, fused[:4])
         checked += 1
         if name.startswith(("forward_kernel", "forward_hop_kernel", "forward_hop2_kernel", "forward_rows_kernel", "carry_exact_kernel")):
-            assert any(re.search(r"\bv_(pk_)?mul_f(32|64)\b", l) for l in body), name       # the arithmetic is really there
+            assert any(re.search(r"\bv_(pk_)?mul_f(32|64)(_e32|_e64|_dpp|_sdwa)?\b", l) for l in body), name       # the arithmetic is really there
     assert checked >= 40
 
 
