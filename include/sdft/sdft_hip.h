@@ -170,7 +170,6 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
    "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB
                        and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back), 0 / 1
-   "inverse_depth" exact-order synthesis with 16 rows per wave: tiles in flight per wave (0 = heuristic, 1, 4)
    "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
                        result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
    "stage_bytes"   segment size of the host-pointer staging path

@@ -127,12 +127,11 @@ if __name__ == "__main__":
                 pl.close()
             del out
     if which == "relay":
-        # exact carries: relay form against the ring form, alone (profile events) and inside the call
+        # exact carries: relay form against the serial pass, alone (profile events) and inside the call
         for shape in ((262144, 4096, "blackman", "f32f32"), (262144, 1024, "hann", "f32f32"), (1000000, 1024, "hann", "f32f64")):
             n, m, win, combo = shape
             extra = {"carry": 1} if combo == "f32f64" else {}
-            for opts in ({"chain_relay": 0}, {}, {"relay_waves": 6}, {"relay_waves": 7}, {"relay_flow": 0}, {"relay_flow": 0, "segments": 4},
-                         {"segments": 1}, {"segments": 1, "chain_relay": 0}):
+            for opts in ({"chain": 0}, {}, {"relay_waves": 6}, {"relay_waves": 7}, {"relay_flow": 0}, {"relay_flow": 0, "segments": 4}, {"segments": 1}):
                 run(n, m, win, combo, **extra, **opts)
     if which == "mid":
         # calls between a hop and the north star's 48000 samples: chunk length against wall time per call
@@ -188,54 +187,12 @@ if __name__ == "__main__":
             for ch in (0, 96, 128, 160, 192, 256, 384):
                 run(48000, 1024, chunk=ch, reps=20)
         run(48000, 1024, fft_carry=0, reps=20)
-    if which == "ringseg":
-        for sg in (2, 4, 6, 8, 12, 16):
-            run(262144, 4096, "blackman", "f32f32", segments=sg)
-        for sg in (2, 4, 8):
-            run(262144, 2048, "blackman", "f32f32", segments=sg)
-            run(262144, 1024, "hann", "f32f32", segments=sg)
-    if which == "ring64":
-        for L in (0, 16):
-            for P in (6, 7):
-                run(1000000, 1024, carry=1, segments=1, chain_block=L, chain_producers=P)
-                run(1000000, 1024, carry=1, chain_block=L, chain_producers=P)
-    if which == "ringdbg":
-        for dbg in (0, 4, 8):
-            run(262144, 1024, "hann", "f32f32", segments=1, chain_debug=dbg)
-            run(1000000, 1024, carry=1, segments=1, chain_debug=dbg)
-    if which == "ringp":
-        for P in (3, 4, 5, 6, 7):
-            run(262144, 1024, "hann", "f32f32", chain_producers=P, segments=1)
-        for L in (8, 16):
-            run(262144, 1024, "hann", "f32f32", chain_block=L, segments=1, chain_producers=7)
-        for P in (4, 6, 7):
-            run(1000000, 1024, carry=1, segments=1, chain_producers=P)
-    if which == "ring":
-        for ring in (0, 1):
-            run(262144, 1024, "hann", "f32f32", chain_ring=ring, segments=1)
-            run(262144, 1024, "hann", "f32f32", chain_ring=ring)
-            run(262144, 4096, "blackman", "f32f32", chain_ring=ring)
-            run(262144, 2048, "blackman", "f32f32", chain_ring=ring)
-            run(1000000, 1024, carry=1, chain_ring=ring)
-            run(1000000, 1024, carry=1, chain_ring=ring, segments=1)
     if which == "chainlen":
         for ch in (192, 256, 384, 768):
             run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chunk=ch)
         for ch in (192, 384):
             for sg in (4, 8):
                 run(262144, 4096, "blackman", "f32f32", chain=2, segments=sg, chunk=ch)
-        run(262144, 4096, "blackman", "f32f32", chain=2, chunk=384, chain_producers=4)
-        run(262144, 4096, "blackman", "f32f32", chain=2, chunk=384, chain_producers=3)
-    if which == "chaindbg":
-        for dbg in (0, 1, 2, 3, 5, 9, 13):
-            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_debug=dbg)
-        for P in (2, 4, 6):
-            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_producers=P)
-        for L in (8, 16):
-            run(262144, 1024, "hann", "f32f32", chain=2, segments=1, chain_block=L)
-        run(262144, 1024, "hann", "f32f32", chain=0, segments=1)
-        run(262144, 4096, "blackman", "f32f32", chain=2, segments=1)
-        run(262144, 4096, "blackman", "f32f32", chain=0, segments=1)
     if which == "exact":
         for chain in (0, 2):
             run(262144, 4096, "blackman", "f32f32", chain=chain)

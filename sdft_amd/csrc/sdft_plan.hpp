@@ -161,7 +161,6 @@ class Plan
   // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
   // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
   long opt_inverse_nt = -1;
-  long opt_inverse_depth = 0;    // ... with 16 rows: tiles in flight per wave (0 = heuristic; 1, 4)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
@@ -213,7 +212,6 @@ class Plan
   long last_hop_pipe = 0;
   long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
-  long opt_chain_relay = 1;      // exact carries: relay form (identical waves pass acc on as a token; products stay in registers)
   long opt_relay_waves = 0;      // waves per workgroup of the relay form (0 = default)
   DevBuf<unsigned long long> d_chain_stats;
   long last_chain = 0;
@@ -654,7 +652,7 @@ class Plan
     // cursor (chunk j starts at sample j*len - shift; one more chunk may be needed for the tail)
     const size_t serial_waves = ((nb + kWave / 2 - 1) / (kWave / 2)) * channels;
     const bool chain_ok = exact && chunks > 1 && opt_chain && fid_canonical && (opt_chain >= 2 || serial_waves <= 1024);
-    const unsigned cL = (chain_ok && opt_chain_relay && n < ((size_t)1 << 31)) ? relay_block(len) : 0u;
+    const unsigned cL = (chain_ok && n < ((size_t)1 << 31)) ? relay_block(len) : 0u;
     const bool use_chain = cL != 0;
     const unsigned shift = use_chain ? (unsigned)(cursor % cL) : 0u;
     if (shift) { chunks = (long)((n + shift + (size_t)len - 1) / (size_t)len); last_chunks = chunks; }
@@ -1500,14 +1498,8 @@ class Plan
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 32, 1, false>), g, b, 0, stream, ia);
     }
-    else if (rw >= 16)
-    {
-      // medium calls: 16 rows per wave with a ring of 4 tiles in flight (round 4) -- a quarter of the instructions per byte
-      // of the 4-row form, and unlike one tile of look-ahead not a chain of N/16 memory round trips
-      const bool deep = opt_inverse_depth > 0 ? opt_inverse_depth >= 4 : (!OPS && total_rows < (size_t)32 * 8192);
-      if constexpr (!OPS) { if (deep) { hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 4, false>), g, b, 0, stream, ia); return; } }
-      hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
-    }
+    // (16 rows x 4 tiles in flight was measured in round 4 and lost to 4 x 8 below 64 Ki rows and to 16 x 1 above: scripts/inverse_ab.py)
+    else if (rw >= 16) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
     else
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>), g, b, 0, stream, ia);
