@@ -552,3 +552,10 @@ def test_freed_device_address_reused_as_host_memory():
         assert hip.hipMemcpy(C.c_void_p(got.data_ptr()), dev2, C.c_size_t(nbytes), 3) == 0
         assert rel(got.cpu().numpy(), want) <= 1e-6
         assert hip.hipFree(dev2) == 0
+
+
+def test_driver_entry_point_smoke():
+    """__graft_entry__.smoke() is what the driver runs on a fresh box before the bench: it has to pass in the suite too
+    (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""
+    import __graft_entry__ as entry
+    entry.smoke()
