@@ -39,7 +39,8 @@ int         sdft_hip_check_expr(const char* expr, const char* arch);
 
 /* measurement aid: average ms of a store-only kernel over `bytes` of device memory.
    pattern 0 = linear fill; pattern 1 = the forward kernel's tiling (rows of `row_slots` 16-byte
-   slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave) */
+   slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave); pattern 2 = one workgroup per time chunk writing
+   whole rows in lockstep (`lanes` = rows per barrier); pattern 3 = the same with non-temporal stores */
 double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
                                    unsigned chunk_len, int reps);
 /* measurement aid: occupies `cus` CUs (nothing shares them) for `milliseconds` on a stream of its own and returns at once;

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void store_tiled_kernel(v2f64* dst, size_t 
 
 // pattern 2: one workgroup of row_slots/64 waves per time chunk; the waves write one whole row
 // per step and meet at a barrier every `sync_every` rows (the shape of a row-lockstep kernel)
+template <bool NT>
 __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t rows, unsigned row_slots, unsigned chunk_len,
                                                               unsigned sync_every)
 {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t
   unsigned since = 0;
   for (size_t t = t0; t < t1; ++t)
   {
-    if (threadIdx.x < row_slots) *p = v;
+    if (threadIdx.x < row_slots) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
     p += row_slots; v.x += 1.0;
     if (sync_every && ++since == sync_every) { __syncthreads(); since = 0; }
   }
@@ -311,12 +312,16 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
   auto launch = [&]() {
     if (pattern == 0)
       hipLaunchKernelGGL(store_linear_kernel, dim3(256 * 8), dim3(kBlock), 0, 0, (v2f64*)dst, slots);
-    else if (pattern == 2)
+    else if (pattern == 2 || pattern == 3)                   // 3: the same with non-temporal stores
     {
       const size_t rows = slots / row_slots;
       const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
-      hipLaunchKernelGGL(store_rowgroup_kernel, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (v2f64*)dst, rows,
-                         row_slots, chunk_len, lanes /* = sync_every */);
+      if (pattern == 2)
+        hipLaunchKernelGGL(store_rowgroup_kernel<false>, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (v2f64*)dst, rows,
+                           row_slots, chunk_len, lanes /* = sync_every */);
+      else
+        hipLaunchKernelGGL(store_rowgroup_kernel<true>, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (v2f64*)dst, rows,
+                           row_slots, chunk_len, lanes /* = sync_every */);
     }
     else
     {
