@@ -51,7 +51,8 @@ def _worker(rank, world, port, q):
         shard.barrier()
         total = shard.sum_over_ranks(local)
         rate, secs = shard.job_throughput(count * n, 0.5 + rank)      # slowest rank defines the time
-        q.put((rank, first, count, total, rate, secs))
+        census = shard.run_census(0.5 + rank, 0.7 - 0.1 * rank, rank)     # (round 4) what makes a multi-GPU record checkable
+        q.put((rank, first, count, total, rate, secs, census))
     finally:
         dist.destroy_process_group()
 
@@ -70,6 +71,13 @@ def test_two_rank_gloo_sharding():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    census = [r[-1] for r in res]
+    res = [r[:-1] for r in res]
+    for cs in census:                                              # the same census on every rank
+        assert cs["backend"] == "gloo" and cs["ranks"] == 2 and cs["world_size"] == 2 and cs["distinct_local_devices"] == 2
+        assert cs["seconds_min"] == 0.5 and cs["seconds_max"] == 1.5
+        assert np.isclose(cs["roofline_frac_min"], 0.6) and np.isclose(cs["roofline_frac_max"], 0.7)
+    assert shard.run_census(1.0, 0.5) == {"backend": None, "ranks": 1, "world_size": 1}     # no process group: one rank
     (r0, f0, c0, t0, rate0, s0), (r1, f1, c1, t1, rate1, s1) = res
     assert (f0, c0, f1, c1) == (0, 3, 3, 2)
     want = 0.0
