@@ -154,7 +154,8 @@ class Plan
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
   long opt_pinned_io = 1;        // small host sample buffers travel through a pinned scratch the kernels access directly
   long opt_pointers = 0;         // 0 = ask the runtime on every call (hipPointerGetAttributes, ~0.1 us), 1 = all device, 2 = all host
-  long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 4, 16, 32)
+  long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 4, 8, 16, 32)
+  size_t inverse_capacity[2] = {0, 0};   // waves the chip holds at once of the 4-row and the 8-row form (occupancy x CUs), 0: not asked yet
   // Synthesis reads the matrix with non-temporal loads (-1 = by size, 0 / 1).  The host pattern is analysis -> synthesis of the
   // same matrix: the analysis leaves the matrix's last 256 MiB dirty in the Infinity Cache, and ordinary loads of the rest
   // push those lines out to HBM while they read -- streaming loads leave them where the next analysis overwrites them.
@@ -1473,6 +1474,30 @@ class Plan
     last_inverse_form = 1;
     long rw = opt_inverse_rows > 0 ? opt_inverse_rows
                                    : (total_rows <= 1024 ? 1 : total_rows < 65536 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
+    // Medium calls are a staircase in the row count: the waves of a launch that does not fit the chip at once leave a last,
+    // partly filled round that runs at a lone wave's pace (a chain of memory round trips: 30-45 us).  Where 4 rows per wave
+    // need a second round and 8 rows per wave (4 tiles in flight) fit in one, the 8-row form is taken: TD = FD = double,
+    // m = 1000: 36000 ... 56000 rows 10-18 % faster (n = 44100: 137 -> 115 us), profiles/r04_synthesis_rows_per_wave.txt.
+    if constexpr (!OPS)
+    {
+      if (opt_inverse_rows <= 0 && rw == 4)
+      {
+        if (inverse_capacity[0] == 0)
+        {
+          int dev_cus = 0, b4 = 0, b8 = 0;
+          if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>, kBlock, 0) == hipSuccess &&
+              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>, kBlock, 0) == hipSuccess)
+          {
+            inverse_capacity[0] = (size_t)std::max(1, b4) * dev_cus * kWavesPerBlock;
+            inverse_capacity[1] = (size_t)std::max(1, b8) * dev_cus * kWavesPerBlock;
+          }
+          else { (void)hipGetLastError(); inverse_capacity[0] = inverse_capacity[1] = (size_t)-1; }
+        }
+        const size_t groups4 = (total_rows + 3) / 4, groups8 = (total_rows + 7) / 8;
+        if (groups4 > inverse_capacity[0] && groups8 <= inverse_capacity[1]) rw = 8;
+      }
+    }
     if (OPS && rw != 1) rw = 16;                                                 // one streaming instantiation with the operation built in
     size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
     eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
@@ -1500,6 +1525,10 @@ class Plan
     }
     // (16 rows x 4 tiles in flight was measured in round 4 and lost to 4 x 8 below 64 Ki rows and to 16 x 1 above: scripts/inverse_ab.py)
     else if (rw >= 16) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
+    else if (rw >= 8)
+    {
+      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>), g, b, 0, stream, ia);
+    }
     else
     {
       if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>), g, b, 0, stream, ia);

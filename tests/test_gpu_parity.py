@@ -348,6 +348,11 @@ def test_inverse_is_bit_identical(combo, latency):
             assert np.array_equal(p.isdft(d), want), (combo, latency, m, n)
             got = p.isdft(torch.from_numpy(d).cuda()).cpu().numpy()
             assert np.array_equal(got, want), (combo, latency, m, n)
+            # every streaming form of the exact-order kernel (rows per wave x tiles in flight; round 4 added 8 x 4)
+            for rows in (4, 8, 16) + ((32,) if combo[3:] == "f64" else ()):
+                p.set_option("inverse_rows", rows)
+                assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want), (combo, latency, m, n, rows)
+            p.set_option("inverse_rows", 0)
             p.set_option("exact_inverse", 0)                       # wave-parallel sum: inside the bar, not identical
             assert rel_err(p.isdft(d), want) <= TOL[combo[3:]]
     ch, m, n = 3, 96, 200
