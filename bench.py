@@ -219,14 +219,17 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
     res["inverse_kernel_us"] = round(pr["inverse"][0] / max(pr["inverse"][1], 1) * 1e3, 1)
     p.close()
     # the literal drop-in: malloc'ed x, buffer, y exactly as test.c:62-64 has them (numpy arrays = pageable host memory):
-    # default (copies through the runtime's pageable path) and with option host_register = 1 (the library maps the
-    # caller's buffers once and the kernels work on them over PCIe; for hosts that keep their buffers, like test.c)
+    # default (copies through pinned pieces of the plan: nothing of the caller's is handed to the runtime to pin), with
+    # option host_copy = 1 (the runtime's pageable path, for hosts that keep their buffers, like test.c) and with option
+    # host_register = 1 (the library maps the caller's buffers once and the kernels work on them over PCIe; likewise)
     xh = sine_sweep(total, dtype=td)
     yh = np.zeros(total, dtype=td)
     dh = np.zeros((hop, m), dtype=np.complex128 if combo[3:] == "f64" else np.complex64)
-    for label, reg in (("us_per_hop_host_pointers", 0), ("us_per_hop_host_pointers_registered", 1)):
+    for label, reg, rt in (("us_per_hop_host_pointers", 0, 0), ("us_per_hop_host_pointers_runtime_copy", 0, 1),
+                           ("us_per_hop_host_pointers_registered", 1, 0)):
         p = SDFT(m, "hann", 1.0, combo, device=device)
         p.set_option("host_register", reg)
+        p.set_option("host_copy", rt)
         w = 0.0
         for rep in range(2):
             t0 = time.perf_counter()

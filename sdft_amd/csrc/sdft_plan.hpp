@@ -130,6 +130,7 @@ class Plan
   Tables<FD> tab;
 
   int device = 0;
+  int compute_units = 256;       // CUs of the plan's device (one row-group workgroup each)
   hipStream_t stream = nullptr;
   bool own_stream = false, async = false;
 
@@ -240,6 +241,7 @@ class Plan
     if (window < 0 || window > 3) window = WIN_BOXCAR;      // reference: unknown window -> default branch (:394)
     tab.build(nbins, latency);
     SDFT_TRY(hipGetDevice(&device));
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) compute_units = cus; else (void)hipGetLastError(); }
     if (!lane_selftest()) return false;
     SDFT_TRY(hipStreamCreate(&stream));
     own_stream = true;
@@ -255,9 +257,9 @@ class Plan
     for (int q = 0; q < 2; ++q)
       if (!d_accs[q].reserve(channels * nb) || !d_fids[q].reserve(channels * nb)) return false;
     if (!d_hist[0].reserve(channels * span) || !d_hist[1].reserve(channels * span)) return false;
-    SDFT_TRY(hipMemcpyAsync(d_tw.p, tab.tw.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
-    SDFT_TRY(hipMemcpyAsync(d_syn.p, tab.syn.data(), nb * sizeof(fdx), hipMemcpyHostToDevice, stream));
-    SDFT_TRY(hipMemcpyAsync(d_wtab.p, tab.wtab.data(), span * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    if (!to_device(d_tw.p, tab.tw.data(), nb * sizeof(fdx))) return false;
+    if (!to_device(d_syn.p, tab.syn.data(), nb * sizeof(fdx))) return false;
+    if (!to_device(d_wtab.p, tab.wtab.data(), span * sizeof(fdx))) return false;
     return reset();
   }
 
@@ -273,6 +275,7 @@ class Plan
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
     if (h_io) { (void)hipHostFree(h_io); h_io = nullptr; d_io = nullptr; }
+    release_pin();
     if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
     forget_host_buffers();
     if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
@@ -305,7 +308,7 @@ class Plan
     SDFT_TRY(hipMemsetAsync(d_hist[0].p, 0, channels * span * sizeof(TD), stream));
     SDFT_TRY(hipMemsetAsync(acc_p(), 0, channels * nb * sizeof(fdx), stream));
     std::vector<fdx> ones(channels * nb, cmake<FD>((FD)1, (FD)0));
-    SDFT_TRY(hipMemcpyAsync(fid_p(), ones.data(), ones.size() * sizeof(fdx), hipMemcpyHostToDevice, stream));
+    if (!to_device(fid_p(), ones.data(), ones.size() * sizeof(fdx))) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     return true;
   }
@@ -426,6 +429,18 @@ class Plan
       // (measured, N = 1024 f64: n = 1024 77 -> 31 us, 4096 77 -> 36, 12000 79 -> 53, 24000 95 -> 91)
       if (mid) want = std::max(1L, std::min((190L + (long)channels - 1) / (long)channels, (long)(n / 32)));
       else want = std::max(1L, std::min(want, (long)(n / (carry_mode == CARRY_EXACT ? 128 : 192))));
+      // Whole rounds of the chip: a row group is one workgroup per CU, so a launch of 260 ... 500 workgroups on 256 CUs is one
+      // full round plus a partly filled one that takes just as long (n = 52000: 260 chunks of 200 rows 226 us = 47 % of peak,
+      // 250 chunks of 208 rows 168 us = 63.5 %; the same at 56000 / 60000 / 66000: profiles/r04_analysis_by_call_length.txt).
+      // Between one and two rounds the call takes ONE round of longer chunks.
+      if (!mid && carry_mode != CARRY_EXACT && opt_target_waves <= 0)
+      {
+        // (short rows too: N = 512 is two workgroups to a CU, yet 260 chunks take 118.5 us where 250 take 91.9 - a CU with two
+        // workgroups is simply twice as long at it)
+        const long round = (long)compute_units;
+        const long blocks = want * (long)channels;
+        if (blocks > round && blocks < 2L * round) want = std::max(1L, round / (long)channels);
+      }
       // (n = 48000: 250 chunks of 192 rows leave 6 CUs idle; 256 chunks of 188 rows were measured the same, 137.3 against
       // 137.9 us per call, and 128 chunks of 376 rows 145 us: the call is bound by HBM, not by the CUs that feed it)
       len = (long)((n + want - 1) / want);
@@ -1747,11 +1762,126 @@ class Plan
     return dev;
   }
 
-  // one strip per channel; per-channel async copies (no pitch limits, works for any size)
+  // ---- copies between the caller's host memory and the device ---------------------------------------------------
+  // The runtime's own path for pageable memory PINS the caller's pages once a copy exceeds its threshold (about 1 MiB) and
+  // remembers the pin per stream, keyed by address and size.  A host that frees such a buffer, lets the heap shrink and
+  // later gets the address back (numpy does; so does any long-lived process) makes the next copy find a pin whose pages
+  // left the process in between -- the driver does not re-attach it and the copy kernel faults the GPU ("Write access to a
+  // read-only page", the process is gone; seen in this library's own test suite about one run in three, round 4).  So
+  // nothing of the caller's is ever handed to the runtime to pin: copies beyond 64 KiB go through a pair of pinned 2 MiB
+  // pieces of the plan (DMA of one piece while the host copies the other), smaller ones through the runtime's staging
+  // buffers as before.  scripts/pageable_copy_probe.hip, profiles/r04_host_copy_paths.txt: every piece costs ~15 us
+  // of its own (1.6 MB in pieces of 128 KiB: 200 us), the host's memcpy out of pinned memory the device has just written
+  // runs at ~30 GB/s; 1.6 MB as one piece: 85 us out, ~55 us in, against 37 us each way on a pin the runtime remembered;
+  // long copies 26-31 against 55 GB/s.  A hop-sized matrix (up to both pieces, 4 MiB) skips the DMA: the kernels write or
+  // read the pinned pieces themselves over PCIe (sdft_n / isdft_n below; option "host_direct" = 0 turns that off).
+  // Option "host_copy" = 1 hands everything to the runtime (a host that allocates its buffers once and keeps them, like
+  // the reference's driver, loses nothing by it).
+  // Both are complete on return as far as the caller's memory goes: to_device has read it, to_host has written it.
+  static constexpr size_t kPinPiece = (size_t)2 << 20;
+  long opt_host_copy = 0;
+  long opt_host_direct = 1;                                  // hop-sized matrices: the kernels work on the pinned pieces themselves
+  char* h_pin = nullptr;
+  char* d_pin = nullptr;                                     // the same pieces as the kernels see them
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_busy[2] = {false, false};
+  long pin_copies = 0;
+  double pin_us_memcpy = 0, pin_us_device = 0;               // where a staged call's time went: the host's memcpy, waiting for the device
+  static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void free_pin_pages()
+  {
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr; d_pin = nullptr;
+  }
+  bool ensure_pin()
+  {
+    if (h_pin) return true;
+    if (hipHostMalloc((void**)&h_pin, 2 * kPinPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h_pin = nullptr; return false; }
+    if (hipHostGetDevicePointer((void**)&d_pin, h_pin, 0) != hipSuccess || !d_pin) { (void)hipGetLastError(); free_pin_pages(); return false; }
+    for (int k = 0; k < 2; ++k)
+      if (hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming) != hipSuccess)
+      {
+        (void)hipGetLastError();
+        if (k == 1) (void)hipEventDestroy(pin_ev[0]);
+        pin_ev[0] = pin_ev[1] = nullptr; free_pin_pages(); return false;
+      }
+    return true;
+  }
+  void release_pin()
+  {
+    for (int k = 0; k < 2; ++k) { if (pin_ev[k]) { (void)hipEventSynchronize(pin_ev[k]); (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; } pin_busy[k] = false; }
+    free_pin_pages();
+    (void)hipGetLastError();
+  }
+  bool pin_wait(int k)
+  {
+    if (pin_busy[k]) { SDFT_TRY(hipEventSynchronize(pin_ev[k])); pin_busy[k] = false; }
+    return true;
+  }
+  bool to_device(void* dst, const void* src, size_t bytes)
+  {
+    if (bytes == 0) return true;
+    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
+    {
+      SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+      return true;
+    }
+    ++pin_copies;
+    int k = 0;
+    for (size_t o = 0; o < bytes; o += kPinPiece, k ^= 1)
+    {
+      const size_t len = std::min(kPinPiece, bytes - o);
+      if (!pin_wait(k)) return false;
+      memcpy(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len);
+      SDFT_TRY(hipMemcpyAsync((char*)dst + o, h_pin + (size_t)k * kPinPiece, len, hipMemcpyHostToDevice, stream));
+      SDFT_TRY(hipEventRecord(pin_ev[k], stream));
+      pin_busy[k] = true;
+    }
+    return true;                                             // the pieces still in flight are waited for before their next use
+  }
+  bool to_host(void* dst, const void* src, size_t bytes)
+  {
+    if (bytes == 0) return true;
+    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
+    {
+      SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+      return true;
+    }
+    ++pin_copies;
+    int k = 0, pk = -1;
+    size_t po = 0, plen = 0;
+    for (size_t o = 0; o < bytes || pk >= 0; k ^= 1)
+    {
+      size_t len = 0;
+      if (o < bytes)
+      {
+        len = std::min(kPinPiece, bytes - o);
+        if (!pin_wait(k)) return false;
+        SDFT_TRY(hipMemcpyAsync(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len, hipMemcpyDeviceToHost, stream));
+        SDFT_TRY(hipEventRecord(pin_ev[k], stream));
+        pin_busy[k] = true;
+      }
+      if (pk >= 0)
+      {
+        if (!pin_wait(pk)) return false;
+        memcpy((char*)dst + po, h_pin + (size_t)pk * kPinPiece, plen);
+      }
+      if (o < bytes) { pk = k; po = o; plen = len; o += len; } else pk = -1;
+    }
+    return true;
+  }
+
+  // one strip per channel (no pitch limits, works for any size); kind says which side is the caller's host memory
   bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, hipMemcpyKind kind)
   {
     for (size_t c = 0; c < channels; ++c)
-      SDFT_TRY(hipMemcpyAsync((char*)dst + c * dpitch, (const char*)src + c * spitch, width, kind, stream));
+    {
+      void* d = (char*)dst + c * dpitch;
+      const void* s = (const char*)src + c * spitch;
+      if (kind == hipMemcpyHostToDevice) { if (!to_device(d, s, width)) return false; }
+      else if (kind == hipMemcpyDeviceToHost) { if (!to_host(d, s, width)) return false; }
+      else SDFT_TRY(hipMemcpyAsync(d, s, width, kind, stream));
+    }
     return true;
   }
 
@@ -1810,13 +1940,42 @@ class Plan
       if (om && !xm && !xd && small_x)
       {
         if (!d_stage_td.reserve(channels * n)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, channels * n * sizeof(TD), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_stage_td.p, x, channels * n * sizeof(TD))) return false;
         xm = d_stage_td.p;
       }
       if (xm && om)
       {
         const bool ok = forward_device(n, xm, n, om, n * nbins, nullptr);
         return ok && finish_mapped(channels * n * nbins);   // host memory: complete on return, through the stream
+      }
+    }
+    // a hop-sized matrix for host memory (the reference driver's 100 x 1000 bins = 1.6 MB, test/test.c:62-83): the kernels
+    // write it into the plan's pinned pieces over PCIe -- no staging matrix, no DMA launch -- and the host copies it out
+    // (scripts/host_hop_paths.py, profiles/r04_host_copy_paths.txt)
+    {
+      const size_t obytes = channels * n * nbins * sizeof(fdx), xbytes = channels * n * sizeof(TD);
+      if (!od && opt_host_copy == 0 && opt_host_direct && obytes <= 2 * kPinPiece && (xd || xbytes <= kSmallHostBytes) && ensure_pin())
+      {
+        if (!pin_wait(0) || !pin_wait(1)) return false;
+        const TD* xm = x;
+        if (!xd)
+        {
+          if (xbytes <= kIoBytes && opt_pinned_io && ensure_io()) { memcpy(h_io, x, xbytes); xm = d_io; }
+          else
+          {
+            if (!d_stage_td.reserve(channels * n)) return false;
+            if (!to_device(d_stage_td.p, x, xbytes)) return false;
+            xm = d_stage_td.p;
+          }
+        }
+        ++pin_copies;
+        const double t0 = now_us();
+        if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(d_pin), n * nbins, nullptr)) return false;
+        if (!finish_mapped(channels * n * nbins)) return false;
+        const double t1 = now_us();
+        memcpy(dfts, h_pin, obytes);
+        pin_us_device += t1 - t0; pin_us_memcpy += now_us() - t1;
+        return true;
       }
     }
     // staged path (host pointers): time segments so that the staging matrix stays bounded;
@@ -1875,14 +2034,14 @@ class Plan
       if (!table_on_device)
       {
         if (!d_rowptr.reserve(n)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_rowptr.p, dfts, n * sizeof(fdx*), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_rowptr.p, dfts, n * sizeof(fdx*))) return false;
         table = d_rowptr.p;
       }
       const TD* xs = x;
       if (!is_device_pointer(x))
       {
         if (!d_stage_td.reserve(n)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, n * sizeof(TD), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_stage_td.p, x, n * sizeof(TD))) return false;
         xs = d_stage_td.p;
       }
       return forward_device(n, xs, n, nullptr, 0, table) && synchronize();
@@ -1944,10 +2103,31 @@ class Plan
         bool ok = inverse_device(n, im, n * nbins, nullptr, ym, n);
         if (ok && ym == d_stage_td.p && !yd)
         {
-          const hipError_t e = hipMemcpyAsync(y, ym, channels * n * sizeof(TD), hipMemcpyDeviceToHost, stream);
-          if (e != hipSuccess) { set_error("hipMemcpyAsync", hipGetErrorString(e)); ok = false; }
+          ok = to_host(y, ym, channels * n * sizeof(TD));
         }
         return ok && finish_mapped(channels * n * nbins);
+      }
+    }
+    // a hop-sized matrix in host memory: copied into the plan's pinned pieces, which the kernel reads over PCIe
+    {
+      const size_t ibytes = channels * n * nbins * sizeof(fdx), ybytes = channels * n * sizeof(TD);
+      if (!id && opt_host_copy == 0 && opt_host_direct && ibytes <= 2 * kPinPiece && (yd || ybytes <= kSmallHostBytes) && ensure_pin())
+      {
+        if (!pin_wait(0) || !pin_wait(1)) return false;
+        const double t0 = now_us();
+        memcpy(h_pin, dfts, ibytes);
+        const double t1 = now_us();
+        pin_us_memcpy += t1 - t0;
+        ++pin_copies;
+        TD* ym = y;
+        const bool through_io = !yd && ybytes <= kIoBytes && opt_pinned_io && ensure_io();
+        if (!yd) { if (through_io) ym = d_io; else { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; } }
+        if (!inverse_device(n, reinterpret_cast<const fdx*>(d_pin), n * nbins, nullptr, ym, n)) return false;
+        if (!yd && !through_io && !to_host(y, ym, ybytes)) return false;
+        if (!finish_mapped(channels * n * nbins)) return false;
+        pin_us_device += now_us() - t1;
+        if (through_io) memcpy(y, h_io, ybytes);
+        return true;
       }
     }
     const size_t row_bytes = channels * nbins * sizeof(fdx);
@@ -1994,14 +2174,14 @@ class Plan
       if (!table_on_device)
       {
         if (!d_rowptr.reserve(n)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_rowptr.p, dfts, n * sizeof(fdx*), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_rowptr.p, dfts, n * sizeof(fdx*))) return false;
         table = d_rowptr.p;
       }
       TD* yy = y;
       const bool yd = is_device_pointer(y);
       if (!yd) { if (!d_stage_td.reserve(n)) return false; yy = d_stage_td.p; }
       if (!inverse_device(n, nullptr, 0, table, yy, n)) return false;
-      if (!yd) SDFT_TRY(hipMemcpyAsync(y, yy, n * sizeof(TD), hipMemcpyDeviceToHost, stream));
+      if (!yd && !to_host(y, yy, n * sizeof(TD))) return false;
       return synchronize();
     }
     const size_t seg = std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(nbins * sizeof(fdx), 1)));
@@ -2079,7 +2259,7 @@ class Plan
       if (!on_device(g))
       {
         if (!d_gain.reserve(rows * nbins * 2)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_gain.p, g, rows * nbins * per_bin * sizeof(FD), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_gain.p, g, rows * nbins * per_bin * sizeof(FD))) return false;
         g = d_gain.p;
       }
       op.gain = g;
@@ -2102,7 +2282,7 @@ class Plan
       else
       {
         if (!d_gain.reserve(ex->np)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_gain.p, ex->p, ex->np * sizeof(FD), hipMemcpyHostToDevice, stream));
+        if (!to_device(d_gain.p, ex->p, ex->np * sizeof(FD))) return false;
         op.gain = d_gain.p;
       }
     }
@@ -2115,7 +2295,7 @@ class Plan
     if (!xd)
     {
       if (!d_stage_td.reserve(channels * n)) return false;
-      SDFT_TRY(hipMemcpyAsync(d_stage_td.p, x, channels * n * sizeof(TD), hipMemcpyHostToDevice, stream));
+      if (!to_device(d_stage_td.p, x, channels * n * sizeof(TD))) return false;
       xs = d_stage_td.p;
     }
     TD* ys = y;
@@ -2237,7 +2417,7 @@ class Plan
     if (!ok) return false;
     if (!yd)
     {
-      SDFT_TRY(hipMemcpyAsync(y, ys, channels * n * sizeof(TD), hipMemcpyDeviceToHost, stream));
+      if (!to_host(y, ys, channels * n * sizeof(TD))) return false;
       return synchronize();
     }
     return finish(channels * n * nbins);
@@ -2277,9 +2457,10 @@ class Plan
     if (nbins)
     {
       if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }
-      if (acc) SDFT_TRY(hipMemcpy(acc_p(), acc, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice));
-      if (fid) { SDFT_TRY(hipMemcpy(fid_p(), fid, channels * nbins * sizeof(fdx), hipMemcpyHostToDevice)); fid_canonical = false; }
-      if (hist) SDFT_TRY(hipMemcpy(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD), hipMemcpyHostToDevice));
+      if (acc && !to_device(acc_p(), acc, channels * nbins * sizeof(fdx))) return false;
+      if (fid) { if (!to_device(fid_p(), fid, channels * nbins * sizeof(fdx))) return false; fid_canonical = false; }
+      if (hist && !to_device(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD))) return false;
+      SDFT_TRY(hipStreamSynchronize(stream));
     }
     cursor = cur;
     return true;
@@ -2292,9 +2473,10 @@ class Plan
     SDFT_TRY(hipStreamSynchronize(stream));
     if (nbins)
     {
-      if (acc) SDFT_TRY(hipMemcpy(acc, acc_p(), channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
-      if (fid) SDFT_TRY(hipMemcpy(fid, fid_p(), channels * nbins * sizeof(fdx), hipMemcpyDeviceToHost));
-      if (hist) SDFT_TRY(hipMemcpy(hist, d_hist[hist_cur].p, channels * 2 * nbins * sizeof(TD), hipMemcpyDeviceToHost));
+      if (acc && !to_host(acc, acc_p(), channels * nbins * sizeof(fdx))) return false;
+      if (fid && !to_host(fid, fid_p(), channels * nbins * sizeof(fdx))) return false;
+      if (hist && !to_host(hist, d_hist[hist_cur].p, channels * 2 * nbins * sizeof(TD))) return false;
+      SDFT_TRY(hipStreamSynchronize(stream));
     }
     if (cur) *cur = cursor;
     return true;
