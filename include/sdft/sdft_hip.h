@@ -112,7 +112,11 @@ int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t
 /* ---- streams ---------------------------------------------------------------------------------
    Every plan owns a HIP stream.  Calls with host pointers always return with the output
    complete.  Calls with device pointers do too unless option "async" is 1; then they return after
-   enqueueing and sdft_hip_synchronize() (or the caller's own stream sync) completes them. */
+   enqueueing and sdft_hip_synchronize() (or the caller's own stream sync) completes them.
+   Asynchronous analysis calls on the plan's OWN stream may run on internal streams beside it (option "pipeline"):
+   sdft_hip_synchronize() and every later call of the plan wait for them; a host that wants to queue its own work behind
+   a call asks for the stream with sdft_hip_get_stream() -- from then on every kernel of the plan is on that stream -- or
+   hands the plan a stream of its own with sdft_hip_set_stream(). */
 int   sdft_hip_set_stream(sdft_t* sdft, void* hip_stream /* hipStream_t */) SDFT_HIP_SYMBOL(set_stream);
 void* sdft_hip_get_stream(sdft_t* sdft) SDFT_HIP_SYMBOL(get_stream);
 int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
@@ -173,6 +177,11 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back), 0 / 1
    "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
                        result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
+   "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a
+                       small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
+                       other call of the plan and sdft_hip_synchronize wait for them.  Off by itself on a caller's stream, once
+                       sdft_hip_get_stream has been called, and with profiling.  0 = one stream.  get_option "last_pipelined",
+                       "pipelined_calls"
    "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
                        plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable
                        memory pins the pages and remembers the pin by address; a host that frees the buffer, lets the heap

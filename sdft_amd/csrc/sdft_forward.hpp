@@ -324,7 +324,7 @@ template <int CP, int QB, typename TD, typename FD>
 SDFT_D cx<FD>* self_carry(const SelfArgs<TD, FD>& sa, const ForwardArgs<FD>& a, cx<FD>* cells, unsigned chunk, size_t ch, size_t t0)
 {
   const unsigned m = 2u * a.nbins;
-  if (chunk + 1 == a.chunks)
+  if (chunk + 1 == a.chunks && sa.hist_out)
   {
     const TD* xv = sa.x + ch * sa.x_stride;
     const TD* hv = sa.hist_in + ch * (size_t)m;

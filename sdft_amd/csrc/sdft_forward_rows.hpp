@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
     if (have_prev) { __syncthreads(); sum_group(buf ^ 1, prev_m, prev_t); }      // the last group
   }
 
-  if (chunk + 1 == a.chunks)
+  if (chunk + 1 == a.chunks && a.acc_state)                // (pipelined calls: self_state_kernel has written the state already)
   {
 #pragma unroll
     for (int q = 0; q < S; ++q)
@@ -537,6 +537,30 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   if constexpr (SELF) { if (sa.stamps && chunk + 1 == a.chunks && threadIdx.x == 0) sa.stamps[6] = __builtin_readcyclecounter(); }
 #endif
   signal_done_workgroup(a.done);
+}
+
+// Pipelined calls: the plan's state AFTER a whole call, computed ahead of the call's rows -- the carry a chunk that started
+// at sample n would derive for itself (fold of all n samples + one FFT in LDS, self_carry), the rotation from the table,
+// the delay line.  One workgroup per channel, a few microseconds; with it the row kernels of consecutive calls depend on
+// this chain of small kernels only, not on each other, and run on two streams: the next call's workgroups take the CUs
+// the moment the previous call's leave them (Plan::forward_self).
+template <typename TD, typename FD>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void self_state_kernel(ForwardArgs<FD> a, SelfArgs<TD, FD> sa)
+{
+  extern __shared__ __align__(16) unsigned char rows_dyn_lds[];
+  cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
+  const size_t ch = blockIdx.x;
+  const unsigned span = 2u * a.nbins;
+  // (as the last chunk's workgroup: that one writes the delay line; "its chunk" starts where the call ends)
+  const cx<FD>* dft = self_carry<2, 16>(sa, a, cells, a.chunks - 1u, ch, a.n);
+  const unsigned c = (unsigned)(((size_t)a.cursor0 + a.n) % span);
+  for (unsigned k = threadIdx.x; k < a.nbins; k += blockDim.x)
+  {
+    cx<FD> acc = sa.acc_in[ch * a.nbins + k];
+    if (dft) acc = cadd(acc, dft[self_slot(sa, k)]);
+    a.acc_state[ch * a.nbins + k] = acc;
+    a.fid_state[ch * a.nbins + k] = a.wtab[(size_t)(((unsigned long long)k * c) % span)];
+  }
 }
 
 }  // namespace sdfthip

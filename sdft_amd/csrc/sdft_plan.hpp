@@ -184,11 +184,11 @@ class Plan
   // device-resident stream state
   DevBuf<fdx> d_tw, d_syn, d_wtab;
   // acc / fid / delay line are double-buffered: single-chunk calls read one set and write the other
-  DevBuf<fdx> d_accs[2], d_fids[2];
+  DevBuf<fdx> d_accs[4], d_fids[4];                        // state slots: a call reads [st_cur], writes [st_cur ^ 1] (pipelined calls: the next of the ring of four)
   int st_cur = 0;
   fdx* acc_p() { return d_accs[st_cur].p; }
   fdx* fid_p() { return d_fids[st_cur].p; }
-  DevBuf<TD> d_hist[2];
+  DevBuf<TD> d_hist[4];
   int hist_cur = 0;
   size_t cursor = 0;             // reference cursor (:153)
 
@@ -233,7 +233,7 @@ class Plan
   long prof_calls[ST_COUNT] = {};
 
   // last launch geometry (introspection for tests / bench)
-  long last_chunks = 0, last_chunk_len = 0, last_tiles = 0, last_interior = 0;
+  long last_chunks = 0, last_chunk_len = 0, last_tiles = 0, last_interior = 0, last_pipelined = 0;
 
   bool create(size_t dftsize, int win, double lat, size_t nch)
   {
@@ -254,9 +254,8 @@ class Plan
     if (nbins == 0) return true;
     const size_t nb = nbins, span = 2 * nbins;
     if (!d_tw.reserve(nb) || !d_syn.reserve(nb) || !d_wtab.reserve(span)) return false;
-    for (int q = 0; q < 2; ++q)
-      if (!d_accs[q].reserve(channels * nb) || !d_fids[q].reserve(channels * nb)) return false;
-    if (!d_hist[0].reserve(channels * span) || !d_hist[1].reserve(channels * span)) return false;
+    for (int q = 0; q < 4; ++q)
+      if (!d_accs[q].reserve(channels * nb) || !d_fids[q].reserve(channels * nb) || !d_hist[q].reserve(channels * span)) return false;
     if (!to_device(d_tw.p, tab.tw.data(), nb * sizeof(fdx))) return false;
     if (!to_device(d_syn.p, tab.syn.data(), nb * sizeof(fdx))) return false;
     if (!to_device(d_wtab.p, tab.wtab.data(), span * sizeof(fdx))) return false;
@@ -266,10 +265,12 @@ class Plan
   void destroy()
   {
     (void)hipSetDevice(device);
+    (void)pipe_join();
     if (stream) (void)hipStreamSynchronize(stream);
     d_tw.release(); d_syn.release(); d_wtab.release();
-    for (int q = 0; q < 2; ++q) { d_accs[q].release(); d_fids[q].release(); }
-    d_hist[0].release(); d_hist[1].release(); d_delta.release(); d_carry.release(); d_seed.release();
+    release_pipe();
+    for (int q = 0; q < 4; ++q) { d_accs[q].release(); d_fids[q].release(); d_hist[q].release(); }
+    d_delta.release(); d_carry.release(); d_seed.release();
     d_stage_td.release(); d_stage_fdx.release(); d_rowptr.release(); d_fseed.release();
     d_gain.release(); d_stage_y.release(); d_chain_stats.release();
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
@@ -301,6 +302,7 @@ class Plan
   // sdft.h:517-529
   bool reset()
   {
+    if (!pipe_join()) return false;
     cursor = 0; hist_cur = 0; st_cur = 0; fid_canonical = true;
     if (nbins == 0) return true;
     if (!bind()) return false;
@@ -315,6 +317,7 @@ class Plan
 
   bool set_stream(hipStream_t s)
   {
+    if (!pipe_join()) return false;
     if (stream) SDFT_TRY(hipStreamSynchronize(stream));
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     stream = s; own_stream = false;
@@ -323,6 +326,7 @@ class Plan
 
   bool synchronize()
   {
+    if (!pipe_join()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (status_armed)
     {
@@ -648,7 +652,7 @@ class Plan
     last_kernel = use_rows ? 2 : 1;
     last_chunks = chunks; last_chunk_len = len; last_tiles = ntiles; last_interior = inter;
     last_segments = 1; last_fused = 0; last_self = 0; last_chain = 0;
-    if (chunks == 1 && opt_hop_kernel && nbins >= 2 && !fuse) return forward_hop(n, x, x_stride, out, out_stride, rows);
+    if (chunks == 1 && opt_hop_kernel && nbins >= 2 && !fuse) { if (!pipe_join()) return false; return forward_hop(n, x, x_stride, out, out_stride, rows); }
 
     const bool exact = (carry_mode == CARRY_EXACT);
     // self-carried chunks: every workgroup derives its carry-in from the raw samples (fold + one FFT in LDS) and forms
@@ -662,6 +666,7 @@ class Plan
     const bool self = self_form && chunks > 1 && ((span & (span - 1)) == 0 || len > 64);
     last_self = self;
     if (self) return forward_self(n, x, x_stride, out, out_stride, chunks, len, fuse);
+    if (!pipe_join()) return false;
     // exact carries: relay form (seed table + identical waves that take the blocks of cL steps in turn, a block's products in
     // registers) while the serial pass would leave most SIMDs idle; the plain serial pass when bins x channels already
     // fill the chip.  The chunk grid is shifted so that every chunk but the first starts on a block boundary of the
@@ -965,6 +970,64 @@ class Plan
     return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && self_cells() != 0 && n <= self_max;
   }
 
+  // ---- pipelined calls ------------------------------------------------------------------------------------------
+  // Asynchronous analysis calls on the plan's own stream: consecutive calls' row kernels do not wait for each other.  What
+  // ties call k + 1 to call k is the plan's state; self_state_kernel computes it from the call's samples ahead of the rows
+  // (main stream: a chain of small kernels), the rows go to two streams in turn, each waiting for the state it reads only.
+  // The next call's workgroups take the CUs as the previous call's leave them: launch gap, prologue (fold + FFT, no HBM
+  // traffic) and the ragged end of a call are covered by the neighbour's stores.  State slots form a ring of four: the
+  // state kernel of call k + 3 overwrites what the rows of call k read, and waits for them.
+  // Anything else that touches the plan joins first (the main stream waits for the outstanding rows).  Off once the host has
+  // asked for the stream (sdft_hip_get_stream: it may queue work of its own behind a call), with profiling, on a caller's stream.
+  long opt_pipeline = 1;
+  bool stream_exposed = false;
+  hipStream_t row_streams[2] = {nullptr, nullptr};
+  hipEvent_t ev_pre = nullptr, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long pipe_seq = 0, pipe_calls = 0;
+  bool pipe_open = false;
+  bool ensure_pipe()
+  {
+    if (ev_pre) return true;
+    for (int i = 0; i < 2; ++i) SDFT_TRY(hipStreamCreateWithFlags(&row_streams[i], hipStreamNonBlocking));
+    SDFT_TRY(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) SDFT_TRY(hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming));
+    return true;
+  }
+  bool pipe_join()
+  {
+    if (!pipe_open) return true;
+    const unsigned long long last = pipe_seq;               // calls issued since the last join: the last one on each row stream
+    for (unsigned long long i = 0; i < 2 && i < last; ++i) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[(last - 1 - i) & 3], 0));
+    pipe_open = false; pipe_seq = 0;
+    return true;
+  }
+  void release_pipe()
+  {
+    for (int i = 0; i < 2; ++i) if (row_streams[i]) { (void)hipStreamSynchronize(row_streams[i]); (void)hipStreamDestroy(row_streams[i]); row_streams[i] = nullptr; }
+    if (ev_pre) { (void)hipEventDestroy(ev_pre); ev_pre = nullptr; }
+    for (int i = 0; i < 4; ++i) if (ev_rows[i]) { (void)hipEventDestroy(ev_rows[i]); ev_rows[i] = nullptr; }
+    pipe_open = false; pipe_seq = 0;
+    (void)hipGetLastError();
+  }
+  bool pipe_wanted(const void* fuse) const
+  {
+    return !fuse && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 && sizeof(FD) == 8;
+  }
+  bool launch_self_state(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned threads)
+  {
+    auto kern = self_state_kernel<TD, FD>;
+    const size_t lds = self_cells() * sizeof(fdx);
+    static thread_local int raised_on = -1;
+    if (raised_on != device)
+    {
+      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+      raised_on = device;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)channels), dim3(threads), lds, stream, fa, sa);
+    SDFT_TRY(hipGetLastError());
+    return true;
+  }
+
   // ---- self-carried chunks: the whole chunk-parallel call in one launch (SelfArgs in sdft_kernels.hpp) ----
   bool forward_self(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, long chunks, long len,
                     const FuseArgs<TD, FD>* fuse)
@@ -997,6 +1060,40 @@ class Plan
     const unsigned blocks = (unsigned)(channels * (size_t)chunks);
     const bool fused = opt_fused != 0;
     last_fused = fused; last_segments = 1; last_chain = 0;
+    last_pipelined = 0;
+    if constexpr (sizeof(FD) == 8)
+    {
+      if (pipe_wanted(fuse) && ensure_pipe())
+      {
+        const int s1 = (st_cur + 1) & 3, h1 = (hist_cur + 1) & 3;
+        hipStream_t rs = row_streams[pipe_seq & 1];
+        // the rows read the state everything queued on the main stream so far leaves behind
+        SDFT_TRY(hipEventRecord(ev_pre, stream));
+        SDFT_TRY(hipStreamWaitEvent(rs, ev_pre, 0));
+        // the slot the state kernel writes was read by the rows of three calls ago
+        if (pipe_seq >= 3) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[(pipe_seq + 1) & 3], 0));
+        ForwardArgs<FD> fs = fa; SelfArgs<TD, FD> ss = sa;
+        fs.acc_state = d_accs[s1].p; fs.fid_state = d_fids[s1].p; ss.hist_out = d_hist[h1].p;
+        fs.done.flag = nullptr; fs.done.count = nullptr; fs.done.seq = 0; fs.done.total = 0;
+        if (!launch_self_state(fs, ss, (unsigned)(row_waves() * kWave))) return false;
+        ForwardArgs<FD> fr = fa; SelfArgs<TD, FD> sr = sa;
+        fr.acc_state = nullptr; fr.fid_state = nullptr; sr.hist_out = nullptr;
+        fr.done.flag = nullptr; fr.done.count = nullptr; fr.done.seq = 0; fr.done.total = 0;
+        hipStream_t main_stream = stream;
+        stream = rs;
+        const bool ok = launch_forward_rows_self(fr, sr, blocks, (unsigned)(row_waves() * kWave), fused);
+        stream = main_stream;
+        if (!ok) return false;
+        SDFT_TRY(hipEventRecord(ev_rows[pipe_seq & 3], rs));
+        ++pipe_seq; ++pipe_calls; pipe_open = true;
+        last_pipelined = 1;
+        st_cur = s1; hist_cur = h1;
+        fid_canonical = true;                                // the rotation comes from the table
+        cursor = (cursor + n) % span;
+        return true;
+      }
+    }
+    if (!pipe_join()) return false;
     if (!prof_begin(ST_FORWARD)) return false;
     if constexpr (sizeof(FD) == 8)
     {
@@ -1555,6 +1652,7 @@ class Plan
   {
     if (n == 0) return true;
     SDFT_TRY(hipSetDevice(device));
+    if (!pipe_join()) return false;
     if (!prof_begin(ST_INVERSE)) return false;
     InverseArgs<TD, FD> ia;
     ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
@@ -2441,6 +2539,7 @@ class Plan
   // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)
   bool scale_rows(fdx* mat, size_t stride, size_t rows, const SpectralOp<FD>& op)
   {
+    if (!pipe_join()) return false;
     const size_t total = channels * rows * nbins;
     const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
     hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, op);
@@ -2453,6 +2552,7 @@ class Plan
   bool set_state(const fdx* acc, const fdx* fid, const TD* hist, size_t cur)
   {
     if (!bind()) return false;
+    if (!pipe_join()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (nbins)
     {
@@ -2470,6 +2570,7 @@ class Plan
   bool get_state(fdx* acc, fdx* fid, TD* hist, size_t* cur)
   {
     if (!bind()) return false;
+    if (!pipe_join()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (nbins)
     {

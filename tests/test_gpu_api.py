@@ -597,6 +597,71 @@ def test_host_memory_is_never_handed_to_the_runtime_to_pin():
         assert p.api.last_error() is None
 
 
+def test_pipelined_calls_are_the_calls_one_after_the_other():
+    """Asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a small kernel ahead
+    of the call's rows (self_state_kernel), the rows of consecutive calls run on two streams.  Same results as one stream
+    (<= 1e-12: the carry a chunk derives is the same fold + FFT either way; only the state handed to the next call is formed
+    by the state kernel instead of the last chunk's recurrence), within the oracle's bar, and everything that follows a
+    pipelined call -- synthesis, a hop, the state, a reset -- sees it complete.  Not pipelined: a caller's stream, a plan
+    whose stream the host has asked for, profiling."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    m, n, calls = 512, 20000, 7
+    xs = [noise(n, seed=50 + i) for i in range(calls)]
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = [ref.sdft(x) for x in xs]
+    hop = noise(64, seed=70)
+    want_hop = ref.sdft(hop)
+    got = {}
+    for pipe in (0, 1):
+        with SDFT(m, "hann", 1.0, "f32f64") as p:
+            p.set_option("async", 1)
+            p.set_option("pipeline", pipe)
+            outs = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(calls)]
+            xd = [torch.from_numpy(x).cuda() for x in xs]
+            for i in range(calls):
+                p.sdft(xd[i], outs[i])
+            assert p.get_option("last_pipelined") == pipe and p.get_option("pipelined_calls") == pipe * calls
+            y = p.isdft(outs[-1])                               # joins: reads what the last rows wrote
+            h = p.sdft(torch.from_numpy(hop).cuda())            # a hop on the state the state kernels left
+            p.synchronize()
+            st = p.state()
+            got[pipe] = ([o.cpu().numpy() for o in outs], y.cpu().numpy(), h.cpu().numpy(), st)
+            assert p.api.last_error() is None
+    for a, b, w in zip(got[1][0], got[0][0], want):
+        assert rel(a, b) <= 1e-12 and rel(a, w) <= 1e-11
+    assert rel(got[1][1], got[0][1]) <= 1e-6 and rel(got[1][1], ref.isdft(want[-1])) <= 1e-6
+    assert rel(got[1][2], got[0][2]) <= 1e-12 and rel(got[1][2], want_hop) <= 1e-11
+    assert got[1][3][3] == got[0][3][3] and rel(got[1][3][0], got[0][3][0]) <= 1e-12 and np.array_equal(got[1][3][2], got[0][3][2])
+    # a reset in the middle, then again
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        xd = torch.from_numpy(xs[0]).cuda()
+        a = p.sdft(xd); b = p.sdft(xd)
+        p.reset()
+        c = p.sdft(xd)
+        p.synchronize()
+        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy()) and not np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+        assert p.get_option("pipelined_calls") == 3
+        # the host asks for the stream: from here on everything is on it
+        assert p.api.get_stream(p._p)
+        p.sdft(xd)
+        assert p.get_option("last_pipelined") == 0
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        s = torch.cuda.Stream()
+        p.set_stream(s.cuda_stream)
+        p.sdft(torch.from_numpy(xs[0]).cuda())
+        p.synchronize()
+        assert p.get_option("last_pipelined") == 0 and p.get_option("pipelined_calls") == 0
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        p.set_option("profile", 1)
+        p.sdft(torch.from_numpy(xs[0]).cuda())
+        p.synchronize()
+        assert p.get_option("last_pipelined") == 0
+
+
 def test_driver_entry_point_smoke():
     """__graft_entry__.smoke() is what the driver runs on a fresh box before the bench: it has to pass in the suite too
     (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""
