@@ -146,21 +146,29 @@ def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz
     o48 = scratch.view(-1)[: n48 * m].view(n48, m)
     b48 = n48 * (m * esz + np.dtype(td).itemsize)
     res = {}
-    for mode in ("sync", "async"):
+    # (async_two_buffers: a host that alternates between two matrices -- consecutive calls then overlap, option "pipeline";
+    # calls into ONE matrix are ordered behind each other as on one stream)
+    o48b = torch.empty_like(o48)
+    for mode in ("sync", "async", "async_two_buffers"):
         p = SDFT(m, window, 1.0, combo, device=device)
-        if mode == "async":
+        if mode != "sync":
             p.set_option("async", 1)
-        xs48, os48 = C.c_void_p(x48.data_ptr()), C.c_void_p(o48.data_ptr())
-        for _ in range(5):
-            p.api.sdft_n(p._p, n48, xs48, os48)              # the raw C-ABI call, as a C host makes it
+        xs48 = C.c_void_p(x48.data_ptr())
+        os48 = [C.c_void_p(o48.data_ptr()), C.c_void_p((o48b if mode == "async_two_buffers" else o48).data_ptr())]
+        for i in range(6):
+            p.api.sdft_n(p._p, n48, xs48, os48[i & 1])       # the raw C-ABI call, as a C host makes it
         p.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(50):
-            p.api.sdft_n(p._p, n48, xs48, os48)
+        for i in range(50):
+            p.api.sdft_n(p._p, n48, xs48, os48[i & 1])
         p.synchronize(); torch.cuda.synchronize()
         w = (time.perf_counter() - t0) / 50
         res[mode] = {"ms_per_call_wall": round(w * 1e3, 4), "msamples_s_wall": round(n48 / w / 1e6, 1),
                      "gbs_wall": round(b48 / w / 1e9, 1), "frac_of_peak_wall": round(b48 / w / 1e9 / HBM_PEAK_GBS, 4)}
+        if mode == "async_two_buffers":
+            res[mode]["pipelined_calls"] = int(p.get_option("pipelined_calls"))
+            res[mode]["chunks"] = [int(p.get_option("last_chunks")), int(p.get_option("last_chunk_len"))]
+            res[mode]["row_streams"] = {0: "none (one stream)", 1: "ordinary", 2: "by priority"}.get(int(p.get_option("pipeline_streams")) // 10, "?")
         if mode == "async":
             p.set_option("profile", 1)                   # kernel time in a separate pass
             for _ in range(20):

@@ -179,9 +179,11 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
    "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a
                        small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
-                       other call of the plan and sdft_hip_synchronize wait for them.  Off by itself on a caller's stream, once
-                       sdft_hip_get_stream has been called, and with profiling.  0 = one stream.  get_option "last_pipelined",
-                       "pipelined_calls"
+                       other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
+                       the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
+                       stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
+                       profiling.  0 = one stream.  get_option "last_pipelined", "pipelined_calls", "pipelined_ordered",
+                       "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
    "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
                        plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable
                        memory pins the pages and remembers the pin by address; a host that frees the buffer, lets the heap

@@ -563,4 +563,12 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void self_state_kernel(Forwar
   }
 }
 
+// One wave that stays for `ticks` of the 100 MHz wall clock: Plan::ensure_pipe launches one on each of its streams and looks
+// whether they ran at the same time -- streams that share a hardware queue run one after the other.
+template <typename FD> __global__ __launch_bounds__(kWave) void queue_probe_kernel(unsigned long long ticks)   // (a template: one definition per translation unit)
+{
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace sdfthip

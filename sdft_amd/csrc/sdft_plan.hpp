@@ -437,7 +437,16 @@ class Plan
       // full round plus a partly filled one that takes just as long (n = 52000: 260 chunks of 200 rows 226 us = 47 % of peak,
       // 250 chunks of 208 rows 168 us = 63.5 %; the same at 56000 / 60000 / 66000: profiles/r04_analysis_by_call_length.txt).
       // Between one and two rounds the call takes ONE round of longer chunks.
-      if (!mid && carry_mode != CARRY_EXACT && opt_target_waves <= 0)
+      // Pipelined calls are the opposite case: the next call's workgroups fill whatever a launch leaves free, and a launch
+      // that fills the chip exactly keeps all workgroups in step -- every CU in its prologue at the same time, nobody storing.
+      // About 300 chunks of >= 160 rows, whatever the length (n = 48 000: 250 x 192 141 us, 300 x 160 129.5 us = 76 % of
+      // peak; 66 000: 295 x 224 best; 100 000: 313 x 320; 262 144: 298 x 880 -- profiles/r04_pipelined_calls.txt)
+      if (!mid && pipe_this && opt_target_waves <= 0)
+      {
+        const long total = std::max(1L, (300L + (long)channels - 1) / (long)channels);
+        want = std::max(1L, std::min(total, (long)(n / 160)));
+      }
+      else if (!mid && carry_mode != CARRY_EXACT && opt_target_waves <= 0)
       {
         // (short rows too: N = 512 is two workgroups to a CU, yet 260 chunks take 118.5 us where 250 take 91.9 - a CU with two
         // workgroups is simply twice as long at it)
@@ -646,6 +655,14 @@ class Plan
       long pw, ps;
       process_geometry(opt_fused != 0, pw, ps, n);
       self_form = ps <= 2 && self_cells() * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
+    }
+    // pipelined calls (forward_self): decided here because their time chunks are cut differently
+    pipe_this = false;
+    if (self_form && !fuse && !rows && out)
+    {
+      const uintptr_t olo = reinterpret_cast<uintptr_t>(out), ohi = olo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
+      pipe_this = pipe_wanted(nullptr) && !ranges_overlap(olo, ohi, prev_out);
+      prev_out = PipeRange{olo, ohi};
     }
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
@@ -980,15 +997,84 @@ class Plan
   // Anything else that touches the plan joins first (the main stream waits for the outstanding rows).  Off once the host has
   // asked for the stream (sdft_hip_get_stream: it may queue work of its own behind a call), with profiling, on a caller's stream.
   long opt_pipeline = 1;
+  long pipe_stream_kind = 0, pipe_stream_attempts = 0;        // 1 = ordinary streams, 2 = by priority (0: none found, one stream)
+  std::vector<hipStream_t> spare_streams;
   bool stream_exposed = false;
   hipStream_t row_streams[2] = {nullptr, nullptr};
   hipEvent_t ev_pre = nullptr, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned long long pipe_seq = 0, pipe_calls = 0;
+  unsigned long long pipe_seq = 0, pipe_calls = 0, pipe_ordered = 0;
   bool pipe_open = false;
+  // what the outstanding row launches write (by launch number & 3): a call whose matrix or samples overlap one of them is
+  // ordered behind it, as one stream would have it (a host that writes call after call into the same buffer gets the
+  // last call's rows, not a mixture)
+  struct PipeRange { uintptr_t lo, hi; };
+  PipeRange pipe_out[4] = {};
+  PipeRange prev_out = {0, 0};                               // the matrix of the previous analysis call of the self-carried form
+  bool pipe_this = false;                                    // forward_launch: this call is pipelined
+  int pipe_stream_of[4] = {0, 0, 0, 0};                      // the row stream a launch went to
+  static bool ranges_overlap(uintptr_t alo, uintptr_t ahi, const PipeRange& b) { return alo < b.hi && b.lo < ahi; }
   bool ensure_pipe()
   {
     if (ev_pre) return true;
-    for (int i = 0; i < 2; ++i) SDFT_TRY(hipStreamCreateWithFlags(&row_streams[i], hipStreamNonBlocking));
+    // The two row streams must not share a hardware queue with each other or with the main stream: kernels of one queue
+    // run one after the other, and the waits between the streams then only cost (the bench process measured 180 us per
+    // pipelined call at n = 48 000 where a fresh process measured 128-140; the runtime deals its few hardware queues out
+    // by its own rules).  So the streams are tried: a 200 us wave on each of the three at once (queue_probe_kernel), timed
+    // by events -- they must have run at the same time.  Up to three pairs of ordinary streams, then one stream above and
+    // one below the plan's priority (separate queue pools; 3-4 % slower than a good ordinary pair, the lower-priority
+    // launch falls behind), else the plan stays on one stream.  Once per plan, a quarter of a millisecond per pair tried.
+    {
+      SDFT_TRY(hipStreamSynchronize(stream));
+      hipEvent_t ev[6] = {};
+      for (auto& e : ev) SDFT_TRY(hipEventCreate(&e));
+      auto release_events = [&]() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+      auto concurrent = [&](hipStream_t a, hipStream_t b) -> int {
+        hipStream_t st[3] = {stream, a, b};
+        for (int i = 0; i < 3; ++i)
+        {
+          if (hipEventRecord(ev[2 * i], st[i]) != hipSuccess) return -1;
+          hipLaunchKernelGGL((queue_probe_kernel<FD>), dim3(1), dim3(kWave), 0, st[i], 20000ull);
+          if (hipEventRecord(ev[2 * i + 1], st[i]) != hipSuccess) return -1;
+        }
+        for (int i = 0; i < 3; ++i) if (hipStreamSynchronize(st[i]) != hipSuccess) return -1;
+        // three waves of 200 us: from any start to any end less than two of them
+        float span_ms = 0.f, worst = 0.f;
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j)
+          {
+            if (hipEventElapsedTime(&span_ms, ev[2 * i], ev[2 * j + 1]) != hipSuccess) return -1;
+            worst = std::max(worst, span_ms);
+          }
+        return worst < 0.35f ? 1 : 0;
+      };
+      bool found = false;
+      int lo = 0, hi = 0;                                     // (numerically: greatest = lowest priority)
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+      for (int attempt = 0; attempt < 4 && !found; ++attempt)
+      {
+        hipStream_t cand[2] = {nullptr, nullptr};
+        const bool by_priority = attempt == 3;
+        if (by_priority && lo == hi) break;
+        for (int i = 0; i < 2; ++i)
+        {
+          const hipError_t e = by_priority ? hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, i == 0 ? hi : lo)
+                                           : hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
+          if (e != hipSuccess) { (void)hipGetLastError(); if (cand[0]) (void)hipStreamDestroy(cand[0]); release_events(); return false; }
+        }
+        const int ok = concurrent(cand[0], cand[1]);
+        if (ok == 1) { row_streams[0] = cand[0]; row_streams[1] = cand[1]; found = true; pipe_stream_kind = by_priority ? 2 : 1; pipe_stream_attempts = attempt + 1; }
+        else
+        {
+          (void)hipGetLastError();
+          // (kept alive until the search is over: a destroyed stream's queue would be handed to the next candidate)
+          spare_streams.push_back(cand[0]); spare_streams.push_back(cand[1]);
+        }
+      }
+      for (hipStream_t sp : spare_streams) (void)hipStreamDestroy(sp);
+      spare_streams.clear();
+      release_events();
+      if (!found) { opt_pipeline = 0; pipe_stream_kind = 0; return false; }
+    }
     SDFT_TRY(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) SDFT_TRY(hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming));
     return true;
@@ -996,8 +1082,13 @@ class Plan
   bool pipe_join()
   {
     if (!pipe_open) return true;
-    const unsigned long long last = pipe_seq;               // calls issued since the last join: the last one on each row stream
-    for (unsigned long long i = 0; i < 2 && i < last; ++i) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[(last - 1 - i) & 3], 0));
+    // the last launch on each row stream (among the four the ring remembers; older ones are ordered before them)
+    bool seen[2] = {false, false};
+    for (unsigned long long back = 1; back <= 4 && back <= pipe_seq; ++back)
+    {
+      const int q = (int)((pipe_seq - back) & 3), rsi = pipe_stream_of[q];
+      if (!seen[rsi]) { seen[rsi] = true; SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[q], 0)); }
+    }
     pipe_open = false; pipe_seq = 0;
     return true;
   }
@@ -1063,13 +1154,39 @@ class Plan
     last_pipelined = 0;
     if constexpr (sizeof(FD) == 8)
     {
-      if (pipe_wanted(fuse) && ensure_pipe())
+      // A host that writes call after call into ONE matrix gains nothing from two streams and would pay for the order
+      // between them (an event wait across streams, satisfied or not, costs the row kernels 5-15 us per call: n = 48 000,
+      // 165-171 against 157 us): a call whose matrix overlaps the previous call's takes the one-stream form.  A host that
+      // alternates between two matrices is pipelined, each matrix on its own stream.
+      const uintptr_t olo = reinterpret_cast<uintptr_t>(out), ohi = olo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
+      if (pipe_this && !fuse && ensure_pipe())
       {
+        const uintptr_t xlo = reinterpret_cast<uintptr_t>(x), xhi = xlo + ((channels - 1) * x_stride + n) * sizeof(TD);
+        // samples that an outstanding launch is still writing (a matrix reinterpreted as samples): no overlap for this call
+        for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
+          if (ranges_overlap(xlo, xhi, pipe_out[(pipe_seq - back) & 3])) { if (!pipe_join()) return false; break; }
         const int s1 = (st_cur + 1) & 3, h1 = (hist_cur + 1) & 3;
-        hipStream_t rs = row_streams[pipe_seq & 1];
+        // Which row stream: the other one than the previous launch's -- unless this call's matrix overlaps what an
+        // outstanding launch writes (a host that reuses one matrix): then the stream of the latest such launch, whose order
+        // costs nothing (an event wait across streams costs ~15 us per call: n = 48 000 into one matrix 171 against 157 us)
+        int rsi = pipe_seq ? (pipe_stream_of[(pipe_seq - 1) & 3] ^ 1) : 0;
+        bool behind = false;
+        for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
+          if (ranges_overlap(olo, ohi, pipe_out[(pipe_seq - back) & 3])) { rsi = pipe_stream_of[(pipe_seq - back) & 3]; behind = true; break; }
+        hipStream_t rs = row_streams[rsi];
         // the rows read the state everything queued on the main stream so far leaves behind
         SDFT_TRY(hipEventRecord(ev_pre, stream));
         SDFT_TRY(hipStreamWaitEvent(rs, ev_pre, 0));
+        if (behind)
+        {
+          ++pipe_ordered;
+          // (overlapping launches on the other stream as well: the latest of them)
+          for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
+          {
+            const int q = (int)((pipe_seq - back) & 3);
+            if (pipe_stream_of[q] != rsi && ranges_overlap(olo, ohi, pipe_out[q])) { SDFT_TRY(hipStreamWaitEvent(rs, ev_rows[q], 0)); break; }
+          }
+        }
         // the slot the state kernel writes was read by the rows of three calls ago
         if (pipe_seq >= 3) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[(pipe_seq + 1) & 3], 0));
         ForwardArgs<FD> fs = fa; SelfArgs<TD, FD> ss = sa;
@@ -1085,6 +1202,8 @@ class Plan
         stream = main_stream;
         if (!ok) return false;
         SDFT_TRY(hipEventRecord(ev_rows[pipe_seq & 3], rs));
+        pipe_out[pipe_seq & 3] = PipeRange{olo, ohi};
+        pipe_stream_of[pipe_seq & 3] = rsi;
         ++pipe_seq; ++pipe_calls; pipe_open = true;
         last_pipelined = 1;
         st_cur = s1; hist_cur = h1;

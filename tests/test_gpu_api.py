@@ -633,6 +633,40 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
     assert rel(got[1][1], got[0][1]) <= 1e-6 and rel(got[1][1], ref.isdft(want[-1])) <= 1e-6
     assert rel(got[1][2], got[0][2]) <= 1e-12 and rel(got[1][2], want_hop) <= 1e-11
     assert got[1][3][3] == got[0][3][3] and rel(got[1][3][0], got[0][3][0]) <= 1e-12 and np.array_equal(got[1][3][2], got[0][3][2])
+    # call after call into the SAME matrix: the last call's rows, as on one stream (the launches are ordered behind each other);
+    # samples that are an earlier call's matrix reinterpreted
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        one = torch.empty((n, m), dtype=torch.complex128, device="cuda")
+        xd = [torch.from_numpy(x).cuda() for x in xs]
+        for i in range(calls):
+            p.sdft(xd[i], one)
+        p.synchronize()
+        assert p.get_option("pipelined_calls") == 1               # the first call only: a matrix that is reused takes the one-stream form
+        assert rel(one.cpu().numpy(), got[0][0][-1]) <= 1e-12
+        # two matrices in turn: pipelined, each matrix on its own stream, the third call behind the first
+        p.reset()
+        two = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(2)]
+        before = p.get_option("pipelined_calls")
+        for i in range(calls):
+            p.sdft(xd[i], two[i & 1])
+        p.synchronize()
+        assert p.get_option("pipelined_calls") - before == calls and p.get_option("pipelined_ordered") >= calls - 2
+        assert rel(two[(calls - 1) & 1].cpu().numpy(), got[0][0][-1]) <= 1e-12
+        assert rel(two[calls & 1].cpu().numpy(), got[0][0][-2]) <= 1e-12
+    with SDFT(m, "hann", 1.0, "f64f64") as p:
+        p.set_option("async", 1)
+        big = torch.empty((n, m), dtype=torch.complex128, device="cuda")
+        x64 = xs[0].astype(np.float64)
+        p.sdft(torch.from_numpy(x64).cuda(), big)
+        as_samples = big.view(torch.float64).reshape(-1)[:n]      # the first n doubles of that matrix, while it is being written
+        second = p.sdft(as_samples)
+        p.synchronize()
+        ref2 = O.best(m, "hann", 1.0, "f64f64")
+        d0 = ref2.sdft(x64)
+        want2 = ref2.sdft(np.ascontiguousarray(d0).view(np.float64).reshape(-1)[:n].copy())
+        assert p.get_option("pipelined_calls") == 2
+        assert rel(second.cpu().numpy(), want2) <= 1e-9
     # a reset in the middle, then again
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         p.set_option("async", 1)
