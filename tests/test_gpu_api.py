@@ -667,6 +667,24 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         want2 = ref2.sdft(np.ascontiguousarray(d0).view(np.float64).reshape(-1)[:n].copy())
         assert p.get_option("pipelined_calls") == 2
         assert rel(second.cpu().numpy(), want2) <= 1e-9
+    # a batched plan (one state workgroup per channel), a size that is not a power of two (the mixed-radix fold)
+    for mm, ch in ((512, 3), (500, 2)):
+        xb = [noise(ch * 9000, seed=80 + i).reshape(ch, 9000) for i in range(4)]
+        res = {}
+        for pipe in (0, 1):
+            with SDFT(mm, "blackman", 1.0, "f32f64", channels=ch) as p:
+                p.set_option("async", 1)
+                p.set_option("pipeline", pipe)
+                xbd = [torch.from_numpy(x).cuda() for x in xb]      # (alive until the calls are through: they are asynchronous)
+                outs = [p.sdft(x) for x in xbd]
+                p.synchronize()
+                assert p.get_option("pipelined_calls") == pipe * 4, (mm, ch, p.get_option("last_self"))
+                res[pipe] = [o.cpu().numpy() for o in outs] + [p.state()[0]]
+        for a, b in zip(res[1], res[0]):
+            assert rel(a, b) <= 1e-12
+        refb = O.best(mm, "blackman", 1.0, "f32f64")
+        want_b = [refb.sdft(x[1]) for x in xb]
+        assert rel(res[1][3][1], want_b[3]) <= 1e-11
     # a reset in the middle, then again
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         p.set_option("async", 1)
