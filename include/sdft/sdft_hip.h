@@ -188,12 +188,12 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable
                        memory pins the pages and remembers the pin by address; a host that frees the buffer, lets the heap
                        shrink and gets the address back later makes the next copy fault the GPU (process gone).  1 = the
-                       runtime's path: about twice as fast (the reference driver's hop, 1.6 MB out and back: 128 against
-                       229 us; long copies 55 against 26-31 GB/s) and safe for a host that allocates its buffers once and
-                       keeps them, like the reference's driver (test/test.c:62-83) -- as is "host_register" = 1 (112 us);
+                       runtime's path: faster (the reference driver's hop, 1.6 MB out and back: 128 against
+                       197 us; long copies 55 against 26 GB/s) and safe for a host that allocates its buffers once and
+                       keeps them, like the reference's driver (test/test.c:62-83) -- as is "host_register" = 1 (110 us);
                        get_option "host_copies_staged" counts the copies that went through the pieces
    "host_direct"   1 (default) = a host matrix of up to 4 MiB is written / read by the kernels in the pinned pieces themselves
-                       (over PCIe, no DMA launch: 229 against 251 us per hop), 0 = always DMA between staging matrix and pieces
+                       (over PCIe, no DMA launch: 197 against 224 us per hop), 0 = always DMA between staging matrix and pieces
    "stage_bytes"   segment size of the host-pointer staging path
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
   // SELF: carry-in by fold + FFT of everything before this chunk (dynamic LDS: 2N cells)
   cx<FD>* cells = reinterpret_cast<cx<FD>*>(rows_dyn_lds);
   cx<FD>* dft = nullptr;                                   // the chunk's carry-in minus acc(0), bin k at self_slot(k)
-  if constexpr (SELF) dft = self_carry<2, 16>(sa, a, cells, chunk, ch, t0);
+  // (double samples: 8 rows of the fold in flight instead of 16 -- with 16 the 128-register kernel spills 48 of them)
+  if constexpr (SELF) dft = self_carry<2, (sizeof(TD) == 8 ? 8 : 16)>(sa, a, cells, chunk, ch, t0);
 
   const long vlast_bin = (long)nv * kWave * BPL - 1;      // last (possibly virtual) bin of the group
   BinState<FD> s[S][BPL];
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void self_state_kernel(Forwar
   const size_t ch = blockIdx.x;
   const unsigned span = 2u * a.nbins;
   // (as the last chunk's workgroup: that one writes the delay line; "its chunk" starts where the call ends)
-  const cx<FD>* dft = self_carry<2, 16>(sa, a, cells, a.chunks - 1u, ch, a.n);
+  const cx<FD>* dft = self_carry<2, (sizeof(TD) == 8 ? 8 : 16)>(sa, a, cells, a.chunks - 1u, ch, a.n);
   const unsigned c = (unsigned)(((size_t)a.cursor0 + a.n) % span);
   for (unsigned k = threadIdx.x; k < a.nbins; k += blockDim.x)
   {

@@ -13,6 +13,9 @@
 #include <string.h>
 
 #include <algorithm>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <chrono>
 #include <string>
 #include <vector>
@@ -90,6 +93,36 @@ struct Tables
 enum CarryMode : int { CARRY_FAST = 0, CARRY_EXACT = 1 };
 
 enum ProfileStage : int { ST_DELTA = 0, ST_CARRY = 1, ST_FORWARD = 2, ST_INVERSE = 3, ST_COUNT = 4 };
+
+// The host's copies between the caller's memory and the plan's pinned pieces: streaming (non-temporal) stores for anything
+// beyond 256 KiB -- the destination is not read again by this core, and without the read-for-ownership of every line the
+// copy out of memory the device has just written runs at 42 instead of 30 GB/s (scripts/host_memcpy_probe.hip,
+// profiles/r04_host_copy_paths.txt; two threads spawned per piece: slower than one)
+static inline void host_copy_bytes(void* dst_, const void* src_, size_t bytes)
+{
+#if defined(__SSE2__)
+  if (bytes >= ((size_t)256 << 10))
+  {
+    char* dst = static_cast<char*>(dst_);
+    const char* src = static_cast<const char*>(src_);
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+    memcpy(dst, src, head); dst += head; src += head; bytes -= head;
+    const size_t blocks = bytes / 64;
+    for (size_t i = 0; i < blocks; ++i)
+    {
+      const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 0), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 1);
+      const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 2), d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 3);
+      _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 0, a); _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 1, b);
+      _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 2, c); _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 3, d);
+      src += 64; dst += 64;
+    }
+    _mm_sfence();
+    memcpy(dst, src, bytes - blocks * 64);
+    return;
+  }
+#endif
+  memcpy(dst_, src_, bytes);
+}
 
 static inline bool is_device_pointer(const void* p)
 {
@@ -1988,9 +2021,10 @@ class Plan
   // nothing of the caller's is ever handed to the runtime to pin: copies beyond 64 KiB go through a pair of pinned 2 MiB
   // pieces of the plan (DMA of one piece while the host copies the other), smaller ones through the runtime's staging
   // buffers as before.  scripts/pageable_copy_probe.hip, profiles/r04_host_copy_paths.txt: every piece costs ~15 us
-  // of its own (1.6 MB in pieces of 128 KiB: 200 us), the host's memcpy out of pinned memory the device has just written
-  // runs at ~30 GB/s; 1.6 MB as one piece: 85 us out, ~55 us in, against 37 us each way on a pin the runtime remembered;
-  // long copies 26-31 against 55 GB/s.  A hop-sized matrix (up to both pieces, 4 MiB) skips the DMA: the kernels write or
+  // of its own (1.6 MB in pieces of 128 KiB: 200 us), the host's copy out of pinned memory the device has just written
+  // runs at 42 GB/s with streaming stores (host_copy_bytes; glibc memcpy 30); 1.6 MB as one piece: ~70 us out, ~50 us in,
+  // against 37 us each way on a pin the runtime remembered;
+  // long copies 26 against 55 GB/s.  A hop-sized matrix (up to both pieces, 4 MiB) skips the DMA: the kernels write or
   // read the pinned pieces themselves over PCIe (sdft_n / isdft_n below; option "host_direct" = 0 turns that off).
   // Option "host_copy" = 1 hands everything to the runtime (a host that allocates its buffers once and keeps them, like
   // the reference's driver, loses nothing by it).
@@ -2049,7 +2083,7 @@ class Plan
     {
       const size_t len = std::min(kPinPiece, bytes - o);
       if (!pin_wait(k)) return false;
-      memcpy(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len);
+      host_copy_bytes(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len);
       SDFT_TRY(hipMemcpyAsync((char*)dst + o, h_pin + (size_t)k * kPinPiece, len, hipMemcpyHostToDevice, stream));
       SDFT_TRY(hipEventRecord(pin_ev[k], stream));
       pin_busy[k] = true;
@@ -2081,7 +2115,7 @@ class Plan
       if (pk >= 0)
       {
         if (!pin_wait(pk)) return false;
-        memcpy((char*)dst + po, h_pin + (size_t)pk * kPinPiece, plen);
+        host_copy_bytes((char*)dst + po, h_pin + (size_t)pk * kPinPiece, plen);
       }
       if (o < bytes) { pk = k; po = o; plen = len; o += len; } else pk = -1;
     }
@@ -2190,7 +2224,7 @@ class Plan
         if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(d_pin), n * nbins, nullptr)) return false;
         if (!finish_mapped(channels * n * nbins)) return false;
         const double t1 = now_us();
-        memcpy(dfts, h_pin, obytes);
+        host_copy_bytes(dfts, h_pin, obytes);
         pin_us_device += t1 - t0; pin_us_memcpy += now_us() - t1;
         return true;
       }
@@ -2332,7 +2366,7 @@ class Plan
       {
         if (!pin_wait(0) || !pin_wait(1)) return false;
         const double t0 = now_us();
-        memcpy(h_pin, dfts, ibytes);
+        host_copy_bytes(h_pin, dfts, ibytes);
         const double t1 = now_us();
         pin_us_memcpy += t1 - t0;
         ++pin_copies;

@@ -167,6 +167,28 @@ def test_kernels_contain_no_fused_multiply_add(hip_library, combo):
     assert checked >= 40
 
 
+@pytest.mark.parametrize("combo", ("f32f64", "f32f32", "f64f64", "f64f32"))
+def test_the_kernels_of_the_two_reference_calls_do_not_spill(hip_library, combo):
+    """The row-group analysis kernel sits at the 128 registers a 16-wave workgroup can have; one more value alive across its
+    prologue and the compiler starts spilling (round 4: the self-carried form for double samples spilled 48 registers after an
+    unrelated change, sdft_sdft_n at the reference's bench.cpp shape went from 147 to 170 us and only the bench noticed).
+    No scratch instruction in the kernels of sdft_sdft_n / sdft_isdft_n: the analysis kernels without fused synthesis (SYN = 0),
+    the bin-pair kernel, the state kernel, the exact-order synthesis kernels, the relay."""
+    kernels = disassemble(combo, hip_library)
+    checked = 0
+    for name, body in kernels.items():
+        args = re.search(r"<(.*)>", name)
+        params = [a.strip() for a in args.group(1).split(",")] if args else []
+        hot = (name.startswith("forward_rows_kernel") and len(params) > 5 and params[5] == "0") or \
+            name.startswith(("forward_rows_f32_kernel", "self_state_kernel", "inverse_exact_kernel", "carry_relay_kernel", "forward_hop2_kernel"))
+        if not hot:
+            continue
+        spills = [l for l in body if "scratch_" in l]
+        assert not spills, (combo, name, len(spills), spills[:2])
+        checked += 1
+    assert checked >= 20, checked
+
+
 def test_hand_written_sequences_are_in_place(hip_library):
     """The FD float exact passes are spelled out in ISA (pinned registers, DPP lane-pair multiplies);
     a compiler bump that drops or rewrites them must not pass silently."""
