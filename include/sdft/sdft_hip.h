@@ -182,7 +182,9 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
                        the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
                        stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
-                       profiling.  0 = one stream.  get_option "last_pipelined", "pipelined_calls", "pipelined_ordered",
+                       profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
+                       falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
+                       "pipelined_calls", "pipelined_ordered",
                        "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
    "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
                        plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable

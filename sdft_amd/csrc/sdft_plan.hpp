@@ -1083,7 +1083,7 @@ class Plan
       bool found = false;
       int lo = 0, hi = 0;                                     // (numerically: greatest = lowest priority)
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-      for (int attempt = 0; attempt < 4 && !found; ++attempt)
+      for (int attempt = (opt_pipeline == 2 ? 3 : 0); attempt < 4 && !found; ++attempt)      // (option pipeline = 2: the pair by priority at once)
       {
         hipStream_t cand[2] = {nullptr, nullptr};
         const bool by_priority = attempt == 3;

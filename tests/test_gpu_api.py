@@ -667,6 +667,18 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         want2 = ref2.sdft(np.ascontiguousarray(d0).view(np.float64).reshape(-1)[:n].copy())
         assert p.get_option("pipelined_calls") == 2
         assert rel(second.cpu().numpy(), want2) <= 1e-9
+    # the row streams picked by priority (the fallback when no ordinary pair runs concurrently): same results
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        p.set_option("pipeline", 2)
+        xd = [torch.from_numpy(x).cuda() for x in xs]
+        outs = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(calls)]
+        for i in range(calls):
+            p.sdft(xd[i], outs[i])
+        p.synchronize()
+        assert p.get_option("pipelined_calls") == calls and p.get_option("pipeline_streams") // 10 == 2
+        for o, b in zip(outs, got[1][0]):
+            assert np.array_equal(o.cpu().numpy(), b)
     # a batched plan (one state workgroup per channel), a size that is not a power of two (the mixed-radix fold)
     for mm, ch in ((512, 3), (500, 2)):
         xb = [noise(ch * 9000, seed=80 + i).reshape(ch, 9000) for i in range(4)]
