@@ -1057,10 +1057,12 @@ class Plan
     // one below the plan's priority (separate queue pools; 3-4 % slower than a good ordinary pair, the lower-priority
     // launch falls behind), else the plan stays on one stream.  Once per plan, a quarter of a millisecond per pair tried.
     {
-      SDFT_TRY(hipStreamSynchronize(stream));
+      // (nothing in here is an error of the call: a plan that cannot have its streams stays on one stream)
       hipEvent_t ev[6] = {};
-      for (auto& e : ev) SDFT_TRY(hipEventCreate(&e));
       auto release_events = [&]() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+      auto give_up = [&]() { (void)hipGetLastError(); release_events(); opt_pipeline = 0; pipe_stream_kind = 0; return false; };
+      if (hipStreamSynchronize(stream) != hipSuccess) return give_up();
+      for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { e = nullptr; return give_up(); }
       auto concurrent = [&](hipStream_t a, hipStream_t b) -> int {
         hipStream_t st[3] = {stream, a, b};
         for (int i = 0; i < 3; ++i)
@@ -1092,7 +1094,7 @@ class Plan
         {
           const hipError_t e = by_priority ? hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, i == 0 ? hi : lo)
                                            : hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
-          if (e != hipSuccess) { (void)hipGetLastError(); if (cand[0]) (void)hipStreamDestroy(cand[0]); release_events(); return false; }
+          if (e != hipSuccess) { if (cand[0]) (void)hipStreamDestroy(cand[0]); for (hipStream_t sp : spare_streams) (void)hipStreamDestroy(sp); spare_streams.clear(); return give_up(); }
         }
         const int ok = concurrent(cand[0], cand[1]);
         if (ok == 1) { row_streams[0] = cand[0]; row_streams[1] = cand[1]; found = true; pipe_stream_kind = by_priority ? 2 : 1; pipe_stream_attempts = attempt + 1; }
@@ -1105,11 +1107,12 @@ class Plan
       }
       for (hipStream_t sp : spare_streams) (void)hipStreamDestroy(sp);
       spare_streams.clear();
+      if (!found) return give_up();
       release_events();
-      if (!found) { opt_pipeline = 0; pipe_stream_kind = 0; return false; }
     }
-    SDFT_TRY(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
-    for (int i = 0; i < 4; ++i) SDFT_TRY(hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming));
+    bool ok = hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { release_pipe(); opt_pipeline = 0; pipe_stream_kind = 0; return false; }
     return true;
   }
   bool pipe_join()
