@@ -9,9 +9,10 @@ sys.path.insert(0, ".")
 from sdft_amd.sdft import SDFT
 from sdft_amd.signals import sine_sweep
 
-m = 1024
-big = [torch.empty((262144, m), dtype=torch.complex128, device="cuda") for _ in range(2)]
-for n in (12000, 24000, 36000, 48000, 48000, 66000, 131072, 262144):
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+sizes = [int(a) for a in sys.argv[2:]] or [12000, 24000, 36000, 48000, 48000, 66000, 131072, 262144]
+big = [torch.empty((max(sizes), m), dtype=torch.complex128, device="cuda") for _ in range(2)]
+for n in sizes:
     x = torch.from_numpy(sine_sweep(n)).cuda()
     o = [b[:n] for b in big]
     for pipe in (0, 1):
