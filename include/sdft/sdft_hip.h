@@ -114,7 +114,8 @@ int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t
    complete.  Calls with device pointers do too unless option "async" is 1; then they return after
    enqueueing and sdft_hip_synchronize() (or the caller's own stream sync) completes them.
    Asynchronous analysis calls on the plan's OWN stream may run on internal streams beside it (option "pipeline"):
-   sdft_hip_synchronize() and every later call of the plan wait for them; a host that wants to queue its own work behind
+   sdft_hip_synchronize() and every later call of the plan wait for them, and so does the null stream (they are blocking
+   streams like the plan's own: a plain hipMemcpy of the results sees them complete); a host that wants to queue its own work behind
    a call asks for the stream with sdft_hip_get_stream() -- from then on every kernel of the plan is on that stream -- or
    hands the plan a stream of its own with sdft_hip_set_stream(). */
 int   sdft_hip_set_stream(sdft_t* sdft, void* hip_stream /* hipStream_t */) SDFT_HIP_SYMBOL(set_stream);

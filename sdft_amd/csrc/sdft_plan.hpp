@@ -1092,8 +1092,10 @@ class Plan
         if (by_priority && lo == hi) break;
         for (int i = 0; i < 2; ++i)
         {
-          const hipError_t e = by_priority ? hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, i == 0 ? hi : lo)
-                                           : hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
+          // (blocking streams, like the plan's own: a host that reads its results with a plain hipMemcpy relies on the null
+          // stream waiting for the plan's work, and that has to include the rows)
+          const hipError_t e = by_priority ? hipStreamCreateWithPriority(&cand[i], hipStreamDefault, i == 0 ? hi : lo)
+                                           : hipStreamCreateWithFlags(&cand[i], hipStreamDefault);
           if (e != hipSuccess) { if (cand[0]) (void)hipStreamDestroy(cand[0]); for (hipStream_t sp : spare_streams) (void)hipStreamDestroy(sp); spare_streams.clear(); return give_up(); }
         }
         const int ok = concurrent(cand[0], cand[1]);

@@ -667,6 +667,22 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         want2 = ref2.sdft(np.ascontiguousarray(d0).view(np.float64).reshape(-1)[:n].copy())
         assert p.get_option("pipelined_calls") == 2
         assert rel(second.cpu().numpy(), want2) <= 1e-9
+    # a host that reads its results with a plain hipMemcpy (the null stream waits for the plan's streams, rows included)
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        import ctypes as C
+        from sdft_amd import capi
+        hip = C.CDLL(capi.hip_runtime)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        p.set_option("async", 1)
+        xd = [torch.from_numpy(x).cuda() for x in xs[:3]]
+        outs = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(3)]
+        for i in range(3):
+            p.sdft(xd[i], outs[i])
+        host = np.empty((n, m), dtype=np.complex128)
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(outs[2].data_ptr()), C.c_size_t(host.nbytes), 2) == 0   # device to host, no other synchronisation
+        assert p.get_option("pipelined_calls") == 3
+        assert np.array_equal(host, got[1][0][2])
+        p.synchronize()
     # the row streams picked by priority (the fallback when no ordinary pair runs concurrently): same results
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         p.set_option("async", 1)
