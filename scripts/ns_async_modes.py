@@ -1,5 +1,6 @@
 """North-star shape, asynchronous calls through the raw C-ABI: one matrix / two matrices in turn, pipeline 0 / 1."""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -20,6 +21,8 @@ for n in sizes:
             p = SDFT(m, "hann", 1.0, "f32f64")
             p.set_option("async", 1)
             p.set_option("pipeline", pipe)
+            if os.environ.get("SELF_MAX"):
+                p.set_option("self_carry_max", int(os.environ["SELF_MAX"]))
             xp = C.c_void_p(x.data_ptr())
             op = [C.c_void_p(o[0].data_ptr()), C.c_void_p(o[(bufs - 1)].data_ptr())]
             for i in range(6):

@@ -681,7 +681,18 @@ class Plan
     long chunks, len;
     // (the folded fused kernel and the row-group forward kernel have the self-carried form)
     const bool folded_fuse = fuse && !wants_reference_order() && !fuse->store && opt_fold && coeff_ready;
-    bool self_form = self_eligible(n, fuse != nullptr) && (fuse ? folded_fuse : use_rows);
+    // pipelined calls (forward_self): decided here because they take the self-carried form at any length and cut time differently
+    pipe_this = false;
+    uintptr_t out_lo = 0, out_hi = 0;
+    if (!fuse && !rows && out && use_rows)
+    {
+      out_lo = reinterpret_cast<uintptr_t>(out); out_hi = out_lo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
+      // (calls of a few thousand rows gain a microsecond from it and cost the host seven runtime calls instead of one,
+      // 19 against 3 us: n = 4096, m = 1024: 25.6 against 26.4 us per call; from n = 8192 on 30.4 against 32.9)
+      pipe_this = pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
+                  !ranges_overlap(out_lo, out_hi, prev_out);
+    }
+    bool self_form = self_eligible(n, fuse != nullptr, pipe_this) && (fuse ? folded_fuse : use_rows);
     if (self_form && fuse)
     {
       // the fused kernel folds into its transpose tiles: the 2N cells have to fit them, and it has one or two bins per lane
@@ -689,16 +700,8 @@ class Plan
       process_geometry(opt_fused != 0, pw, ps, n);
       self_form = ps <= 2 && self_cells() * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
     }
-    // pipelined calls (forward_self): decided here because their time chunks are cut differently
-    pipe_this = false;
-    if (self_form && !fuse && !rows && out)
-    {
-      const uintptr_t olo = reinterpret_cast<uintptr_t>(out), ohi = olo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
-      // (calls of a few thousand rows gain a microsecond from it and cost the host seven runtime calls instead of one,
-      // 19 against 3 us: n = 4096, m = 1024: 25.6 against 26.4 us per call; from n = 8192 on 30.4 against 32.9)
-      pipe_this = pipe_wanted(nullptr) && channels * n * nb >= ((size_t)6 << 20) && !ranges_overlap(olo, ohi, prev_out);
-      prev_out = PipeRange{olo, ohi};
-    }
+    if (!self_form) pipe_this = false;
+    if (out_hi) prev_out = PipeRange{out_lo, out_hi};
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
@@ -1016,10 +1019,12 @@ class Plan
     return (opt_self >= 1 && smooth_radices(span).count > 0 && 2 * span * sizeof(fdx) <= (size_t)80 * 1024) ? 2 * span : 0;
   }
   // what the self-carried form needs of the plan and the call (the kernel that has it is chosen by the caller)
-  bool self_eligible(size_t n, bool fused_call) const
+  // (any_length: pipelined calls take the form whatever the length -- one stream runs long calls faster with the pre-pass,
+  // n = 1e6: 77.3 against 75.5 % of peak, but two matrices in turn, pipelined: 82.4 %)
+  bool self_eligible(size_t n, bool fused_call, bool any_length = false) const
   {
     const size_t self_max = fused_call ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
-    return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && self_cells() != 0 && n <= self_max;
+    return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && self_cells() != 0 && (n <= self_max || any_length);
   }
 
   // ---- pipelined calls ------------------------------------------------------------------------------------------
@@ -1044,7 +1049,7 @@ class Plan
   // last call's rows, not a mixture)
   struct PipeRange { uintptr_t lo, hi; };
   PipeRange pipe_out[4] = {};
-  PipeRange prev_out = {0, 0};                               // the matrix of the previous analysis call of the self-carried form
+  PipeRange prev_out = {0, 0};                               // the matrix of the previous analysis call (dense, row-group kernel)
   bool pipe_this = false;                                    // forward_launch: this call is pipelined
   int pipe_stream_of[4] = {0, 0, 0, 0};                      // the row stream a launch went to
   static bool ranges_overlap(uintptr_t alo, uintptr_t ahi, const PipeRange& b) { return alo < b.hi && b.lo < ahi; }
