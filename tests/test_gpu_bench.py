@@ -61,6 +61,11 @@ def test_single_rank_bench_line_contract():
     assert cfg["single_sample"]["sdft_us_per_call_device_row"] > 0 and cfg["single_sample"]["cpu_sdft_us_per_sample"] > 0
     assert res["roofline"]["traffic"] is None or "replayed" in res["roofline"]["traffic_source"]
     assert res["ranks"] is None                                                    # the census belongs to N > 1 lines
+    # the headline workload as asynchronous calls into two matrices in turn (pipelined calls), and the north star's shape likewise
+    two = res["two_matrices_in_turn"]
+    assert "error" in two or (two["pipelined_calls"] >= 10 and 0 < two["frac_of_peak_wall"] < 1), two
+    ns = res["north_star_n48000"]["async_two_buffers"]
+    assert ns["pipelined_calls"] >= 50 and ns["row_streams"] in ("ordinary", "by priority"), ns
 
 
 def test_eight_rank_bench_plumbing():
