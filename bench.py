@@ -735,8 +735,22 @@ def main():
                                                   "pipelined_calls": int(pp.get_option("pipelined_calls")),
                                                   "chunks": [int(pp.get_option("last_chunks")), int(pp.get_option("last_chunk_len"))],
                                                   "note": "asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn (option pipeline, default)"}
+                # ... and the synthesis of the two matrices in turn (stateless: the calls go to the two row streams in turn)
+                y2 = [torch.empty(n, dtype=x.dtype, device="cuda") for _ in range(2)]
+                yptr = [C.c_void_p(y2[0].data_ptr()), C.c_void_p(y2[1].data_ptr())]
+                for i in range(2):
+                    pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
+                pp.synchronize(); torch.cuda.synchronize()
+                tq = time.perf_counter()
+                for i in range(10):
+                    pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
+                pp.synchronize(); torch.cuda.synchronize()
+                wq = (time.perf_counter() - tq) / 10
+                result["two_matrices_in_turn"].update({"synthesis_ms_per_call_wall": round(wq * 1e3, 4), "synthesis_msamples_s": round(n / wq / 1e6, 1),
+                                                       "synthesis_frac_of_peak_wall": round(n * (m * esz + np.dtype(td).itemsize) / wq / 1e9 / HBM_PEAK_GBS, 4),
+                                                       "pipelined_synthesis_calls": int(pp.get_option("pipelined_inverse_calls"))})
                 pp.close()
-                del out2
+                del out2, y2
             except Exception as e:                              # (a second 16 GB matrix: not on every box)
                 result["two_matrices_in_turn"] = {"error": str(e)[:200]}
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)

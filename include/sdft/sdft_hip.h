@@ -182,10 +182,12 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
                        other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
                        the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
-                       stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
+                       stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).
+                       Asynchronous synthesis calls that come back to back take the two streams in turn as well (n = 48 000:
+                       67 -> 80 %); a synthesis never runs beside an analysis.  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
                        profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
                        falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
-                       "pipelined_calls", "pipelined_ordered",
+                       "pipelined_calls", "pipelined_inverse_calls", "pipelined_ordered",
                        "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
    "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
                        plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable

@@ -1121,10 +1121,29 @@ class Plan
     }
     bool ok = hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&ev_inv[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { release_pipe(); opt_pipeline = 0; pipe_stream_kind = 0; return false; }
     return true;
   }
-  bool pipe_join()
+  // Synthesis calls are stateless: consecutive asynchronous ones (a host that synthesises matrix after matrix) go to the two
+  // row streams in turn as well -- n = 48 000: 148 -> 122 us per call, 66 -> 80 % of peak; n = 262 144: 82 -> 86 %
+  // (two plans in turn, scripts/pair_overlap_probe.py ...) -- but never beside an analysis: a synthesis waits for the
+  // rows of the analyses before it, an analysis for the syntheses before it (reads mixed into the write stream cost HBM
+  // more than the overlap gains: 1.62 against 1.47 ms per pair at n = 262 144).
+  hipEvent_t ev_inv[2] = {nullptr, nullptr};                 // the last synthesis launch on each row stream
+  bool inv_used[2] = {false, false};
+  int inv_last = 1;
+  PipeRange inv_prev_y = {0, 0};
+  unsigned long long inv_calls = 0;
+  long last_inverse_pipelined = 0;
+  bool pipe_join_inverses()
+  {
+    for (int i = 0; i < 2; ++i)
+      if (inv_used[i]) { SDFT_TRY(hipStreamWaitEvent(stream, ev_inv[i], 0)); inv_used[i] = false; }
+    return true;
+  }
+  bool pipe_join() { return pipe_join_rows() && pipe_join_inverses(); }
+  bool pipe_join_rows()
   {
     if (!pipe_open) return true;
     // the last launch on each row stream (among the four the ring remembers; older ones are ordered before them)
@@ -1142,6 +1161,7 @@ class Plan
     for (int i = 0; i < 2; ++i) if (row_streams[i]) { (void)hipStreamSynchronize(row_streams[i]); (void)hipStreamDestroy(row_streams[i]); row_streams[i] = nullptr; }
     if (ev_pre) { (void)hipEventDestroy(ev_pre); ev_pre = nullptr; }
     for (int i = 0; i < 4; ++i) if (ev_rows[i]) { (void)hipEventDestroy(ev_rows[i]); ev_rows[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { if (ev_inv[i]) { (void)hipEventDestroy(ev_inv[i]); ev_inv[i] = nullptr; } inv_used[i] = false; }
     pipe_open = false; pipe_seq = 0;
     (void)hipGetLastError();
   }
@@ -1206,6 +1226,7 @@ class Plan
       const uintptr_t olo = reinterpret_cast<uintptr_t>(out), ohi = olo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
       if (pipe_this && !fuse && ensure_pipe())
       {
+        if (!pipe_join_inverses()) return false;             // never beside a synthesis
         const uintptr_t xlo = reinterpret_cast<uintptr_t>(x), xhi = xlo + ((channels - 1) * x_stride + n) * sizeof(TD);
         // samples that an outstanding launch is still writing (a matrix reinterpreted as samples): no overlap for this call
         for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
@@ -1816,7 +1837,23 @@ class Plan
   {
     if (n == 0) return true;
     SDFT_TRY(hipSetDevice(device));
-    if (!pipe_join()) return false;
+    const bool ops_wanted = op && op->kind != OP_IDENTITY;
+    last_inverse_pipelined = 0;
+    const bool inv_pipe = !rows && !ops_wanted && pipe_wanted(nullptr) && channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
+    if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
+    hipStream_t main_stream = stream;
+    int si = 0;
+    uintptr_t ylo = 0, yhi = 0;
+    if (inv_pipe)
+    {
+      // the other stream than the previous synthesis -- the same one if the two write overlapping samples
+      ylo = reinterpret_cast<uintptr_t>(y); yhi = ylo + ((channels - 1) * y_stride + n) * sizeof(TD);
+      si = ranges_overlap(ylo, yhi, inv_prev_y) ? inv_last : (inv_last ^ 1);
+      SDFT_TRY(hipEventRecord(ev_pre, stream));               // behind everything the main stream has been given (the joins above too)
+      SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_pre, 0));
+      stream = row_streams[si];
+    }
+    struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};
     if (!prof_begin(ST_INVERSE)) return false;
     InverseArgs<TD, FD> ia;
     ia.in = in; ia.in_stride = in_stride; ia.in_rows = rows; ia.syn = d_syn.p; ia.y = y; ia.y_stride = y_stride;
@@ -1836,6 +1873,12 @@ class Plan
     SDFT_TRY(hipGetLastError());
     if (rtc_failed) { rtc_failed = false; return false; }    // (the compiler's words are in the error channel already)
     if (!prof_end(ST_INVERSE)) return false;
+    if (inv_pipe)
+    {
+      SDFT_TRY(hipEventRecord(ev_inv[si], stream));
+      inv_used[si] = true; inv_last = si; inv_prev_y = PipeRange{ylo, yhi};
+      ++inv_calls; last_inverse_pipelined = 1;
+    }
     return true;
   }
 

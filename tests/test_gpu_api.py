@@ -667,6 +667,27 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         want2 = ref2.sdft(np.ascontiguousarray(d0).view(np.float64).reshape(-1)[:n].copy())
         assert p.get_option("pipelined_calls") == 2
         assert rel(second.cpu().numpy(), want2) <= 1e-9
+    # syntheses back to back (stateless: two streams in turn), never beside an analysis; an analysis behind them waits
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("async", 1)
+        xd = [torch.from_numpy(x).cuda() for x in xs[:4]]
+        mats = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(4)]
+        ys = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(4)]
+        for i in range(4):
+            p.sdft(xd[i], mats[i])
+        for i in range(4):
+            p.isdft(mats[i], ys[i])
+        assert p.get_option("pipelined_inverse_calls") == 4 and p.get_option("last_inverse_pipelined") == 1
+        again = p.sdft(xd[0], mats[1])                          # overwrites a matrix a synthesis may still be reading: waits for it
+        p.isdft(mats[1], ys[0])                                 # ... and writes samples another synthesis wrote: ordered behind it
+        p.synchronize()
+        want_y = [ref.isdft(got[0][0][i]) for i in range(4)]
+        for i in (1, 2, 3):
+            assert np.array_equal(ys[i].cpu().numpy(), want_y[i]), i
+        ref5 = O.best(m, "hann", 1.0, "f32f64")
+        for i in range(4):
+            ref5.sdft(xs[i])
+        assert np.array_equal(ys[0].cpu().numpy(), ref5.isdft(ref5.sdft(xs[0])))
     # a host that reads its results with a plain hipMemcpy (the null stream waits for the plan's streams, rows included)
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         import ctypes as C
