@@ -63,7 +63,8 @@ def test_single_rank_bench_line_contract():
     assert res["ranks"] is None                                                    # the census belongs to N > 1 lines
     # the headline workload as asynchronous calls into two matrices in turn (pipelined calls), and the north star's shape likewise
     two = res["two_matrices_in_turn"]
-    assert "error" in two or (two["pipelined_calls"] >= 10 and 0 < two["frac_of_peak_wall"] < 1), two
+    assert "error" in two or (two["pipelined_calls"] >= 10 and 0 < two["frac_of_peak_wall"] < 1 and
+                              two["pipelined_synthesis_calls"] >= 10 and 0 < two["synthesis_frac_of_peak_wall"] < 1), two
     ns = res["north_star_n48000"]["async_two_buffers"]
     assert ns["pipelined_calls"] >= 50 and ns["row_streams"] in ("ordinary", "by priority"), ns
 
