@@ -1839,7 +1839,9 @@ class Plan
     SDFT_TRY(hipSetDevice(device));
     const bool ops_wanted = op && op->kind != OP_IDENTITY;
     last_inverse_pipelined = 0;
-    const bool inv_pipe = !rows && !ops_wanted && pipe_wanted(nullptr) && channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
+    // (whatever FD is: the synthesis has no state to carry from call to call)
+    const bool inv_pipe = !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
+                          channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
     if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
     hipStream_t main_stream = stream;
     int si = 0;

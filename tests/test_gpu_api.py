@@ -688,6 +688,18 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         for i in range(4):
             ref5.sdft(xs[i])
         assert np.array_equal(ys[0].cpu().numpy(), ref5.isdft(ref5.sdft(xs[0])))
+    # FD float plans: the analysis has exact carries and stays on one stream, the syntheses take two
+    with SDFT(m, "hann", 1.0, "f32f32") as p:
+        reff = O.best(m, "hann", 1.0, "f32f32")
+        p.set_option("async", 1)
+        xd = [torch.from_numpy(x).cuda() for x in xs[:3]]
+        mats = [p.sdft(x) for x in xd]
+        ysf = [p.isdft(mt) for mt in mats]
+        p.synchronize()
+        assert p.get_option("pipelined_calls") == 0 and p.get_option("pipelined_inverse_calls") == 3
+        for i in range(3):
+            wd = reff.sdft(xs[i])
+            assert np.array_equal(mats[i].cpu().numpy(), wd) and np.array_equal(ysf[i].cpu().numpy(), reff.isdft(wd)), i
     # a host that reads its results with a plain hipMemcpy (the null stream waits for the plan's streams, rows included)
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         import ctypes as C
