@@ -677,6 +677,8 @@ class Plan
     SDFT_TRY(hipSetDevice(device));
     flag_pending = false;                                    // only the hop kernel signals its completion
 
+    if (prev_was_inverse && inverse_run == 1) inv_batch_mode = false;        // analysis, synthesis, analysis, ...: see inv_batch_mode
+    prev_was_inverse = false; inverse_run = 0;
     const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
     // (the folded fused kernel and the row-group forward kernel have the self-carried form)
@@ -1130,6 +1132,11 @@ class Plan
   // (two plans in turn, scripts/pair_overlap_probe.py ...) -- but never beside an analysis: a synthesis waits for the
   // rows of the analyses before it, an analysis for the syntheses before it (reads mixed into the write stream cost HBM
   // more than the overlap gains: 1.62 against 1.47 ms per pair at n = 262 144).
+  // Only for hosts that do synthesise call after call: a host that alternates analysis and synthesis (the reference's loop)
+  // would pay an event wait between streams per call and gain nothing, so the mode is learnt from the calls themselves --
+  // on when a synthesis follows a synthesis, off when an analysis follows a lone synthesis.
+  bool prev_was_inverse = false, inv_batch_mode = false;
+  int inverse_run = 0;
   hipEvent_t ev_inv[2] = {nullptr, nullptr};                 // the last synthesis launch on each row stream
   bool inv_used[2] = {false, false};
   int inv_last = 1;
@@ -1840,7 +1847,8 @@ class Plan
     const bool ops_wanted = op && op->kind != OP_IDENTITY;
     last_inverse_pipelined = 0;
     // (whatever FD is: the synthesis has no state to carry from call to call)
-    const bool inv_pipe = !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
+    if (prev_was_inverse) inv_batch_mode = true;
+    const bool inv_pipe = inv_batch_mode && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
                           channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
     if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
     hipStream_t main_stream = stream;
@@ -1875,6 +1883,7 @@ class Plan
     SDFT_TRY(hipGetLastError());
     if (rtc_failed) { rtc_failed = false; return false; }    // (the compiler's words are in the error channel already)
     if (!prof_end(ST_INVERSE)) return false;
+    prev_was_inverse = true; ++inverse_run;
     if (inv_pipe)
     {
       SDFT_TRY(hipEventRecord(ev_inv[si], stream));
