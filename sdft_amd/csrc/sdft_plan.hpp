@@ -679,6 +679,8 @@ class Plan
 
     if (prev_was_inverse && inverse_run == 1) inv_batch_mode = false;        // analysis, synthesis, analysis, ...: see inv_batch_mode
     prev_was_inverse = false; inverse_run = 0;
+    if (prev_was_analysis && !fuse) ana_batch_mode = true;
+    prev_was_analysis = !fuse; if (!fuse) ++analysis_run;
     const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
     // (the folded fused kernel and the row-group forward kernel have the self-carried form)
@@ -691,7 +693,7 @@ class Plan
       out_lo = reinterpret_cast<uintptr_t>(out); out_hi = out_lo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
       // (calls of a few thousand rows gain a microsecond from it and cost the host seven runtime calls instead of one,
       // 19 against 3 us: n = 4096, m = 1024: 25.6 against 26.4 us per call; from n = 8192 on 30.4 against 32.9)
-      pipe_this = pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
+      pipe_this = ana_batch_mode && pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
                   !ranges_overlap(out_lo, out_hi, prev_out);
     }
     bool self_form = self_eligible(n, fuse != nullptr, pipe_this) && (fuse ? folded_fuse : use_rows);
@@ -1137,6 +1139,9 @@ class Plan
   // on when a synthesis follows a synthesis, off when an analysis follows a lone synthesis.
   bool prev_was_inverse = false, inv_batch_mode = false;
   int inverse_run = 0;
+  // (the same for analyses: a host that alternates analysis and synthesis on two matrices has no two analyses to overlap)
+  bool prev_was_analysis = false, ana_batch_mode = false;
+  int analysis_run = 0;
   hipEvent_t ev_inv[2] = {nullptr, nullptr};                 // the last synthesis launch on each row stream
   bool inv_used[2] = {false, false};
   int inv_last = 1;
@@ -1848,6 +1853,8 @@ class Plan
     last_inverse_pipelined = 0;
     // (whatever FD is: the synthesis has no state to carry from call to call)
     if (prev_was_inverse) inv_batch_mode = true;
+    if (prev_was_analysis && analysis_run == 1) ana_batch_mode = false;
+    prev_was_analysis = false; analysis_run = 0;
     const bool inv_pipe = inv_batch_mode && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
                           channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
     if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
