@@ -184,7 +184,8 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
                        the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
                        stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).
                        Asynchronous synthesis calls that come back to back take the two streams in turn as well (n = 48 000:
-                       67 -> 80 %); a synthesis never runs beside an analysis.  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
+                       67 -> 80 %); a synthesis never runs beside an analysis.  Either kind of call is pipelined only once two
+                       of them have come in a row (a host that alternates analysis and synthesis stays on one stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
                        profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
                        falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
                        "pipelined_calls", "pipelined_inverse_calls", "pipelined_ordered",
