@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X Sliding DFT engine (contract: see README/DESIGN).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts the N ranks itself, as a child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident
@@ -420,8 +420,36 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True):
     return res
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1), relay its output -- rank 0's one JSON line included -- and hand back its return code.
+    Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image), and this
+    process never replaces itself with another program."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    backend = os.environ.get("SDFT_BENCH_BACKEND", "nccl")
+    if have < args.gpus and backend == "nccl":
+        print(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s): refusing to print a line that is not a {args.gpus}-GPU "
+              f"measurement (SDFT_BENCH_BACKEND=gloo runs the ranks on the GPUs there are, for functional tests only)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr)
+    r = subprocess.run(cmd, env=env, cwd=ROOT)
+    return r.returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -430,6 +458,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if world != args.gpus:
+        # a record that says n_gpus = WORLD_SIZE while the command line asked for something else helps nobody
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # one rank per GPU; SDFT_BENCH_BACKEND=gloo lets several ranks share a GPU for functional tests
@@ -443,8 +474,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
 
     from sdft_amd import shard
     from sdft_amd.sdft import SDFT
@@ -827,13 +856,25 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    # an N-GPU line must BE an N-GPU measurement: every rank in the collectives, and under RCCL every rank on a GPU of its own
+    bad = None
+    if census is not None:
+        if census["ranks"] != n_gpus:
+            bad = f"{census['ranks']} ranks took part in the collectives, --gpus says {n_gpus}"
+        elif backend == "nccl" and census["distinct_local_devices"] != n_gpus:
+            bad = f"the {n_gpus} ranks sit on {census['distinct_local_devices']} distinct GPU(s)"
     if rank == 0:
+        if bad:
+            print(f"[bench] NOT a valid {n_gpus}-GPU line: {bad}", file=sys.stderr)
+            result["invalid"] = bad
         print(json.dumps(result), flush=True)
     if plan is not None:
         plan.close()
     if distributed:
         shard.barrier(local_rank)        # rank 0 may still have been busy with its side measurements
         dist.destroy_process_group()
+    if bad:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -288,8 +288,20 @@ int sdft_hip_hold_cus(unsigned cus, double milliseconds)
   static unsigned* sink = nullptr;
   if (!s)
   {
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sink, 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    // (the statics are assigned only once all three steps have succeeded: a half-initialised first call must not make
+    // later calls launch with a null sink or without the LDS attribute)
+    hipStream_t ns = nullptr;
+    unsigned* nsink = nullptr;
+    if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (hipMalloc((void**)&nsink, 4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      if (nsink) (void)hipFree(nsink);
+      (void)hipStreamDestroy(ns);
+      return -1;
+    }
+    s = ns; sink = nsink;
   }
   if (cus == 0) return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;       // wait for the release
   hipLaunchKernelGGL(hold_cu_kernel, dim3(cus), dim3(512), 159 * 1024, s, (unsigned long long)(milliseconds * 1e5), sink);

@@ -330,7 +330,7 @@ class Plan
   }
 
   // a host driving several GPUs from one process may have switched the current device
-  bool bind() { flag_pending = false; flag_wanted = false; SDFT_TRY(hipSetDevice(device)); return true; }
+  bool bind() { flag_pending = false; flag_wanted = false; pipe_allowed = false; SDFT_TRY(hipSetDevice(device)); return true; }
 
   // sdft.h:517-529
   bool reset()
@@ -1055,6 +1055,10 @@ class Plan
   PipeRange pipe_out[4] = {};
   PipeRange prev_out = {0, 0};                               // the matrix of the previous analysis call (dense, row-group kernel)
   bool pipe_this = false;                                    // forward_launch: this call is pipelined
+  // Only calls whose every pointer is the caller's DEVICE memory may leave the plan's stream: the host-pointer routes reuse
+  // the plan's staging buffers (d_stage_*, d_io, d_pin) on the main stream right behind a launch and promise the outputs
+  // complete on return.  Set by the device/device branches of sdft_n / isdft_n for the duration of the call.
+  bool pipe_allowed = false;
   int pipe_stream_of[4] = {0, 0, 0, 0};                      // the row stream a launch went to
   static bool ranges_overlap(uintptr_t alo, uintptr_t ahi, const PipeRange& b) { return alo < b.hi && b.lo < ahi; }
   bool ensure_pipe()
@@ -1145,7 +1149,7 @@ class Plan
   hipEvent_t ev_inv[2] = {nullptr, nullptr};                 // the last synthesis launch on each row stream
   bool inv_used[2] = {false, false};
   int inv_last = 1;
-  PipeRange inv_prev_y = {0, 0};
+  PipeRange inv_y[2] = {};                                   // the samples the last synthesis on each row stream writes
   unsigned long long inv_calls = 0;
   long last_inverse_pipelined = 0;
   bool pipe_join_inverses()
@@ -1179,7 +1183,7 @@ class Plan
   }
   bool pipe_wanted(const void* fuse) const
   {
-    return !fuse && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 && sizeof(FD) == 8;
+    return !fuse && pipe_allowed && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 && sizeof(FD) == 8;
   }
   bool launch_self_state(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned threads)
   {
@@ -1285,7 +1289,7 @@ class Plan
         ++pipe_seq; ++pipe_calls; pipe_open = true;
         last_pipelined = 1;
         st_cur = s1; hist_cur = h1;
-        fid_canonical = true;                                // the rotation comes from the table
+        fid_canonical = false;                               // the rotation comes from the closed-form table (as the one-stream self form below)
         cursor = (cursor + n) % span;
         return true;
       }
@@ -1855,7 +1859,7 @@ class Plan
     if (prev_was_inverse) inv_batch_mode = true;
     if (prev_was_analysis && analysis_run == 1) ana_batch_mode = false;
     prev_was_analysis = false; analysis_run = 0;
-    const bool inv_pipe = inv_batch_mode && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
+    const bool inv_pipe = inv_batch_mode && pipe_allowed && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
                           channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
     if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
     hipStream_t main_stream = stream;
@@ -1865,9 +1869,17 @@ class Plan
     {
       // the other stream than the previous synthesis -- the same one if the two write overlapping samples
       ylo = reinterpret_cast<uintptr_t>(y); yhi = ylo + ((channels - 1) * y_stride + n) * sizeof(TD);
-      si = ranges_overlap(ylo, yhi, inv_prev_y) ? inv_last : (inv_last ^ 1);
+      si = ranges_overlap(ylo, yhi, inv_y[inv_last]) ? inv_last : (inv_last ^ 1);
       SDFT_TRY(hipEventRecord(ev_pre, stream));               // behind everything the main stream has been given (the joins above too)
       SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_pre, 0));
+      // what the OTHER row stream still has outstanding: samples this call overwrites (a host that rotates three sample
+      // buffers) or a matrix that was reinterpreted from them -- ordered behind it
+      const int so = si ^ 1;
+      if (inv_used[so])
+      {
+        const uintptr_t ilo = reinterpret_cast<uintptr_t>(in), ihi = ilo + ((channels - 1) * in_stride + n * nbins) * sizeof(fdx);
+        if (ranges_overlap(ylo, yhi, inv_y[so]) || ranges_overlap(ilo, ihi, inv_y[so])) SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_inv[so], 0));
+      }
       stream = row_streams[si];
     }
     struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};
@@ -1894,7 +1906,7 @@ class Plan
     if (inv_pipe)
     {
       SDFT_TRY(hipEventRecord(ev_inv[si], stream));
-      inv_used[si] = true; inv_last = si; inv_prev_y = PipeRange{ylo, yhi};
+      inv_used[si] = true; inv_last = si; inv_y[si] = PipeRange{ylo, yhi};
       ++inv_calls; last_inverse_pipelined = 1;
     }
     return true;
@@ -1936,7 +1948,16 @@ class Plan
   // wall-clock time (about twice what the call can take at HBM speed, at most 5 ms; 50 ms for the word) and only then
   // block.  flag_fallbacks counts completion words that never became visible (get_option "flag_fallbacks").
   long flag_fallbacks = 0;
-  bool finish(size_t work = 0)
+  static constexpr double kPeakBytesPerUs = 8.0e6;          // HBM3E spec peak, 8 TB/s (MI355X_MICROARCH.md): no call ends sooner than bytes / this
+  static inline void cpu_relax()
+  {
+#if defined(__SSE2__)
+    _mm_pause();
+#endif
+  }
+  // hbm_bytes: what the call has to move through HBM at least (0: unknown -- sleep on the stream)
+  size_t matrix_bytes(size_t n) const { return channels * n * nbins * sizeof(fdx); }
+  bool finish(size_t hbm_bytes = 0)
   {
     if (async) return true;
     using clock = std::chrono::steady_clock;
@@ -1962,13 +1983,23 @@ class Plan
       ++flag_fallbacks;
       return synchronize();                                  // never seen: fall back to the stream
     }
-    // (calls that stream for longer than ~60 us are better off sleeping on the stream than hammering it with queries:
-    // n = 48000, N = 1024: 169 -> 165 us per call; n <= 4096: 32 against 35 us the other way -- profiles/r04_sync_completion.txt)
-    if (opt_spin && work && (double)work * (double)sizeof(fdx) / 5.0e6 <= 60.0)
+    // The wait is the same on every box and never sleeps on the stream while the call can still be running: a sleeping
+    // hipStreamSynchronize wakes up 9 us late on one box and 45 us late on another (round 4 slept for calls beyond 60 us and
+    // lost 10 % of the north star's synchronous rate on the box it was not tuned on; profiles/r05_sync_completion.txt).  A call
+    // cannot end before its bytes have moved at the chip's peak rate (kPeakBytesPerUs -- the spec figure, a LOWER bound of the
+    // time, not a tuned one): until then the host spins on its own clock without touching the runtime (queries that cannot
+    // succeed yet only compete with the completion signal's handler for the runtime's locks), then it polls the stream.
+    // Option "spin": 0 = sleep on the stream, 1 = this (default), 2 = poll from the start.
+    if (opt_spin && hbm_bytes)
     {
-      const double est_us = (double)work * (double)sizeof(fdx) / 5.0e6;      // at 5 TB/s
-      const auto budget = std::chrono::microseconds((long long)std::min(5000.0, 100.0 + 2.0 * est_us));
+      const double floor_us = (double)hbm_bytes / kPeakBytesPerUs;
+      const auto budget = std::chrono::microseconds((long long)std::min(20000.0, 200.0 + 4.0 * floor_us));
       const clock::time_point t0 = clock::now();
+      if (opt_spin == 1 && floor_us > 8.0)
+      {
+        const auto quiet = std::chrono::nanoseconds((long long)(floor_us * 1000.0));
+        while (clock::now() - t0 < quiet) cpu_relax();
+      }
       for (unsigned spins = 1;; ++spins)
       {
         const hipError_t e = hipStreamQuery(stream);
@@ -1984,10 +2015,10 @@ class Plan
   // calls whose kernels read and wrote the caller's host memory in place (map_host): always complete on return, and
   // through the stream's own synchronisation -- the point at which the runtime promises the host sees what the device
   // wrote over PCIe (a stream query that reports "done" first keeps the wait short; the synchronisation then returns at once)
-  bool finish_mapped(size_t work)
+  bool finish_mapped(size_t hbm_bytes)
   {
     const bool saved = async; async = false;
-    const bool ok = finish(work);
+    const bool ok = finish(hbm_bytes);
     async = saved;
     if (!ok) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
@@ -2145,6 +2176,7 @@ class Plan
   bool to_device(void* dst, const void* src, size_t bytes)
   {
     if (bytes == 0) return true;
+    if (!pipe_join()) return false;                          // (a no-op unless row streams hold outstanding launches)
     if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
     {
       SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
@@ -2166,6 +2198,7 @@ class Plan
   bool to_host(void* dst, const void* src, size_t bytes)
   {
     if (bytes == 0) return true;
+    if (!pipe_join()) return false;
     if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
     {
       SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
@@ -2204,7 +2237,7 @@ class Plan
       const void* s = (const char*)src + c * spitch;
       if (kind == hipMemcpyHostToDevice) { if (!to_device(d, s, width)) return false; }
       else if (kind == hipMemcpyDeviceToHost) { if (!to_host(d, s, width)) return false; }
-      else SDFT_TRY(hipMemcpyAsync(d, s, width, kind, stream));
+      else { if (!pipe_join()) return false; SDFT_TRY(hipMemcpyAsync(d, s, width, kind, stream)); }
     }
     return true;
   }
@@ -2236,9 +2269,10 @@ class Plan
     if (xd && od)
     {
       flag_wanted = true;                                    // a call of one time chunk may signal its own completion
+      pipe_allowed = true;
       const bool ok = forward_device(n, x, n, dfts, n * nbins, nullptr);
-      flag_wanted = false;
-      return ok && finish(channels * n * nbins);
+      flag_wanted = false; pipe_allowed = false;
+      return ok && finish(matrix_bytes(n));
     }
 
     // small host samples, device matrix (hop-wise streaming from a host signal, sdft_sdft on a device row): through the
@@ -2250,7 +2284,7 @@ class Plan
       flag_wanted = true;
       const bool ok = forward_device(n, d_io, n, dfts, n * nbins, nullptr);
       flag_wanted = false;
-      const bool done = ok && finish(channels * n * nbins);
+      const bool done = ok && finish(matrix_bytes(n));
       async = saved;
       return done;
     }
@@ -2270,7 +2304,7 @@ class Plan
       if (xm && om)
       {
         const bool ok = forward_device(n, xm, n, om, n * nbins, nullptr);
-        return ok && finish_mapped(channels * n * nbins);   // host memory: complete on return, through the stream
+        return ok && finish_mapped(matrix_bytes(n));   // host memory: complete on return, through the stream
       }
     }
     // a hop-sized matrix for host memory (the reference driver's 100 x 1000 bins = 1.6 MB, test/test.c:62-83): the kernels
@@ -2295,7 +2329,7 @@ class Plan
         ++pin_copies;
         const double t0 = now_us();
         if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(d_pin), n * nbins, nullptr)) return false;
-        if (!finish_mapped(channels * n * nbins)) return false;
+        if (!finish_mapped(matrix_bytes(n))) return false;
         const double t1 = now_us();
         host_copy_bytes(dfts, h_pin, obytes);
         pin_us_device += t1 - t0; pin_us_memcpy += now_us() - t1;
@@ -2401,9 +2435,10 @@ class Plan
     if (id && yd)
     {
       flag_wanted = true;
+      pipe_allowed = true;
       const bool ok = inverse_device(n, dfts, n * nbins, nullptr, y, n);
-      flag_wanted = false;
-      return ok && finish(channels * n * nbins);
+      flag_wanted = false; pipe_allowed = false;
+      return ok && finish(matrix_bytes(n));
     }
     // device matrix, small host output: the kernel writes the samples into the pinned scratch
     if (id && !yd && channels * n * sizeof(TD) <= kIoBytes && opt_pinned_io && ensure_io())
@@ -2412,7 +2447,7 @@ class Plan
       flag_wanted = true;
       const bool ok = inverse_device(n, dfts, n * nbins, nullptr, d_io, n);
       flag_wanted = false;
-      const bool done = ok && finish(channels * n * nbins);
+      const bool done = ok && finish(matrix_bytes(n));
       async = saved;
       if (done) memcpy(y, h_io, channels * n * sizeof(TD));
       return done;
@@ -2429,7 +2464,7 @@ class Plan
         {
           ok = to_host(y, ym, channels * n * sizeof(TD));
         }
-        return ok && finish_mapped(channels * n * nbins);
+        return ok && finish_mapped(matrix_bytes(n));
       }
     }
     // a hop-sized matrix in host memory: copied into the plan's pinned pieces, which the kernel reads over PCIe
@@ -2448,7 +2483,7 @@ class Plan
         if (!yd) { if (through_io) ym = d_io; else { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; } }
         if (!inverse_device(n, reinterpret_cast<const fdx*>(d_pin), n * nbins, nullptr, ym, n)) return false;
         if (!yd && !through_io && !to_host(y, ym, ybytes)) return false;
-        if (!finish_mapped(channels * n * nbins)) return false;
+        if (!finish_mapped(matrix_bytes(n))) return false;
         pin_us_device += now_us() - t1;
         if (through_io) memcpy(y, h_io, ybytes);
         return true;
@@ -2744,7 +2779,8 @@ class Plan
       if (!to_host(y, ys, channels * n * sizeof(TD))) return false;
       return synchronize();
     }
-    return finish(channels * n * nbins);
+    // (the fused call moves the samples only -- unless the host asked for a copy of the spectrum or the shape took the two passes)
+    return finish((dfts || last_process_path != 1) ? matrix_bytes(n) : std::max<size_t>(1, channels * n * 2 * sizeof(TD)));
   }
 
   // the host's own operation on stored rows (two-pass route): user_rows_kernel compiled at run time with its statements
@@ -2754,6 +2790,7 @@ class Plan
     snprintf(name, sizeof(name), "sdfthip::user_rows_kernel<%s>", type_name<FD>());
     hipFunction_t fn = nullptr;
     if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
+    if (!pipe_join()) return false;
     const size_t total = channels * rows * nbins;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
     fdx* a0 = mat; size_t a1 = stride, a2 = rows; unsigned a3 = (unsigned)nbins, a4 = (unsigned)channels; SpectralOp<FD> a5 = op;

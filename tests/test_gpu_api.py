@@ -787,6 +787,77 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         assert p.get_option("last_pipelined") == 0
 
 
+def test_host_pointer_calls_never_leave_the_plans_stream():
+    """Advisor, round 4: with option async = 1 a host-pointer call that followed pipelined device-pointer calls could launch on
+    a row stream while its staged copy ran on the main stream (stale samples, no error).  Now only calls whose every pointer is
+    the caller's device memory may be pipelined, and every staged copy joins first.  Syntheses of >= 6 Mi bins into numpy
+    outputs (through the pinned scratch, the small staging path and the segmented staging path) after the plan has learnt to
+    pipeline syntheses; an analysis of numpy samples longer than the stage segment into a device matrix after it has learnt
+    to pipeline analyses; all against pipeline = 0 and the oracle."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    m, n = 1024, 7000                                           # 7000 x 1024 = 6.8 Mi bins per matrix
+    xs = [noise(n, seed=90 + i) for i in range(4)]
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = [ref.sdft(x) for x in xs]
+    want_y = [ref.isdft(w) for w in want]
+    res = {}
+    for pipe in (1, 0):
+        with SDFT(m, "hann", 1.0, "f32f64") as p:
+            p.set_option("async", 1)
+            p.set_option("pipeline", pipe)
+            xd = [torch.from_numpy(x).cuda() for x in xs]
+            mats = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(4)]
+            ysd = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(4)]
+            for i in range(4):
+                p.sdft(xd[i], mats[i])
+            p.synchronize()
+            three = torch.cat(mats[:3])                         # 21000 rows: 84 KB of samples, beyond the small-buffer paths
+            torch.cuda.synchronize()
+            for i in range(3):
+                p.isdft(mats[i], ysd[i])                        # device / device: the plan learns to pipeline syntheses
+            assert p.get_option("pipelined_inverse_calls") == (2 if pipe else 0)
+            before = p.get_option("pipelined_inverse_calls")
+            small = [np.full(n, 7.0, dtype=np.float32) for _ in range(3)]
+            large = [np.full(3 * n, 7.0, dtype=np.float32) for _ in range(2)]
+            def isdft_mixed(mat, y):                            # device matrix, host samples: the raw C-ABI call
+                p.api.isdft_n(p._p, mat.shape[0], C.c_void_p(mat.data_ptr()), C.c_void_p(y.ctypes.data)); p.api.check()
+            isdft_mixed(mats[3], small[0])                      # the pinned scratch
+            isdft_mixed(three, large[0]); isdft_mixed(three, large[1])  # back to back through the staging buffer (segments + copies)
+            p.set_option("pinned_io", 0)
+            isdft_mixed(mats[2], small[1]); isdft_mixed(mats[1], small[2])      # the small staging path
+            assert p.get_option("pipelined_inverse_calls") == before    # none of them left the plan's stream
+            p.synchronize()
+            res[pipe] = [a.copy() for a in small + large]
+    for a, b in zip(res[1], res[0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[1][0], want_y[3]) and np.array_equal(res[1][1], want_y[2]) and np.array_equal(res[1][2], want_y[1])
+    assert np.array_equal(res[1][3], np.concatenate(want_y[:3])) and np.array_equal(res[1][4], res[1][3])
+    # analysis: numpy samples longer than the stage segment into a device matrix, after pipelined analyses
+    xl = np.concatenate([xs[3], xs[0], xs[1]])                  # 21000 samples = 7 segments of 3000 rows
+    res = {}
+    for pipe in (1, 0):
+        with SDFT(m, "hann", 1.0, "f32f64") as p:
+            p.set_option("async", 1)
+            p.set_option("pipeline", pipe)
+            p.set_option("stage_bytes", 3000 * m * 16)
+            xd = [torch.from_numpy(x).cuda() for x in xs]
+            mats = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(3)]
+            for i in range(3):
+                p.sdft(xd[i], mats[i])
+            assert p.get_option("pipelined_calls") == (2 if pipe else 0)
+            out = torch.empty((xl.size, m), dtype=torch.complex128, device="cuda")
+            p.api.sdft_n(p._p, xl.size, C.c_void_p(xl.ctypes.data), C.c_void_p(out.data_ptr())); p.api.check()      # host samples, device matrix
+            assert p.get_option("pipelined_calls") == (2 if pipe else 0)
+            p.synchronize()
+            res[pipe] = out.cpu().numpy()
+    assert rel(res[1], res[0]) <= 1e-12
+    r2 = O.best(m, "hann", 1.0, "f32f64")
+    for x in xs[:3]:
+        r2.sdft(x)
+    assert rel(res[1], r2.sdft(xl)) <= 1e-11
+
+
 def test_driver_entry_point_smoke():
     """__graft_entry__.smoke() is what the driver runs on a fresh box before the bench: it has to pass in the suite too
     (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""

@@ -46,6 +46,35 @@ def test_two_rank_bench_shards_channels():
     assert 0 < rk["roofline_frac_min_over_ranks"] <= rk["roofline_frac_max_over_ranks"] < 1
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how a driver may well call it) must come back as a 2-rank measurement or
+    fail -- never as a one-rank line that says n_gpus = 1 (round-4 review).  bench.py starts torch.distributed.run as a child."""
+    import torch
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    two_gpus = torch.cuda.device_count() >= 2
+    if not two_gpus:
+        # under RCCL it refuses (rc 2, no JSON line) ...
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-extras"],
+                           capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+        assert r.returncode == 2 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stdout[-500:])
+        env["SDFT_BENCH_BACKEND"] = "gloo"                      # ... the functional run shares the one GPU over gloo
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "4096", "--no-extras"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"]["ranks_in_collectives"] == 2 and res["config"]["channels_total"] == 128
+    assert res["ranks"]["distinct_local_devices"] == (2 if two_gpus else 1) and "invalid" not in res
+    # a launcher that started another number of ranks than --gpus says: refused
+    env2 = dict(env); env2["WORLD_SIZE"] = "1"; env2["RANK"] = "0"; env2["LOCAL_RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-extras"],
+                       capture_output=True, text=True, cwd=ROOT, env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
 def test_single_rank_bench_line_contract():
     res = run_bench(1, "--steps", "2", "--warmup", "1", "--samples", "65536", "--cpu-samples", "8192", "--no-cpu-all-cores")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -35,6 +35,31 @@ def bit_digest_numpy(d):
         return np.stack([bits.sum(-1), (bits * w).sum(-1)], axis=-1)
 
 
+def oracle_digests_all_channels(xb, m, window="hann", combo="f32f64"):
+    """The oracle's streaming digests and y for EVERY channel of a batch, one plan per channel, in a pool of host threads (the
+    C call releases the interpreter lock; the GPU box has 256 cores): 64 channels x 48000 rows in a few seconds."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(len(xb), os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(lambda c: O.Port(m, window, 1.0, combo).digest(xb[c]), range(len(xb))))
+
+
+def check_batch_against_oracle(d, y, xb, m, refs):
+    """Every row of every channel at the 1e-9 digest bar, every channel's synthesis within 1e-6 of the oracle's, and the
+    round trip of every channel at the single-channel tests' bar (SNR > 40 dB)."""
+    lag = m - 1
+    for c in range(len(xb)):
+        dig, yref = refs[c]
+        got = row_digest(d[c])
+        scale = np.abs(dig).max(axis=0)
+        assert (np.abs(got - dig).max(axis=0) <= 1e-9 * scale).all(), (c, np.abs(got - dig).max(axis=0) / scale)
+        assert np.abs(y[c] - yref).max() <= 1e-6 * np.abs(yref).max(), c
+        sig = xb[c, 2 * m:-lag].astype(np.float64)
+        err = y[c, 2 * m + lag:].astype(np.float64) - sig
+        assert 10 * np.log10(np.mean(sig ** 2) / np.mean(err ** 2)) > 40, c
+
+
 def test_config2_n1e6_m1024_hann_fp64_digests_and_roundtrip():
     """configs[1]: n=1e6, m=1024, Hann, FD double.  Every one of the 1e6 rows is checked against the
     oracle through four checksums; synthesis against the oracle's y; round trip = delayed input."""
@@ -77,9 +102,10 @@ def test_linearity_and_chunk_invariance_fullsize():
     assert float((ds - ds_c).abs().max()) <= 1e-11 * scale
 
 
-def test_config4_batch_64ch_m2048_sampled_channels():
-    """configs[3]: 64 channels x n=48000 x m=2048, Hann (FD double, 100.7 GB): channels 0, 31, 63
-    are compared row-by-row with the oracle's digests, all channels through synthesis."""
+def test_config4_batch_64ch_m2048_all_channels():
+    """configs[3]: 64 channels x n=48000 x m=2048, Hann (FD double, 100.7 GB): EVERY row of EVERY channel against the
+    oracle's digests (round 4 compared channels 0, 31, 63 and held the other 61 to a round-trip RMS only), every channel's
+    synthesis against the oracle's y, every channel's round trip > 40 dB."""
     import torch
     from sdft_amd.sdft import SDFT
     ch, n, m = 64, 48000, 2048
@@ -87,19 +113,11 @@ def test_config4_batch_64ch_m2048_sampled_channels():
     if free < ch * n * m * 16 * 1.05:
         pytest.skip("not enough free HBM for the 100.7 GB matrix")
     xb = sweep_batch(ch, n)
+    refs = oracle_digests_all_channels(xb, m)
     with SDFT(m, "hann", 1.0, "f32f64", channels=ch) as p:
         d = p.sdft(torch.from_numpy(xb).cuda())
         y = p.isdft(d).cpu().numpy()
-        for c in (0, 31, 63):
-            dig, yref = O.Port(m, "hann", 1.0, "f32f64").digest(xb[c])
-            got = row_digest(d[c])
-            scale = np.abs(dig).max(axis=0)
-            assert (np.abs(got - dig).max(axis=0) <= 1e-9 * scale).all(), c
-            assert np.abs(y[c] - yref).max() <= 1e-6 * np.abs(yref).max()
-    lag = m - 1
-    for c in range(ch):                                                # round trip on every channel
-        err = y[c, 2 * m + lag:].astype(np.float64) - xb[c, 2 * m:-lag]
-        assert np.sqrt(np.mean(err ** 2)) < 0.05, c
+        check_batch_against_oracle(d, y, xb, m, refs)
 
 
 def test_config3_float_roundtrip_n262144():
@@ -213,8 +231,8 @@ def test_exact_carries_under_contention():
 
 def test_config5_one_gpu_share_64ch_m1024():
     """configs[4], one GPU's share: 64 channels x n=48000 x m=1024, Hann, FD double (50.3 GB) through
-    one batched plan.  Channels 0, 31, 63 row by row against the oracle's digests, synthesis and the
-    round trip on every channel."""
+    one batched plan.  EVERY row of EVERY channel against the oracle's digests, synthesis and the
+    round trip (> 40 dB) on every channel."""
     import torch
     from sdft_amd.sdft import SDFT
     ch, n, m = 64, 48000, 1024
@@ -222,17 +240,9 @@ def test_config5_one_gpu_share_64ch_m1024():
     if free < ch * n * m * 16 * 1.05:
         pytest.skip("not enough free HBM for the 50.3 GB matrix")
     xb = sweep_batch(ch, n)
+    refs = oracle_digests_all_channels(xb, m)
     with SDFT(m, "hann", 1.0, "f32f64", channels=ch) as p:
         d = p.sdft(torch.from_numpy(xb).cuda())
         assert p.get_option("last_chunks") > 1
         y = p.isdft(d).cpu().numpy()
-        for c in (0, 31, 63):
-            dig, yref = O.Port(m, "hann", 1.0, "f32f64").digest(xb[c])
-            got = row_digest(d[c])
-            scale = np.abs(dig).max(axis=0)
-            assert (np.abs(got - dig).max(axis=0) <= 1e-9 * scale).all(), c
-            assert np.abs(y[c] - yref).max() <= 1e-6 * np.abs(yref).max()
-    lag = m - 1
-    for c in range(ch):
-        err = y[c, 2 * m + lag:].astype(np.float64) - xb[c, 2 * m:-lag]
-        assert np.sqrt(np.mean(err ** 2)) < 0.05, c
+        check_batch_against_oracle(d, y, xb, m, refs)
