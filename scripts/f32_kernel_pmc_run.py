@@ -6,7 +6,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdft_amd import capi
 from sdft_amd.sdft import SDFT
 from sdft_amd.signals import sine_sweep
@@ -16,6 +17,8 @@ m, n = 4096, 65536
 x = torch.from_numpy(sine_sweep(n, dtype=np.float32)).cuda()
 p = SDFT(m, "blackman", 1.0, "f32f32")
 p.set_option("float_carry_parallel", 1)
+import os
+p.set_option("rows_split", int(os.environ.get("SDFT_SPLIT", "1")))
 d = p.sdft(x)
 p.set_option("async", 1)
 held = int(sys.argv[1]) if len(sys.argv) > 1 else 192

@@ -42,7 +42,8 @@ def run(m, window, n, combo, held, **opts):
 
 if __name__ == "__main__":
     for label, m, window, n, combo, opts in (
-            ("f32 bin-pair kernel, m=4096 blackman", 4096, "blackman", 131072, "f32f32", {"float_carry_parallel": 1, "rows_f32": 1}),
+            ("f32 half-row workgroups, m=4096 blackman", 4096, "blackman", 131072, "f32f32", {"float_carry_parallel": 1, "rows_f32": 1, "rows_split": 1}),
+            ("f32 bin-pair kernel, m=4096 blackman", 4096, "blackman", 131072, "f32f32", {"float_carry_parallel": 1, "rows_f32": 1, "rows_split": 0}),
             ("f32 generic kernel,  m=4096 blackman", 4096, "blackman", 131072, "f32f32", {"float_carry_parallel": 1, "rows_f32": 0}),
             ("f32 bin-pair kernel, m=1024 hann", 1024, "hann", 262144, "f32f32", {"float_carry_parallel": 1, "rows_f32": 1}),
             ("f32 generic kernel,  m=1024 hann", 1024, "hann", 262144, "f32f32", {"float_carry_parallel": 1, "rows_f32": 0}),

@@ -113,11 +113,12 @@ template <typename FD> struct ForwardArgs
 // Flow mode: which (chunk, channel) a workgroup takes, and the wait for the chunk's carries.  The relay kernel stores
 // carries write-through (sc1), waits for them, then stores the flag (sc1); here: relaxed agent-scope polls of the flags,
 // one agent-scope acquire, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility, form R1).
-template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch)
+template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch, unsigned block)
 {
-  if (a.ready) { chunk = a.chunk0 + blockIdx.x / a.ready_channels; ch = blockIdx.x % a.ready_channels; }
-  else { chunk = a.chunk0 + blockIdx.x % a.launch_chunks; ch = blockIdx.x / a.launch_chunks; }
+  if (a.ready) { chunk = a.chunk0 + block / a.ready_channels; ch = block % a.ready_channels; }
+  else { chunk = a.chunk0 + block % a.launch_chunks; ch = block / a.launch_chunks; }
 }
+template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch) { flow_position(a, chunk, ch, blockIdx.x); }
 constexpr unsigned kFlowPollCap = 1u << 19;                // x (sleep + barrier): about half a second
 template <typename FD> SDFT_D bool flow_wait(const ForwardArgs<FD>& a, unsigned chunk, size_t ch)
 {

@@ -330,7 +330,8 @@ class Plan
   }
 
   // a host driving several GPUs from one process may have switched the current device
-  bool bind() { flag_pending = false; flag_wanted = false; pipe_allowed = false; SDFT_TRY(hipSetDevice(device)); return true; }
+  std::chrono::steady_clock::time_point call_start;         // when the entry point in progress began (finish() counts from here)
+  bool bind() { flag_pending = false; flag_wanted = false; pipe_allowed = false; call_start = std::chrono::steady_clock::now(); SDFT_TRY(hipSetDevice(device)); return true; }
 
   // sdft.h:517-529
   bool reset()
@@ -1529,27 +1530,39 @@ class Plan
   long opt_rows_f32 = 1;
   long last_rows_f32 = 0;
   // (samples per lockstep group: 4; 2 measured slower -- 25.5 against 27.9 GB/s per CU, profiles/r04_kernels_beside_held_cus.txt)
-  template <int S> void launch_forward_rows_f32_s(const ForwardArgs<float>& fa, unsigned blocks, unsigned threads)
+  template <int S, bool SPLIT> void launch_forward_rows_f32_s(const ForwardArgs<float>& fa, unsigned blocks, unsigned threads, size_t lds)
   {
     const dim3 g(blocks), b(threads);
     constexpr int G = 4;
     switch (window)
     {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HANN, S, G>), g, b, 0, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HAMMING, S, G>), g, b, 0, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BLACKMAN, S, G>), g, b, 0, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BOXCAR, S, G>), g, b, 0, stream, fa); break;
+      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HANN, S, G, SPLIT>), g, b, lds, stream, fa); break;
+      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HAMMING, S, G, SPLIT>), g, b, lds, stream, fa); break;
+      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BLACKMAN, S, G, SPLIT>), g, b, lds, stream, fa); break;
+      default:           hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BOXCAR, S, G, SPLIT>), g, b, lds, stream, fa); break;
     }
   }
+  // Rows of two slots (2048 < N <= 4096 at FD float) as two one-slot workgroups per row, each computing the one bin pair it
+  // needs of the other half itself (sdft_forward_rows_f32.hpp, SPLIT): 64 registers instead of 96-128, two workgroups to a CU
+  long opt_rows_split = 0, last_rows_split = 0;
   void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads, bool fused)
   {
-    last_rows_f32 = 0;
+    last_rows_f32 = 0; last_rows_split = 0;
     if constexpr (sizeof(FD) == 4)
     {
       if (opt_rows_f32 && nbins % (2 * kWave) == 0 && fa.vec_store && !fa.out_rows)
       {
         last_rows_f32 = 1;
-        if (row_slots() == 1) launch_forward_rows_f32_s<1>(fa, blocks, threads); else launch_forward_rows_f32_s<2>(fa, blocks, threads);
+        if (row_slots() == 1) launch_forward_rows_f32_s<1, false>(fa, blocks, threads, 0);
+        else if (opt_rows_split && nbins % (4 * kWave) == 0 && blocks < 0x40000000u && fa.chunk_len <= 3064u)   // (48 KiB of halo image at most)
+        {
+          // (each half: nbins / 2 bins = nbins / 256 waves of 128 bins; the halo image: one quad per sample of a chunk)
+          ForwardArgs<float> fh = fa;
+          if (fh.done.flag) fh.done.total *= 2;            // every half reports
+          last_rows_split = 1;
+          launch_forward_rows_f32_s<1, true>(fh, 2 * blocks, (unsigned)(nbins / (4 * kWave)) * kWave, ((size_t)fa.chunk_len + 8) * 16);
+        }
+        else launch_forward_rows_f32_s<2, false>(fa, blocks, threads, 0);
         return;
       }
     }
@@ -1997,8 +2010,10 @@ class Plan
       const clock::time_point t0 = clock::now();
       if (opt_spin == 1 && floor_us > 8.0)
       {
+        // (counted from the entry point's start: a call that has waited for its kernels already -- the exact-carry route
+        // checks its poll loops' status word behind a synchronisation -- is not made to wait again)
         const auto quiet = std::chrono::nanoseconds((long long)(floor_us * 1000.0));
-        while (clock::now() - t0 < quiet) cpu_relax();
+        while (clock::now() - call_start < quiet) cpu_relax();
       }
       for (unsigned spins = 1;; ++spins)
       {

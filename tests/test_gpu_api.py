@@ -831,8 +831,9 @@ def test_host_pointer_calls_never_leave_the_plans_stream():
             res[pipe] = [a.copy() for a in small + large]
     for a, b in zip(res[1], res[0]):
         assert np.array_equal(a, b)
-    assert np.array_equal(res[1][0], want_y[3]) and np.array_equal(res[1][1], want_y[2]) and np.array_equal(res[1][2], want_y[1])
-    assert np.array_equal(res[1][3], np.concatenate(want_y[:3])) and np.array_equal(res[1][4], res[1][3])
+    # (the matrices are the chunk-parallel analysis': 3e-13 off the oracle's, so the samples are compared at the parity bar)
+    assert rel(res[1][0], want_y[3]) <= 1e-6 and rel(res[1][1], want_y[2]) <= 1e-6 and rel(res[1][2], want_y[1]) <= 1e-6
+    assert rel(res[1][3], np.concatenate(want_y[:3])) <= 1e-6 and np.array_equal(res[1][4], res[1][3])
     # analysis: numpy samples longer than the stage segment into a device matrix, after pipelined analyses
     xl = np.concatenate([xs[3], xs[0], xs[1]])                  # 21000 samples = 7 segments of 3000 rows
     res = {}
