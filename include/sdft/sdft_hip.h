@@ -121,6 +121,9 @@ int sdft_hip_process_n(sdft_t* sdft, const sdft_size_t nsamples, const sdft_td_t
 int   sdft_hip_set_stream(sdft_t* sdft, void* hip_stream /* hipStream_t */) SDFT_HIP_SYMBOL(set_stream);
 void* sdft_hip_get_stream(sdft_t* sdft) SDFT_HIP_SYMBOL(get_stream);
 int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
+/* measurement aid: the reference driver's loop (test/test.c:69-83: sdft_sdft_n + sdft_isdft_n per hop of `hop` samples on one
+   matrix) run `hops` times from C, as a C host runs it; seconds, or -1 */
+double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t* samples, sdft_fdx_t* dfts, sdft_td_t* out) SDFT_HIP_SYMBOL(time_hops);
 
 /* ---- options -----------------------------------------------------------------------------------
    "async"         0|1   see above
@@ -144,9 +147,16 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
    "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
    "target_waves"  waves the time chunking aims for
    "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis)
-   "spin"          1 (default) = synchronous short calls do not sleep on the stream: calls of one time chunk
-                       poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
-                       before the stream reports the kernel finished), other short calls poll the stream
+   "hop_parts"     0 (default) = a hop-sized call's samples are cut into up to 8 time parts, every (tile of bins, part) a
+                       workgroup on a CU of its own; a part's recurrence wave first runs the stream state through the samples
+                       before it with the reference's own operations, so every bit stays the reference's; 1 = never, n = n parts
+   "spin"          1 (default) = synchronous calls never sleep on the stream while they can still be running: calls of one
+                       time chunk poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
+                       before the stream reports the kernel finished); other calls spin on the host clock until the call's
+                       bytes could have moved at the chip's peak rate, then poll the stream (a sleeping wait wakes up 9 us
+                       late on one box and 45 us late on another); 0 = sleep on the stream, 2 = poll from the start
+   "rows_split"    0 (default) | 1 = FD float rows of 2049 ... 4096 bins (a multiple of 256) as two one-slot workgroups per
+                       row, each computing the one bin pair it needs of the other half itself; same bits, measured 8-14 % slower
    "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn,
                        one dependent addition per step on the chain) while bins x channels leave SIMDs idle, 0 = always the
                        serial pass, 2 = relay form whenever the geometry allows ("chain_block" 8|16|32|64|128 steps,

@@ -14,9 +14,11 @@ m, hop, total = 1000, 100, 20000
 xh = sine_sweep(total)
 yh = np.zeros(total, dtype=np.float32)
 dh = np.zeros((hop, m), dtype=np.complex128)
-for label, reg, rt, direct in (("pinned pieces, kernels on them (default)", 0, 0, 1), ("pinned pieces, DMA", 0, 0, 0), ("runtime's pageable path", 0, 1, 0),
-                               ("registered in place", 1, 0, 0), ("pinned pieces, kernels on them (again)", 0, 0, 1), ("pinned pieces, DMA (again)", 0, 0, 0)):
+for label, reg, rt, direct, threads in (("pinned slots, kernels on them (default: 2 copy threads)", 0, 0, 1, 2), ("... one thread (round 4)", 0, 0, 1, 0), ("... 3 copy threads", 0, 0, 1, 3),
+                                        ("pinned slots, DMA", 0, 0, 0, 2), ("runtime's pageable path", 0, 1, 0, 0),
+                                        ("registered in place", 1, 0, 0, 0), ("pinned slots, kernels on them (again)", 0, 0, 1, 2), ("... one thread (again)", 0, 0, 1, 0)):
     p = SDFT(m, "hann", 1.0, "f32f64")
+    p.set_option("copy_threads", threads)
     p.set_option("host_register", reg)
     p.set_option("host_copy", rt)
     p.set_option("host_direct", direct)
@@ -31,8 +33,8 @@ for label, reg, rt, direct in (("pinned pieces, kernels on them (default)", 0, 0
             t2 = time.perf_counter()
             ta += t1 - t0; ts += t2 - t1
     k = total // hop
-    print(f"{label:42s} sdft_n {ta / k * 1e6:7.1f} us   isdft_n {ts / k * 1e6:7.1f} us   per hop {(ta + ts) / k * 1e6:7.1f} us")
+    print(f"{label:58s} sdft_n {ta / k * 1e6:7.1f} us   isdft_n {ts / k * 1e6:7.1f} us   per hop {(ta + ts) / k * 1e6:7.1f} us")
     if p.get_option("host_copies_staged"):
         c = p.get_option("host_copies_staged")
-        print(f"{'':42s} per staged copy: host memcpy {p.get_option('host_copy_memcpy_us') / c:6.1f} us, device {p.get_option('host_copy_device_us') / c:6.1f} us")
+        print(f"{'':58s} per staged copy: host memcpy {p.get_option('host_copy_memcpy_us') / c:6.1f} us, device {p.get_option('host_copy_device_us') / c:6.1f} us")
     p.close()

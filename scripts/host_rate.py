@@ -8,13 +8,14 @@ from sdft_amd.sdft import SDFT
 from sdft_amd.signals import sine_sweep
 m, n = 1024, 100000
 x = sine_sweep(n)
-for mode in (0, 1, 0, 1):
+for mode, threads in ((0, 2), (0, 0), (1, 0), (0, 3), (0, 1), (0, 2), (1, 0)):
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         p.set_option("host_copy", mode)
+        p.set_option("copy_threads", threads)
         out = np.empty((n, m), dtype=np.complex128); out[:] = 0
         import ctypes as C
         for rep in range(3):
             t0 = time.perf_counter()
             p.api.sdft_n(p._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data))
             w = time.perf_counter() - t0
-        print(f"host_copy={mode}: sdft_n host->host n={n}: {w*1e3:.1f} ms = {n/w/1e6:.2f} Msamples/s = {n*m*16/w/1e9:.1f} GB/s")
+        print(f"host_copy={mode} copy_threads={threads}: sdft_n host->host n={n}: {w*1e3:.1f} ms = {n/w/1e6:.2f} Msamples/s = {n*m*16/w/1e9:.1f} GB/s")

@@ -25,7 +25,7 @@ COMBOS = ("f32f64", "f32f32", "f64f64", "f64f32")
 SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
 KERNEL_FILES = ["sdft_base.hpp", "sdft_carry_fast.hpp", "sdft_carry_exact.hpp", "sdft_forward.hpp", "sdft_forward_hop.hpp", "sdft_ops.hpp",
                 "sdft_forward_rows.hpp", "sdft_fused.hpp", "sdft_inverse.hpp"]      # in include order (sdft_kernels.hpp)
-HEADERS = ["sdft_kernels.hpp", *KERNEL_FILES, "sdft_forward_rows_f32.hpp", "sdft_plan.hpp", "sdft_capi.inc"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc")))            # everything a translation unit may include
 # -fno-slp-vectorize: on this VALU a packed f32 instruction costs what two plain ones cost and its operands have to be
 # assembled by moves (profiles/r04_valu_issue_rates.txt); the vectoriser packs scalar float code all the same -- the generic
 # FD float row kernel runs 28.3 -> 33.9 GB/s per CU without it (profiles/r04_kernels_beside_held_cus.txt).  Kernels that

@@ -45,6 +45,7 @@ def typed_signatures(combo: str):
         "set_stream": (C.c_int, [vp, vp]),
         "get_stream": (vp, [vp]),
         "synchronize": (C.c_int, [vp]),
+        "time_hops": (C.c_double, [vp, sz, sz, vp, vp, vp]),
         "set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
         "get_option": (C.c_long, [vp, C.c_char_p]),
         "get_profile": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

@@ -44,6 +44,7 @@ template <typename TD, typename FD> struct HopArgs
   FD wscale;
   DoneSignal done;            // WPB == 1 launches only: total = workgroups
   unsigned long long* stamps; // development builds (-DSDFT_HOP_STAMPS): realtime stamps of workgroup 0, else nullptr
+  unsigned parts, part_len;   // forward_hop2_kernel: the call's samples in `parts` time parts of part_len samples (1, n: no split)
 };
 
 template <typename TD, typename FD, int BPL, int WIN, bool ROWS, int WPB>
@@ -246,6 +247,13 @@ __global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD
 // stores the rows.  Double-buffered image, one s_barrier per group; same operations on the same operands as
 // forward_hop_kernel, bit for bit.  Differences: staged in LDS by one round of vector loads, as in
 // process_hop_kernel (calls of one time chunk are shorter than kHopMax samples; longer ones keep the one-wave form).
+// Time parts (round 5).  The 100 samples of a hop were one dependent sequence per tile: 100 x 22 instructions of the slower
+// wave at the 5-7 cycles a lone wave pays per fp64 instruction.  The call's samples are now cut into up to 8 parts, every
+// (tile, part) a workgroup on a CU of its own; the recurrence wave of part p first runs the stream state through the
+// samples before its part -- the same acc / fid operations in the same order as the reference (advance_normal / advance_wrap:
+// 10 instructions per sample, no demodulation, no window, no store) -- and so starts its part with exactly the state the
+// serial pass would have there.  Nothing is approximated and nothing is exchanged: every row is still the reference's, bit
+// for bit, and the last part's workgroups write the state.  Critical path per tile: n x 22 -> about n x (10 + 12 / parts).
 // ------------------------------------------------------------------------------------------
 template <typename TD, typename FD, int BPL, int WIN, bool ROWS>
 __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD> a)
@@ -265,7 +273,10 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 recurrence, 1 window + stores
   const unsigned tile = blockIdx.x % a.tiles;
-  const size_t ch = blockIdx.x / a.tiles;
+  const unsigned part = (blockIdx.x / a.tiles) % a.parts;
+  const size_t ch = blockIdx.x / (a.tiles * a.parts);
+  const size_t p0 = (size_t)part * a.part_len;                                   // this workgroup's samples: [p0, p1)
+  const size_t p1 = (p0 + a.part_len < a.n) ? p0 + a.part_len : a.n;
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
@@ -278,13 +289,13 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     const TD* xv = a.x + ch * a.x_stride;
     const TD* hv = a.hist_in + ch * span;
     TD* ho = a.hist_out + ch * span;
-    for (size_t i = (size_t)tile * (2 * kWave) + threadIdx.x; i < span; i += (size_t)a.tiles * (2 * kWave))
+    for (size_t i = ((size_t)part * a.tiles + tile) * (2 * kWave) + threadIdx.x; i < span; i += (size_t)a.tiles * a.parts * (2 * kWave))
     {
       const size_t j = a.n + i;
       ho[i] = (j >= span) ? xv[j - span] : hv[j];
     }
-    // differences of the whole call (sdft.h:564), the subtraction in TD precision
-    for (size_t tt = threadIdx.x; tt < a.n; tt += 2 * kWave)
+    // differences of the call's samples up to the end of this part (sdft.h:564), the subtraction in TD precision
+    for (size_t tt = threadIdx.x; tt < p1; tt += 2 * kWave)
     {
       const TD cur = xv[tt];
       const TD old = (tt < span) ? hv[tt] : xv[tt - span];
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     }
   }
 
-  const size_t groups = (a.n + G - 1) / G;
+  const size_t groups = (p1 - p0 + G - 1) / G;
   if (role == 0)
   {
     // ---------------- recurrence ----------------
@@ -314,11 +325,41 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     __syncthreads();                                         // the differences are staged
     SDFT_HOP2_STAMP(1);
     unsigned c = a.cursor0;
+    // the state at the start of this part: the reference's own acc / fid operations over the samples before it
+    for (size_t tt = 0; tt < p0; tt += G)
+    {
+      TD dd[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) dd[u] = diff_lds[tt + u];  // (a group's reads in one round trip; cells past p0 are staged too: p0 < p1)
+      if (tt + G <= p0 && c + G <= maxc)
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+        {
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) advance_normal(s[b], (FD)dd[u]);
+        }
+        c += G;
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          if (tt + u < p0)
+          {
+            const bool wrap = (c == maxc);                   // wave-uniform
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) { if (wrap) advance_wrap(s[b], (FD)dd[u]); else advance_normal(s[b], (FD)dd[u]); }
+            c = wrap ? 0 : c + 1;
+          }
+      }
+    }
+    SDFT_HOP2_STAMP(3);
     int buf = 0;
     for (size_t g = 0; g < groups; ++g)
     {
-      const size_t t = g * G;
-      const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
+      const size_t t = p0 + g * G;
+      const int m = (p1 - t < (size_t)G) ? (int)(p1 - t) : G;
       TD dd[G];
 #pragma unroll
       for (int u = 0; u < G; ++u) dd[u] = diff_lds[t + u];   // broadcast reads (cells past n were never written: unused)
@@ -364,15 +405,18 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
       buf ^= 1;
     }
     SDFT_HOP2_STAMP(2);
+    if (part + 1 == a.parts)                                 // the state after the call's last sample
+    {
 #pragma unroll
-    for (int b = 0; b < BPL; ++b)
-      if (keep[b])
-      {
-        a.acc_out[sbase + kfirst + b] = s[b].acc;
-        a.fid_out[sbase + kfirst + b] = s[b].fid;
-      }
+      for (int b = 0; b < BPL; ++b)
+        if (keep[b])
+        {
+          a.acc_out[sbase + kfirst + b] = s[b].acc;
+          a.fid_out[sbase + kfirst + b] = s[b].fid;
+        }
+    }
 #ifdef SDFT_HOP_STAMPS
-    if (a.stamps && blockIdx.x == 0 && lane == 0) for (int i = 0; i < 3; ++i) a.stamps[i] = stamp[i];
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && lane == 0) for (int i = 0; i < 4; ++i) a.stamps[i] = stamp[i];       // (the last part: the longest way)
 #endif
   }
   else
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
 #pragma unroll
     for (int b = 0; b < BPL; ++b) { const long k = kfirst + b; keep[b] = owner && k >= 0 && k < nbins; }
     const FD w = a.wscale;
-    cx<FD>* row = a.out + ch * a.out_stride;
+    cx<FD>* row = a.out + ch * a.out_stride + p0 * (size_t)a.nbins;
     const unsigned off_bytes = (keep[0] || (BPL == 2 && keep[BPL - 1])) ? (unsigned)(kfirst < 0 ? 0 : kfirst) * (unsigned)sizeof(cx<FD>) : 0u;
     cx<FD>* const* rows = ROWS ? a.out_rows + ch * a.n : nullptr;
     // neighbour lanes, clamped: lanes that would read outside the wave own no bins (their rows are not stored)
@@ -393,8 +437,8 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     int buf = 0;
     for (size_t g = 0; g < groups; ++g)
     {
-      const size_t t = g * G;
-      const int m = (a.n - t < (size_t)G) ? (int)(a.n - t) : G;
+      const size_t t = p0 + g * G;
+      const int m = (p1 - t < (size_t)G) ? (int)(p1 - t) : G;
       __syncthreads();                                       // group g is in the image
       // every read of the group is requested before the first sample is windowed (a lone wave has nothing else to
       // put into an LDS round trip; rows past the call's end hold stale bins and are not stored)
@@ -472,7 +516,7 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     }
 #ifdef SDFT_HOP_STAMPS
     SDFT_HOP2_STAMP(2);
-    if (a.stamps && blockIdx.x == 0 && lane == 0) for (int i = 0; i < 3; ++i) a.stamps[4 + i] = stamp[i];
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && lane == 0) for (int i = 0; i < 3; ++i) a.stamps[4 + i] = stamp[i];
 #endif
   }
   // completion word: both waves' stores are out before one lane reports

@@ -6,6 +6,8 @@
 
 #include "sdft_kernels.hpp"
 #include "sdft_forward_rows_f32.hpp"      // not part of the run-time-compiled text: plain analysis only
+#include "sdft_plan_logic.hpp"            // every decision that needs no HIP call (unit-tested on the CPU under sanitizers)
+#include "sdft_host_io.hpp"               // the caller's host memory: classification, registration, copies through pinned slots
 
 #include <math.h>
 #include <stdio.h>
@@ -32,11 +34,6 @@ bool lane_selftest();                                   // sdft_common.hip
 bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn);
 bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std::string& lowered_name, std::vector<char>& code);
 
-#define SDFT_TRY(expr)                                                        \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) { set_error(#expr, hipGetErrorString(e_)); return false; } \
-  } while (0)
 
 // ---- plan tables: the reference's own expressions (sdft.h:422-423, :439-446) evaluated on the
 // host with the host libm, so the device tables are bit-identical to the oracle's ------------
@@ -90,66 +87,15 @@ struct Tables
   }
 };
 
+// the constants sdft_plan_logic.hpp is written against are the kernels'
+static_assert(logic::kLanes == kWave && logic::kRowWaves == kRowWavesMax && logic::kRowSlots == kRowSlotsMax && logic::kTimeGroup == kGroup &&
+              logic::kSumBlockLen == kSumBlock && logic::kHopSamples == kHopMax && kGroup % kRowGroup == 0, "sdft_plan_logic.hpp and the kernels disagree");
+static_assert(logic::kWindowHann == WIN_HANN && logic::kWindowBlackman == WIN_BLACKMAN && logic::kWindowBoxcar == WIN_BOXCAR, "window numbering");
+static_assert(sizeof(logic::Radices) == sizeof(RadixList), "radix lists");
+
 enum CarryMode : int { CARRY_FAST = 0, CARRY_EXACT = 1 };
 
 enum ProfileStage : int { ST_DELTA = 0, ST_CARRY = 1, ST_FORWARD = 2, ST_INVERSE = 3, ST_COUNT = 4 };
-
-// The host's copies between the caller's memory and the plan's pinned pieces: streaming (non-temporal) stores for anything
-// beyond 256 KiB -- the destination is not read again by this core, and without the read-for-ownership of every line the
-// copy out of memory the device has just written runs at 42 instead of 30 GB/s (scripts/host_memcpy_probe.hip,
-// profiles/r04_host_copy_paths.txt; two threads spawned per piece: slower than one)
-static inline void host_copy_bytes(void* dst_, const void* src_, size_t bytes)
-{
-#if defined(__SSE2__)
-  if (bytes >= ((size_t)256 << 10))
-  {
-    char* dst = static_cast<char*>(dst_);
-    const char* src = static_cast<const char*>(src_);
-    size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
-    memcpy(dst, src, head); dst += head; src += head; bytes -= head;
-    const size_t blocks = bytes / 64;
-    for (size_t i = 0; i < blocks; ++i)
-    {
-      const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 0), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 1);
-      const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 2), d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 3);
-      _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 0, a); _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 1, b);
-      _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 2, c); _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 3, d);
-      src += 64; dst += 64;
-    }
-    _mm_sfence();
-    memcpy(dst, src, bytes - blocks * 64);
-    return;
-  }
-#endif
-  memcpy(dst_, src_, bytes);
-}
-
-static inline bool is_device_pointer(const void* p)
-{
-  if (!p) return false;
-  hipPointerAttribute_t at;
-  memset(&at, 0, sizeof(at));
-  const hipError_t e = hipPointerGetAttributes(&at, p);
-  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
-}
-
-template <typename T> struct DevBuf
-{
-  T* p = nullptr;
-  size_t cap = 0;
-  bool reserve(size_t count)
-  {
-    if (count <= cap) return true;
-    // allocate first, free afterwards: a failed growth leaves the old buffer usable
-    T* q = nullptr;
-    SDFT_TRY(hipMalloc((void**)&q, count * sizeof(T)));
-    if (p) (void)hipFree(p);
-    p = q; cap = count;
-    return true;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
 
 template <typename TD, typename FD>
 class Plan
@@ -245,6 +191,7 @@ class Plan
   long opt_chain_L = 0, opt_chain_debug = 0;
   long opt_hop_pipe = 1;         // calls of one time chunk, small launches: two waves per tile (forward_hop2_kernel)
   long last_hop_pipe = 0;
+  long opt_hop_parts = 0, last_hop_parts = 1;   // ... in time parts (0 = by the launch's size, 1 = never, n = that many)
   long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_relay_waves = 0;      // waves per workgroup of the relay form (0 = default)
@@ -309,9 +256,9 @@ class Plan
     d_alpha.release(); d_beta.release(); d_partial.release(); d_tickets.release();
     if (h_done_flag) { (void)hipHostFree(h_done_flag); h_done_flag = nullptr; }
     if (h_io) { (void)hipHostFree(h_io); h_io = nullptr; d_io = nullptr; }
-    release_pin();
+    io.release_pin();
     if (h_status) { (void)hipHostFree(h_status); h_status = nullptr; }
-    forget_host_buffers();
+    io.forget_host_buffers();
     if (d_started) { (void)hipFree(d_started); d_started = nullptr; }
     d_ready.release();
     d_done_count.release(); d_walked.release();
@@ -412,110 +359,22 @@ class Plan
     return true;
   }
 
-  // ---- geometry -----------------------------------------------------------------------
-  static int bins_per_lane() { return sizeof(fdx) == 16 ? 1 : 2; }
-  int halo_bins() const { return window == WIN_BLACKMAN ? 2 : (window == WIN_BOXCAR ? 0 : 1); }
-  int halo_lanes() const { return (halo_bins() + bins_per_lane() - 1) / bins_per_lane(); }
-  long interior_lanes() const
-  {
-    // Each lane stores 16 B; a tile of 8*j lanes starts and ends on 128-byte lines, so no line is
-    // shared between two waves.  Measured on MI355X (n=1e6, N=1024, f64): 62 lanes 4.2 TB/s,
-    // 60 lanes 5.4 TB/s, 56 lanes 5.6 TB/s.
-    const long mx = kWave - 2 * halo_lanes();
-    long v = opt_interior > 0 ? std::min(opt_interior, mx) : (mx / 8) * 8;
-    return std::max(v, 1L);
-  }
-  long tiles() const
-  {
-    const long per = interior_lanes() * bins_per_lane();
-    return (long)((nbins + per - 1) / per);
-  }
-  bool rows_kernel_ok(bool row_pointers) const
-  {
-    return opt_rows_kernel && !row_pointers && nbins >= 8 &&
-           nbins <= (size_t)(kWave * kRowWavesMax * bins_per_lane()) * (size_t)std::min<long>(kRowSlotsMax, std::max<long>(1, opt_row_slots_max));
-  }
-  // slots per lane (1, 2 or 4) and physical waves of the row group
-  long row_slots() const
-  {
-    const size_t per = (size_t)(kWave * kRowWavesMax * bins_per_lane());
-    const long need = (long)((nbins + per - 1) / per);
-    return need <= 1 ? 1 : 2;
-  }
-  long row_waves() const
-  {
-    const size_t per = (size_t)(kWave * bins_per_lane()) * (size_t)row_slots();
-    return (long)((nbins + per - 1) / per);
-  }
-
-  // time chunking: enough waves to fill 256 CUs, chunks not shorter than min_len samples
+  // ---- geometry and time chunking: sdft_plan_logic.hpp ---------------------------------------------------------------
+  static int bins_per_lane() { return logic::bins_per_lane(sizeof(fdx)); }
+  int halo_bins() const { return logic::halo_bins(window); }
+  int halo_lanes() const { return logic::halo_lanes(window, sizeof(fdx)); }
+  long interior_lanes() const { return logic::interior_lanes(window, sizeof(fdx), opt_interior); }
+  long tiles() const { return logic::tiles(nbins, window, sizeof(fdx), opt_interior); }
+  bool rows_kernel_ok(bool row_pointers) const { return logic::rows_kernel_ok(nbins, sizeof(fdx), row_pointers, opt_rows_kernel != 0, opt_row_slots_max); }
+  long row_slots() const { return logic::row_slots(nbins, sizeof(fdx)); }       // slots per lane (1 or 2) ...
+  long row_waves() const { return logic::row_waves(nbins, sizeof(fdx)); }       // ... and physical waves of the row group
   void choose_chunks(size_t n, long& chunks, long& len, bool rows_kernel = false) const
   {
-    if (rows_kernel && opt_chunk <= 0 && n >= 512)
-    {
-      // row-group kernel: one workgroup per (channel, chunk).  The forward kernel does not care
-      // (256 ... 2048 workgroups: 2.91-2.95 ms at n = 1e6), the carry pre-pass gets cheaper with
-      // fewer chunks (1017 chunks 0.044 ms, 511 chunks 0.029 ms): two rounds of the 256 CUs
-      // exact carries: 8 overlap segments of >= 256 workgroups (N = 4096 f32, n = 262144: 1024 chunks in 4
-      // segments 2.52 ms, 2048 in 8 2.40; FD double with carry = 1, n = 1e6: 10.4 -> 9.7 ms)
-      const long target_blocks = opt_target_waves > 0 ? std::max(1L, opt_target_waves / row_waves())
-                                                      : (carry_mode == CARRY_EXACT ? 2048 : 512);
-      long want = std::max(1L, (target_blocks + (long)channels - 1) / (long)channels);
-      const bool mid = opt_target_waves <= 0 && channels * n < 36000;
-      // >= 192 samples per chunk; calls between a hop and the north star's 48000 samples are bound by the
-      // serial samples of one chunk (~0.36 us each), not by HBM: about 190 chunks of >= 32 samples
-      // (measured, N = 1024 f64: n = 1024 77 -> 31 us, 4096 77 -> 36, 12000 79 -> 53, 24000 95 -> 91)
-      if (mid) want = std::max(1L, std::min((190L + (long)channels - 1) / (long)channels, (long)(n / 32)));
-      else want = std::max(1L, std::min(want, (long)(n / (carry_mode == CARRY_EXACT ? 128 : 192))));
-      // Whole rounds of the chip: a row group is one workgroup per CU, so a launch of 260 ... 500 workgroups on 256 CUs is one
-      // full round plus a partly filled one that takes just as long (n = 52000: 260 chunks of 200 rows 226 us = 47 % of peak,
-      // 250 chunks of 208 rows 168 us = 63.5 %; the same at 56000 / 60000 / 66000: profiles/r04_analysis_by_call_length.txt).
-      // Between one and two rounds the call takes ONE round of longer chunks.
-      // Pipelined calls are the opposite case: the next call's workgroups fill whatever a launch leaves free, and a launch
-      // that fills the chip exactly keeps all workgroups in step -- every CU in its prologue at the same time, nobody storing.
-      // About 300 chunks of >= 160 rows, whatever the length (n = 48 000: 250 x 192 141 us, 300 x 160 129.5 us = 76 % of
-      // peak; 66 000: 295 x 224 best; 100 000: 313 x 320; 262 144: 298 x 880 -- profiles/r04_pipelined_calls.txt)
-      if (!mid && pipe_this && opt_target_waves <= 0)
-      {
-        const long total = std::max(1L, (300L + (long)channels - 1) / (long)channels);
-        want = std::max(1L, std::min(total, (long)(n / 160)));
-      }
-      else if (!mid && carry_mode != CARRY_EXACT && opt_target_waves <= 0)
-      {
-        // (short rows too: N = 512 is two workgroups to a CU, yet 260 chunks take 118.5 us where 250 take 91.9 - a CU with two
-        // workgroups is simply twice as long at it)
-        const long round = (long)compute_units;
-        const long blocks = want * (long)channels;
-        if (blocks > round && blocks < 2L * round) want = std::max(1L, round / (long)channels);
-      }
-      // (n = 48000: 250 chunks of 192 rows leave 6 CUs idle; 256 chunks of 188 rows were measured the same, 137.3 against
-      // 137.9 us per call, and 128 chunks of 376 rows 145 us: the call is bound by HBM, not by the CUs that feed it)
-      len = (long)((n + want - 1) / want);
-      len = ((len + kGroup - 1) / kGroup) * kGroup;          // kGroup is a multiple of kRowGroup
-      if (carry_mode == CARRY_EXACT)
-      {
-        len = ((len + 31) / 32) * 32;                        // whole trips of the exact pass's inner loop
-        if (mid && len > 32) len = ((len + 63) / 64) * 64;   // whole blocks of the ring form at FD float
-        if (!mid && len > 64) len = ((len + 127) / 128) * 128;   // whole blocks of the relay form
-      }
-      len = std::max(1L, std::min(len, (long)n));
-      chunks = (long)((n + len - 1) / len);
-      return;
-    }
-    const long target = opt_target_waves > 0 ? opt_target_waves : 16384;
-    const long min_len = 64;
-    if (opt_chunk <= 0 && n < 512) { chunks = 1; len = (long)n; return; }   // short hops stay serial (and bit-exact)
-    long want = (long)((target + (long)(channels * tiles()) - 1) / (long)(channels * tiles()));
-    if (opt_chunk > 0) len = (carry_mode == CARRY_FAST) ? ((opt_chunk + kSumBlock - 1) / kSumBlock) * kSumBlock : opt_chunk;
-    else
-    {
-      want = std::max(1L, std::min(want, (long)(n / min_len)));
-      len = (long)((n + want - 1) / want);
-      len = ((len + kGroup - 1) / kGroup) * kGroup;        // whole scalar-load groups (and sum blocks)
-      if (carry_mode == CARRY_EXACT) len = ((len + 31) / 32) * 32;   // whole trips of the exact pass's inner loop
-    }
-    len = std::max(1L, std::min(len, (long)n));
-    chunks = (long)((n + len - 1) / len);
+    logic::ChunkQuery q;
+    q.n = n; q.channels = channels; q.nbins = nbins; q.rows_kernel = rows_kernel; q.exact = carry_mode == CARRY_EXACT; q.pipelined = pipe_this;
+    q.forced_chunk = opt_chunk; q.target_waves = opt_target_waves; q.row_waves = row_waves(); q.tiles = tiles(); q.compute_units = compute_units;
+    const logic::Chunking c = logic::choose_chunks(q);
+    chunks = c.chunks; len = c.len;
   }
 
   // every launch is a 1-D grid (channels ride on grid.x); refuse what would not fit it
@@ -527,19 +386,7 @@ class Plan
   }
 
   // ---- exact carries, relay form: block length / seed table -----------------------------------------
-  // relay form: block length = seed distance: divides 2N and the chunk length; L products live in L registers per lane
-  unsigned relay_block(long len) const
-  {
-    const size_t span = 2 * nbins;
-    const unsigned top = sizeof(FD) == 4 ? 128u : 64u;
-    for (unsigned cand : {128u, 64u, 32u, 16u, 8u})
-    {
-      if (cand > top) continue;
-      if (opt_chain_L > 0 && (unsigned)opt_chain_L != cand) continue;
-      if (span % cand == 0 && (size_t)len % cand == 0 && ((span / cand) * nbins * sizeof(fdx)) <= ((size_t)256 << 20)) return cand;
-    }
-    return 0;
-  }
+  unsigned relay_block(long len) const { return logic::relay_block(nbins, len, sizeof(FD), sizeof(fdx), opt_chain_L); }
   // flow mode of the relay form (see forward_launch)
   long opt_relay_flow = 1, last_flow = 0;
   DevBuf<unsigned> d_ready;
@@ -678,10 +525,7 @@ class Plan
     SDFT_TRY(hipSetDevice(device));
     flag_pending = false;                                    // only the hop kernel signals its completion
 
-    if (prev_was_inverse && inverse_run == 1) inv_batch_mode = false;        // analysis, synthesis, analysis, ...: see inv_batch_mode
-    prev_was_inverse = false; inverse_run = 0;
-    if (prev_was_analysis && !fuse) ana_batch_mode = true;
-    prev_was_analysis = !fuse; if (!fuse) ++analysis_run;
+    calls.on_analysis(fuse != nullptr);                      // (which kind of host is calling: logic::CallPattern)
     const bool use_rows = rows_kernel_ok(rows != nullptr);
     long chunks, len;
     // (the folded fused kernel and the row-group forward kernel have the self-carried form)
@@ -694,8 +538,8 @@ class Plan
       out_lo = reinterpret_cast<uintptr_t>(out); out_hi = out_lo + ((channels - 1) * out_stride + n * nb) * sizeof(fdx);
       // (calls of a few thousand rows gain a microsecond from it and cost the host seven runtime calls instead of one,
       // 19 against 3 us: n = 4096, m = 1024: 25.6 against 26.4 us per call; from n = 8192 on 30.4 against 32.9)
-      pipe_this = ana_batch_mode && pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
-                  !ranges_overlap(out_lo, out_hi, prev_out);
+      pipe_this = calls.analysis_batch && pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
+                  !logic::overlap(out_lo, out_hi, prev_out);
     }
     bool self_form = self_eligible(n, fuse != nullptr, pipe_this) && (fuse ? folded_fuse : use_rows);
     if (self_form && fuse)
@@ -706,7 +550,7 @@ class Plan
       self_form = ps <= 2 && self_cells() * sizeof(fdx) <= process_tiles_bytes((unsigned)(pw * kWave));
     }
     if (!self_form) pipe_this = false;
-    if (out_hi) prev_out = PipeRange{out_lo, out_hi};
+    if (out_hi) prev_out = logic::Range{out_lo, out_hi};
     choose_chunks(n, chunks, len, use_rows);
     const long ntiles = tiles(), inter = interior_lanes();
     last_kernel = use_rows ? 2 : 1;
@@ -1004,25 +848,14 @@ class Plan
     return true;
   }
 
-  // radices of the mixed-radix FFT of `span` points (4, 2, 3, 5); count == 0: span has other prime factors
   static RadixList smooth_radices(size_t span)
   {
-    RadixList rl; rl.count = 0;
-    size_t rem = span;
-    for (unsigned f : {4u, 2u, 3u, 5u})
-      while (rem % f == 0 && rl.count < 15) { rl.r[rl.count++] = (unsigned char)f; rem /= f; }
-    if (rem != 1) rl.count = 0;
+    const logic::Radices r = logic::smooth_radices(span);
+    RadixList rl; rl.count = r.count;
+    for (int i = 0; i < 15; ++i) rl.r[i] = r.r[i];
     return rl;
   }
-  // LDS cells the in-kernel DFT of a self-carried chunk works in: 2N in place for powers of two, two buffers of 2N for
-  // the 2/3/5-smooth sizes (Stockham); 0: this 2N has neither form
-  size_t self_cells() const
-  {
-    const size_t span = 2 * nbins;
-    if (span < 16 || span > 4096) return 0;
-    if ((span & (span - 1)) == 0) return span;
-    return (opt_self >= 1 && smooth_radices(span).count > 0 && 2 * span * sizeof(fdx) <= (size_t)80 * 1024) ? 2 * span : 0;
-  }
+  size_t self_cells() const { return logic::self_cells(nbins, opt_self >= 1, sizeof(fdx)); }
   // what the self-carried form needs of the plan and the call (the kernel that has it is chosen by the caller)
   // (any_length: pipelined calls take the form whatever the length -- one stream runs long calls faster with the pre-pass,
   // n = 1e6: 77.3 against 75.5 % of peak, but two matrices in turn, pipelined: 82.4 %)
@@ -1047,21 +880,16 @@ class Plan
   bool stream_exposed = false;
   hipStream_t row_streams[2] = {nullptr, nullptr};
   hipEvent_t ev_pre = nullptr, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned long long pipe_seq = 0, pipe_calls = 0, pipe_ordered = 0;
-  bool pipe_open = false;
-  // what the outstanding row launches write (by launch number & 3): a call whose matrix or samples overlap one of them is
-  // ordered behind it, as one stream would have it (a host that writes call after call into the same buffer gets the
-  // last call's rows, not a mixture)
-  struct PipeRange { uintptr_t lo, hi; };
-  PipeRange pipe_out[4] = {};
-  PipeRange prev_out = {0, 0};                               // the matrix of the previous analysis call (dense, row-group kernel)
+  unsigned long long pipe_calls = 0, pipe_ordered = 0;
+  // what the outstanding row launches write and which row stream each went to: a call whose matrix or samples overlap one of
+  // them is ordered behind it, as one stream would have it (logic::RowRing decides, this class waits and records)
+  logic::RowRing ring;
+  logic::Range prev_out;                                     // the matrix of the previous analysis call (dense, row-group kernel)
   bool pipe_this = false;                                    // forward_launch: this call is pipelined
   // Only calls whose every pointer is the caller's DEVICE memory may leave the plan's stream: the host-pointer routes reuse
   // the plan's staging buffers (d_stage_*, d_io, d_pin) on the main stream right behind a launch and promise the outputs
   // complete on return.  Set by the device/device branches of sdft_n / isdft_n for the duration of the call.
   bool pipe_allowed = false;
-  int pipe_stream_of[4] = {0, 0, 0, 0};                      // the row stream a launch went to
-  static bool ranges_overlap(uintptr_t alo, uintptr_t ahi, const PipeRange& b) { return alo < b.hi && b.lo < ahi; }
   bool ensure_pipe()
   {
     if (ev_pre) return true;
@@ -1142,35 +970,26 @@ class Plan
   // Only for hosts that do synthesise call after call: a host that alternates analysis and synthesis (the reference's loop)
   // would pay an event wait between streams per call and gain nothing, so the mode is learnt from the calls themselves --
   // on when a synthesis follows a synthesis, off when an analysis follows a lone synthesis.
-  bool prev_was_inverse = false, inv_batch_mode = false;
-  int inverse_run = 0;
-  // (the same for analyses: a host that alternates analysis and synthesis on two matrices has no two analyses to overlap)
-  bool prev_was_analysis = false, ana_batch_mode = false;
-  int analysis_run = 0;
+  logic::CallPattern calls;                                   // ... learnt from the calls (the same for analyses)
   hipEvent_t ev_inv[2] = {nullptr, nullptr};                 // the last synthesis launch on each row stream
-  bool inv_used[2] = {false, false};
-  int inv_last = 1;
-  PipeRange inv_y[2] = {};                                   // the samples the last synthesis on each row stream writes
+  logic::InverseStreams inv;
   unsigned long long inv_calls = 0;
   long last_inverse_pipelined = 0;
   bool pipe_join_inverses()
   {
     for (int i = 0; i < 2; ++i)
-      if (inv_used[i]) { SDFT_TRY(hipStreamWaitEvent(stream, ev_inv[i], 0)); inv_used[i] = false; }
+      if (inv.used[i]) { SDFT_TRY(hipStreamWaitEvent(stream, ev_inv[i], 0)); inv.used[i] = false; }
     return true;
   }
   bool pipe_join() { return pipe_join_rows() && pipe_join_inverses(); }
   bool pipe_join_rows()
   {
-    if (!pipe_open) return true;
+    if (!ring.open) return true;
     // the last launch on each row stream (among the four the ring remembers; older ones are ordered before them)
-    bool seen[2] = {false, false};
-    for (unsigned long long back = 1; back <= 4 && back <= pipe_seq; ++back)
-    {
-      const int q = (int)((pipe_seq - back) & 3), rsi = pipe_stream_of[q];
-      if (!seen[rsi]) { seen[rsi] = true; SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[q], 0)); }
-    }
-    pipe_open = false; pipe_seq = 0;
+    int slots[2];
+    const int count = ring.last_per_stream(slots);
+    for (int i = 0; i < count; ++i) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[slots[i]], 0));
+    ring.joined();
     return true;
   }
   void release_pipe()
@@ -1178,8 +997,8 @@ class Plan
     for (int i = 0; i < 2; ++i) if (row_streams[i]) { (void)hipStreamSynchronize(row_streams[i]); (void)hipStreamDestroy(row_streams[i]); row_streams[i] = nullptr; }
     if (ev_pre) { (void)hipEventDestroy(ev_pre); ev_pre = nullptr; }
     for (int i = 0; i < 4; ++i) if (ev_rows[i]) { (void)hipEventDestroy(ev_rows[i]); ev_rows[i] = nullptr; }
-    for (int i = 0; i < 2; ++i) { if (ev_inv[i]) { (void)hipEventDestroy(ev_inv[i]); ev_inv[i] = nullptr; } inv_used[i] = false; }
-    pipe_open = false; pipe_seq = 0;
+    for (int i = 0; i < 2; ++i) { if (ev_inv[i]) { (void)hipEventDestroy(ev_inv[i]); ev_inv[i] = nullptr; } inv.used[i] = false; }
+    ring.joined();
     (void)hipGetLastError();
   }
   bool pipe_wanted(const void* fuse) const
@@ -1246,32 +1065,24 @@ class Plan
         if (!pipe_join_inverses()) return false;             // never beside a synthesis
         const uintptr_t xlo = reinterpret_cast<uintptr_t>(x), xhi = xlo + ((channels - 1) * x_stride + n) * sizeof(TD);
         // samples that an outstanding launch is still writing (a matrix reinterpreted as samples): no overlap for this call
-        for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
-          if (ranges_overlap(xlo, xhi, pipe_out[(pipe_seq - back) & 3])) { if (!pipe_join()) return false; break; }
+        if (ring.samples_overlap(xlo, xhi) && !pipe_join()) return false;
         const int s1 = (st_cur + 1) & 3, h1 = (hist_cur + 1) & 3;
         // Which row stream: the other one than the previous launch's -- unless this call's matrix overlaps what an
         // outstanding launch writes (a host that reuses one matrix): then the stream of the latest such launch, whose order
         // costs nothing (an event wait across streams costs ~15 us per call: n = 48 000 into one matrix 171 against 157 us)
-        int rsi = pipe_seq ? (pipe_stream_of[(pipe_seq - 1) & 3] ^ 1) : 0;
-        bool behind = false;
-        for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
-          if (ranges_overlap(olo, ohi, pipe_out[(pipe_seq - back) & 3])) { rsi = pipe_stream_of[(pipe_seq - back) & 3]; behind = true; break; }
+        const logic::RowRing::Pick pk = ring.pick(olo, ohi);
+        const int rsi = pk.stream;
         hipStream_t rs = row_streams[rsi];
         // the rows read the state everything queued on the main stream so far leaves behind
         SDFT_TRY(hipEventRecord(ev_pre, stream));
         SDFT_TRY(hipStreamWaitEvent(rs, ev_pre, 0));
-        if (behind)
+        if (pk.behind)
         {
           ++pipe_ordered;
-          // (overlapping launches on the other stream as well: the latest of them)
-          for (unsigned long long back = 1; back <= 3 && back <= pipe_seq; ++back)
-          {
-            const int q = (int)((pipe_seq - back) & 3);
-            if (pipe_stream_of[q] != rsi && ranges_overlap(olo, ohi, pipe_out[q])) { SDFT_TRY(hipStreamWaitEvent(rs, ev_rows[q], 0)); break; }
-          }
+          if (pk.wait_launch >= 0) SDFT_TRY(hipStreamWaitEvent(rs, ev_rows[pk.wait_launch], 0));   // (overlapping launches on the other stream as well: the latest of them)
         }
         // the slot the state kernel writes was read by the rows of three calls ago
-        if (pipe_seq >= 3) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[(pipe_seq + 1) & 3], 0));
+        if (ring.state_reader() >= 0) SDFT_TRY(hipStreamWaitEvent(stream, ev_rows[ring.state_reader()], 0));
         ForwardArgs<FD> fs = fa; SelfArgs<TD, FD> ss = sa;
         fs.acc_state = d_accs[s1].p; fs.fid_state = d_fids[s1].p; ss.hist_out = d_hist[h1].p;
         fs.done.flag = nullptr; fs.done.count = nullptr; fs.done.seq = 0; fs.done.total = 0;
@@ -1284,10 +1095,9 @@ class Plan
         const bool ok = launch_forward_rows_self(fr, sr, blocks, (unsigned)(row_waves() * kWave), fused);
         stream = main_stream;
         if (!ok) return false;
-        SDFT_TRY(hipEventRecord(ev_rows[pipe_seq & 3], rs));
-        pipe_out[pipe_seq & 3] = PipeRange{olo, ohi};
-        pipe_stream_of[pipe_seq & 3] = rsi;
-        ++pipe_seq; ++pipe_calls; pipe_open = true;
+        SDFT_TRY(hipEventRecord(ev_rows[ring.slot()], rs));
+        ring.launched(olo, ohi, rsi);
+        ++pipe_calls;
         last_pipelined = 1;
         st_cur = s1; hist_cur = h1;
         fid_canonical = false;                               // the rotation comes from the closed-form table (as the one-stream self form below)
@@ -1393,16 +1203,27 @@ class Plan
     const bool wide = ha.total_waves > 2048;
     const unsigned long long blocks = wide ? (ha.total_waves + 3) / 4 : ha.total_waves;
     if (!grid_fits(blocks)) return false;
-    ha.done = arm_flag(wide ? 0u : (unsigned)blocks);
+    // small launches of hop-sized calls: two waves per tile (recurrence | window + stores)
+    const bool pipe = !wide && opt_hop_pipe && n <= (size_t)kHopMax;
+    last_hop_pipe = pipe;
+    // ... and the call's samples in time parts, every (tile, part) a workgroup on a CU of its own (forward_hop2_kernel): as many
+    // parts as leave every workgroup a CU, at most 8, at least 12 samples each (the recurrence wave of a part runs the state
+    // through the samples before it: what a part saves is the window, the demodulation and the stores of those samples)
+    ha.parts = 1; ha.part_len = (unsigned)n;
+    if (pipe)
+    {
+      const logic::HopParts hp = logic::hop_parts(n, ha.total_waves, compute_units, opt_hop_parts, flag_wanted && !async);
+      ha.parts = hp.parts; ha.part_len = hp.part_len;
+    }
+    last_hop_parts = ha.parts;
+    const unsigned hop2_blocks = (unsigned)blocks * ha.parts;
+    ha.done = arm_flag(wide ? 0u : (pipe ? hop2_blocks : (unsigned)blocks));     // every workgroup reports
     ha.stamps = nullptr;
 #ifdef SDFT_HOP_STAMPS
     if (d_partial.reserve(64)) { ha.stamps = reinterpret_cast<unsigned long long*>(d_partial.p); last_partial_elems = 0; hop2_stamps = true; }
 #endif
     if (!prof_begin(ST_FORWARD)) return false;
-    // small launches of hop-sized calls: two waves per tile (recurrence | window + stores)
-    const bool pipe = !wide && opt_hop_pipe && n <= (size_t)kHopMax;
-    last_hop_pipe = pipe;
-    if (pipe) { if (rows) launch_hop2_t<true>(ha, (unsigned)blocks); else launch_hop2_t<false>(ha, (unsigned)blocks); }
+    if (pipe) { if (rows) launch_hop2_t<true>(ha, hop2_blocks); else launch_hop2_t<false>(ha, hop2_blocks); }
     else if (rows) { if (wide) launch_hop_t<true, 4>(ha, (unsigned)blocks); else launch_hop_t<true, 1>(ha, (unsigned)blocks); }
     else      { if (wide) launch_hop_t<false, 4>(ha, (unsigned)blocks); else launch_hop_t<false, 1>(ha, (unsigned)blocks); }
     SDFT_TRY(hipGetLastError());
@@ -1721,11 +1542,8 @@ class Plan
   // 1.13 ms, n = 1e6: 0.397 -> 0.388 ms; n = 48000 alone: 0.038 -> 0.045 ms, so not there)
   void process_geometry(bool fused, long& waves, long& slots, size_t n = 0) const
   {
-    waves = std::min<long>(kRowWavesMax, (long)((nbins + kWave - 1) / kWave));
-    long want = opt_proc_slots > 0 ? opt_proc_slots
-              : ((fused && sizeof(FD) == 8 && nbins >= 256) ? ((nbins >= 512 && channels * n >= 400000) ? 4 : 2) : 1);
-    if (want > 1) waves = std::max(1L, std::min(waves, (long)((nbins + kWave * want - 1) / (kWave * want))));
-    slots = (long)((nbins + (size_t)waves * kWave - 1) / ((size_t)waves * kWave));      // bins per lane: 1, 2, (3 ->) 4
+    const logic::ProcessGeometry g = logic::process_geometry(nbins, channels, n, fused, sizeof(FD), opt_proc_slots);
+    waves = g.waves; slots = g.slots;
   }
   bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused, const SelfArgs<TD, FD>* self = nullptr)
   {
@@ -1798,33 +1616,23 @@ class Plan
       }
     }
     last_inverse_form = 1;
-    long rw = opt_inverse_rows > 0 ? opt_inverse_rows
-                                   : (total_rows <= 1024 ? 1 : total_rows < 65536 ? 4 : ((sizeof(FD) == 8 && total_rows >= (size_t)32 * 8192) ? 32 : 16));
-    // Medium calls are a staircase in the row count: the waves of a launch that does not fit the chip at once leave a last,
-    // partly filled round that runs at a lone wave's pace (a chain of memory round trips: 30-45 us).  Where 4 rows per wave
-    // need a second round and 8 rows per wave (4 tiles in flight) fit in one, the 8-row form is taken: TD = FD = double,
-    // m = 1000: 36000 ... 56000 rows 10-18 % faster (n = 44100: 137 -> 115 us), profiles/r04_synthesis_rows_per_wave.txt.
+    // (rows per wave: logic::inverse_rows_per_wave; the capacities of the 4-row and the 8-row form come from the occupancy API)
     if constexpr (!OPS)
     {
-      if (opt_inverse_rows <= 0 && rw == 4)
+      if (opt_inverse_rows <= 0 && inverse_capacity[0] == 0 && total_rows > 1024 && total_rows < 65536)
       {
-        if (inverse_capacity[0] == 0)
+        int dev_cus = 0, b4 = 0, b8 = 0;
+        if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>, kBlock, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>, kBlock, 0) == hipSuccess)
         {
-          int dev_cus = 0, b4 = 0, b8 = 0;
-          if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
-              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>, kBlock, 0) == hipSuccess &&
-              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>, kBlock, 0) == hipSuccess)
-          {
-            inverse_capacity[0] = (size_t)std::max(1, b4) * dev_cus * kWavesPerBlock;
-            inverse_capacity[1] = (size_t)std::max(1, b8) * dev_cus * kWavesPerBlock;
-          }
-          else { (void)hipGetLastError(); inverse_capacity[0] = inverse_capacity[1] = (size_t)-1; }
+          inverse_capacity[0] = (size_t)std::max(1, b4) * dev_cus * kWavesPerBlock;
+          inverse_capacity[1] = (size_t)std::max(1, b8) * dev_cus * kWavesPerBlock;
         }
-        const size_t groups4 = (total_rows + 3) / 4, groups8 = (total_rows + 7) / 8;
-        if (groups4 > inverse_capacity[0] && groups8 <= inverse_capacity[1]) rw = 8;
+        else { (void)hipGetLastError(); inverse_capacity[0] = inverse_capacity[1] = (size_t)-1; }
       }
     }
-    if (OPS && rw != 1) rw = 16;                                                 // one streaming instantiation with the operation built in
+    const long rw = logic::inverse_rows_per_wave(total_rows, sizeof(FD), opt_inverse_rows, inverse_capacity[0], inverse_capacity[1], OPS);
     size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
     eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
     const dim3 g((unsigned)eb), b(kBlock);
@@ -1869,10 +1677,8 @@ class Plan
     const bool ops_wanted = op && op->kind != OP_IDENTITY;
     last_inverse_pipelined = 0;
     // (whatever FD is: the synthesis has no state to carry from call to call)
-    if (prev_was_inverse) inv_batch_mode = true;
-    if (prev_was_analysis && analysis_run == 1) ana_batch_mode = false;
-    prev_was_analysis = false; analysis_run = 0;
-    const bool inv_pipe = inv_batch_mode && pipe_allowed && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
+    calls.on_synthesis_begin();
+    const bool inv_pipe = calls.inverse_batch && pipe_allowed && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
                           channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
     if (!(inv_pipe ? pipe_join_rows() : pipe_join())) return false;
     hipStream_t main_stream = stream;
@@ -1882,17 +1688,14 @@ class Plan
     {
       // the other stream than the previous synthesis -- the same one if the two write overlapping samples
       ylo = reinterpret_cast<uintptr_t>(y); yhi = ylo + ((channels - 1) * y_stride + n) * sizeof(TD);
-      si = ranges_overlap(ylo, yhi, inv_y[inv_last]) ? inv_last : (inv_last ^ 1);
+      const uintptr_t ilo = reinterpret_cast<uintptr_t>(in), ihi = ilo + ((channels - 1) * in_stride + n * nbins) * sizeof(fdx);
+      const logic::InverseStreams::Pick pk = inv.pick(logic::Range{ylo, yhi}, logic::Range{ilo, ihi});
+      si = pk.stream;
       SDFT_TRY(hipEventRecord(ev_pre, stream));               // behind everything the main stream has been given (the joins above too)
       SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_pre, 0));
       // what the OTHER row stream still has outstanding: samples this call overwrites (a host that rotates three sample
       // buffers) or a matrix that was reinterpreted from them -- ordered behind it
-      const int so = si ^ 1;
-      if (inv_used[so])
-      {
-        const uintptr_t ilo = reinterpret_cast<uintptr_t>(in), ihi = ilo + ((channels - 1) * in_stride + n * nbins) * sizeof(fdx);
-        if (ranges_overlap(ylo, yhi, inv_y[so]) || ranges_overlap(ilo, ihi, inv_y[so])) SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_inv[so], 0));
-      }
+      if (pk.wait_other) SDFT_TRY(hipStreamWaitEvent(row_streams[si], ev_inv[si ^ 1], 0));
       stream = row_streams[si];
     }
     struct Restore { hipStream_t& s; hipStream_t v; ~Restore() { s = v; } } restore{stream, main_stream};
@@ -1915,11 +1718,11 @@ class Plan
     SDFT_TRY(hipGetLastError());
     if (rtc_failed) { rtc_failed = false; return false; }    // (the compiler's words are in the error channel already)
     if (!prof_end(ST_INVERSE)) return false;
-    prev_was_inverse = true; ++inverse_run;
+    calls.on_synthesis_launched();
     if (inv_pipe)
     {
       SDFT_TRY(hipEventRecord(ev_inv[si], stream));
-      inv_used[si] = true; inv_last = si; inv_y[si] = PipeRange{ylo, yhi};
+      inv.launched(si, logic::Range{ylo, yhi});
       ++inv_calls; last_inverse_pipelined = 1;
     }
     return true;
@@ -1961,7 +1764,6 @@ class Plan
   // wall-clock time (about twice what the call can take at HBM speed, at most 5 ms; 50 ms for the word) and only then
   // block.  flag_fallbacks counts completion words that never became visible (get_option "flag_fallbacks").
   long flag_fallbacks = 0;
-  static constexpr double kPeakBytesPerUs = 8.0e6;          // HBM3E spec peak, 8 TB/s (MI355X_MICROARCH.md): no call ends sooner than bytes / this
   static inline void cpu_relax()
   {
 #if defined(__SSE2__)
@@ -1999,22 +1801,22 @@ class Plan
     // The wait is the same on every box and never sleeps on the stream while the call can still be running: a sleeping
     // hipStreamSynchronize wakes up 9 us late on one box and 45 us late on another (round 4 slept for calls beyond 60 us and
     // lost 10 % of the north star's synchronous rate on the box it was not tuned on; profiles/r05_sync_completion.txt).  A call
-    // cannot end before its bytes have moved at the chip's peak rate (kPeakBytesPerUs -- the spec figure, a LOWER bound of the
+    // cannot end before its bytes have moved at the chip's peak rate (logic::kPeakBytesPerUs -- the spec figure, a LOWER bound of the
     // time, not a tuned one): until then the host spins on its own clock without touching the runtime (queries that cannot
     // succeed yet only compete with the completion signal's handler for the runtime's locks), then it polls the stream.
     // Option "spin": 0 = sleep on the stream, 1 = this (default), 2 = poll from the start.
     if (opt_spin && hbm_bytes)
     {
-      const double floor_us = (double)hbm_bytes / kPeakBytesPerUs;
-      const auto budget = std::chrono::microseconds((long long)std::min(20000.0, 200.0 + 4.0 * floor_us));
+      const logic::SyncWait w = logic::sync_wait(hbm_bytes);
       const clock::time_point t0 = clock::now();
-      if (opt_spin == 1 && floor_us > 8.0)
+      if (opt_spin == 1 && w.quiet_us > 0)
       {
         // (counted from the entry point's start: a call that has waited for its kernels already -- the exact-carry route
         // checks its poll loops' status word behind a synchronisation -- is not made to wait again)
-        const auto quiet = std::chrono::nanoseconds((long long)(floor_us * 1000.0));
+        const auto quiet = std::chrono::nanoseconds((long long)(w.quiet_us * 1000.0));
         while (clock::now() - call_start < quiet) cpu_relax();
       }
+      const auto budget = std::chrono::microseconds((long long)w.budget_us);
       for (unsigned spins = 1;; ++spins)
       {
         const hipError_t e = hipStreamQuery(stream);
@@ -2053,194 +1855,23 @@ class Plan
     return is_device_pointer(p);
   }
 
-  // ---- host buffers, mapped in place --------------------------------------------------------------------------
-  // A host of the reference hands malloc'ed buffers to every call and reuses them hop after hop
-  // (/root/reference/test/test.c:62-83).  Copying through the runtime's pageable path costs such a hop-sized call more
-  // than its kernels (round 1: 191 us for a 1.6 MB hop); registering the caller's buffer once (hipHostRegister: the
-  // pages are pinned and mapped, the driver follows the mapping with MMU notifiers) lets the kernels read and write it
-  // over PCIe directly -- no staging copy, one synchronisation.  Buffers of 1 MiB and more only (smaller ones share
-  // pages with their heap neighbours), at most 8 ranges that never share a page; anything the runtime refuses
-  // falls back to the staged path.  Option "host_register" = 1 turns it on, "host_register_max" bounds the
-  // bytes of one buffer (default 256 MiB: longer calls run at PCIe speed through the staged path anyway).
-  static constexpr size_t kSmallHostBytes = (size_t)64 << 10;
-  static constexpr size_t kHostRegisterMin = (size_t)1 << 20;       // smaller buffers share pages with their heap neighbours: staged
-  // OFF by default: a registration dies with the mapping it was made on.  A host that frees a buffer and gets the same
-  // address back from its allocator (numpy does, every call) would make a remembered registration fault the GPU
-  // (measured: "Memory access fault" on the second call) -- the driver does not re-attach it.  A C host that allocates
-  // its buffers once, like the reference's driver, sets option "host_register" = 1.
-  long opt_host_register = 0;
-  size_t opt_host_register_max = (size_t)256 << 20;
-  // A registration covers exactly the caller's bytes [a, b) -- NOT the whole pages around them: a long-lived process gets
-  // its megabyte buffers from the heap (glibc raises its mmap threshold as buffers are freed), where the neighbours share
-  // the first and last page; with whole pages registered, a later copy from or to such a neighbour -- inside the
-  // registered range at one end, outside at the other -- fails in the runtime ("invalid argument": seen in the test
-  // suite, never in a fresh process).  Our own registrations still never share a page with each other ([plo, phi) are the
-  // page ranges: two registrations sharing a page would lose it when the first of them is dropped).
-  struct HostReg { uintptr_t a, b, plo, phi; char* dev; unsigned long long used; bool owned, writable; };
-  HostReg host_regs[8] = {};
-  unsigned long long host_reg_clock = 0;
-  long host_reg_hits = 0, host_reg_misses = 0;
-  void drop_host(HostReg& e)
-  {
-    if (e.b && e.owned) { (void)hipHostUnregister(reinterpret_cast<void*>(e.a)); (void)hipGetLastError(); }
-    e = HostReg{};
-  }
-  void forget_host_buffers() { for (HostReg& e : host_regs) drop_host(e); }
-  // device-side address of a host buffer of `bytes` bytes, or nullptr (not used / not possible: take the staged path)
-  void* map_host(const void* p, size_t bytes, bool will_write = false)
-  {
-    if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > opt_host_register_max) return nullptr;
-    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p), b = a + bytes;
-    const uintptr_t plo = a & ~(page - 1), phi = (b + page - 1) & ~(page - 1);
-    for (HostReg& e : host_regs)
-      if (e.b && a >= e.a && b <= e.b)
-      {
-        if (will_write && !e.writable && e.owned) { drop_host(e); break; }   // registered for reading: again, with its pages made writable first
-        e.used = ++host_reg_clock; ++host_reg_hits; return e.dev + (a - e.a);
-      }
-    // anything of ours that shares a page with the new range goes first
-    for (HostReg& e : host_regs)
-      if (e.b && plo < e.phi && e.plo < phi) drop_host(e);
-    HostReg* slot = &host_regs[0];
-    for (HostReg& e : host_regs) { if (!e.b) { slot = &e; break; } if (e.used < slot->used) slot = &e; }
-    drop_host(*slot);
-    ++host_reg_misses;
-    void* dev = nullptr;
-    // memory the host pinned itself (hipHostMalloc, its own hipHostRegister) is mapped already
-    if (hipHostGetDevicePointer(&dev, const_cast<void*>(p), 0) == hipSuccess && dev)
-    {
-      *slot = HostReg{a, b, plo, phi, static_cast<char*>(dev), ++host_reg_clock, false, true};
-      return dev;
-    }
-    (void)hipGetLastError();
-    if (will_write)
-    {
-      // an output buffer the host has never written (calloc, numpy.zeros) may still be mapped to the kernel's shared zero
-      // page, copy on write: every page gets its own writable frame BEFORE it is pinned (writing a byte back to itself --
-      // the buffer is ours to overwrite for the duration of the call), so that what the device writes is what the host reads
-      volatile char* q = reinterpret_cast<volatile char*>(a);
-      for (uintptr_t off = 0; off < bytes; off += page) q[off] = q[off];
-      q[bytes - 1] = q[bytes - 1];
-    }
-    if (hipHostRegister(reinterpret_cast<void*>(a), bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipHostGetDevicePointer(&dev, reinterpret_cast<void*>(a), 0) != hipSuccess || !dev)
-    {
-      (void)hipGetLastError(); (void)hipHostUnregister(reinterpret_cast<void*>(a)); (void)hipGetLastError(); return nullptr;
-    }
-    *slot = HostReg{a, b, plo, phi, static_cast<char*>(dev), ++host_reg_clock, true, will_write};
-    return dev;
-  }
-
-  // ---- copies between the caller's host memory and the device ---------------------------------------------------
-  // The runtime's own path for pageable memory PINS the caller's pages once a copy exceeds its threshold (about 1 MiB) and
-  // remembers the pin per stream, keyed by address and size.  A host that frees such a buffer, lets the heap shrink and
-  // later gets the address back (numpy does; so does any long-lived process) makes the next copy find a pin whose pages
-  // left the process in between -- the driver does not re-attach it and the copy kernel faults the GPU ("Write access to a
-  // read-only page", the process is gone; seen in this library's own test suite about one run in three, round 4).  So
-  // nothing of the caller's is ever handed to the runtime to pin: copies beyond 64 KiB go through a pair of pinned 2 MiB
-  // pieces of the plan (DMA of one piece while the host copies the other), smaller ones through the runtime's staging
-  // buffers as before.  scripts/pageable_copy_probe.hip, profiles/r04_host_copy_paths.txt: every piece costs ~15 us
-  // of its own (1.6 MB in pieces of 128 KiB: 200 us), the host's copy out of pinned memory the device has just written
-  // runs at 42 GB/s with streaming stores (host_copy_bytes; glibc memcpy 30); 1.6 MB as one piece: ~70 us out, ~50 us in,
-  // against 37 us each way on a pin the runtime remembered;
-  // long copies 26 against 55 GB/s.  A hop-sized matrix (up to both pieces, 4 MiB) skips the DMA: the kernels write or
-  // read the pinned pieces themselves over PCIe (sdft_n / isdft_n below; option "host_direct" = 0 turns that off).
-  // Option "host_copy" = 1 hands everything to the runtime (a host that allocates its buffers once and keeps them, like
-  // the reference's driver, loses nothing by it).
+  // ---- the caller's host memory (sdft_host_io.hpp): registered in place, or copied through pinned slots of the plan ----------
+  HostIo io;
+  static constexpr size_t kSmallHostBytes = HostIo::kSmallHostBytes;
+  void* map_host(const void* p, size_t bytes, bool will_write = false) { return io.map_host(p, bytes, will_write); }
   // Both are complete on return as far as the caller's memory goes: to_device has read it, to_host has written it.
-  static constexpr size_t kPinPiece = (size_t)2 << 20;
-  long opt_host_copy = 0;
-  long opt_host_direct = 1;                                  // hop-sized matrices: the kernels work on the pinned pieces themselves
-  char* h_pin = nullptr;
-  char* d_pin = nullptr;                                     // the same pieces as the kernels see them
-  hipEvent_t pin_ev[2] = {nullptr, nullptr};
-  bool pin_busy[2] = {false, false};
-  long pin_copies = 0;
-  double pin_us_memcpy = 0, pin_us_device = 0;               // where a staged call's time went: the host's memcpy, waiting for the device
-  static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-  void free_pin_pages()
-  {
-    if (h_pin) (void)hipHostFree(h_pin);
-    h_pin = nullptr; d_pin = nullptr;
-  }
-  bool ensure_pin()
-  {
-    if (h_pin) return true;
-    if (hipHostMalloc((void**)&h_pin, 2 * kPinPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h_pin = nullptr; return false; }
-    if (hipHostGetDevicePointer((void**)&d_pin, h_pin, 0) != hipSuccess || !d_pin) { (void)hipGetLastError(); free_pin_pages(); return false; }
-    for (int k = 0; k < 2; ++k)
-      if (hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming) != hipSuccess)
-      {
-        (void)hipGetLastError();
-        if (k == 1) (void)hipEventDestroy(pin_ev[0]);
-        pin_ev[0] = pin_ev[1] = nullptr; free_pin_pages(); return false;
-      }
-    return true;
-  }
-  void release_pin()
-  {
-    for (int k = 0; k < 2; ++k) { if (pin_ev[k]) { (void)hipEventSynchronize(pin_ev[k]); (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; } pin_busy[k] = false; }
-    free_pin_pages();
-    (void)hipGetLastError();
-  }
-  bool pin_wait(int k)
-  {
-    if (pin_busy[k]) { SDFT_TRY(hipEventSynchronize(pin_ev[k])); pin_busy[k] = false; }
-    return true;
-  }
+  bool copy_failed() { set_error("host copy", "a copy between host memory and the device through the plan's pinned slots failed"); return false; }
   bool to_device(void* dst, const void* src, size_t bytes)
   {
     if (bytes == 0) return true;
     if (!pipe_join()) return false;                          // (a no-op unless row streams hold outstanding launches)
-    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
-    {
-      SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-      return true;
-    }
-    ++pin_copies;
-    int k = 0;
-    for (size_t o = 0; o < bytes; o += kPinPiece, k ^= 1)
-    {
-      const size_t len = std::min(kPinPiece, bytes - o);
-      if (!pin_wait(k)) return false;
-      host_copy_bytes(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len);
-      SDFT_TRY(hipMemcpyAsync((char*)dst + o, h_pin + (size_t)k * kPinPiece, len, hipMemcpyHostToDevice, stream));
-      SDFT_TRY(hipEventRecord(pin_ev[k], stream));
-      pin_busy[k] = true;
-    }
-    return true;                                             // the pieces still in flight are waited for before their next use
+    return io.to_device(dst, src, bytes, stream) || copy_failed();
   }
   bool to_host(void* dst, const void* src, size_t bytes)
   {
     if (bytes == 0) return true;
     if (!pipe_join()) return false;
-    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
-    {
-      SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
-      return true;
-    }
-    ++pin_copies;
-    int k = 0, pk = -1;
-    size_t po = 0, plen = 0;
-    for (size_t o = 0; o < bytes || pk >= 0; k ^= 1)
-    {
-      size_t len = 0;
-      if (o < bytes)
-      {
-        len = std::min(kPinPiece, bytes - o);
-        if (!pin_wait(k)) return false;
-        SDFT_TRY(hipMemcpyAsync(h_pin + (size_t)k * kPinPiece, (const char*)src + o, len, hipMemcpyDeviceToHost, stream));
-        SDFT_TRY(hipEventRecord(pin_ev[k], stream));
-        pin_busy[k] = true;
-      }
-      if (pk >= 0)
-      {
-        if (!pin_wait(pk)) return false;
-        host_copy_bytes((char*)dst + po, h_pin + (size_t)pk * kPinPiece, plen);
-      }
-      if (o < bytes) { pk = k; po = o; plen = len; o += len; } else pk = -1;
-    }
-    return true;
+    return io.to_host(dst, src, bytes, stream) || copy_failed();
   }
 
   // one strip per channel (no pitch limits, works for any size); kind says which side is the caller's host memory
@@ -2327,9 +1958,9 @@ class Plan
     // (scripts/host_hop_paths.py, profiles/r04_host_copy_paths.txt)
     {
       const size_t obytes = channels * n * nbins * sizeof(fdx), xbytes = channels * n * sizeof(TD);
-      if (!od && opt_host_copy == 0 && opt_host_direct && obytes <= 2 * kPinPiece && (xd || xbytes <= kSmallHostBytes) && ensure_pin())
+      if (!od && io.opt_host_copy == 0 && io.opt_host_direct && obytes <= HostIo::kDirectBytes && (xd || xbytes <= kSmallHostBytes) && io.ensure_pin())
       {
-        if (!pin_wait(0) || !pin_wait(1)) return false;
+        if (!io.pin_idle()) return copy_failed();
         const TD* xm = x;
         if (!xd)
         {
@@ -2341,13 +1972,13 @@ class Plan
             xm = d_stage_td.p;
           }
         }
-        ++pin_copies;
-        const double t0 = now_us();
-        if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(d_pin), n * nbins, nullptr)) return false;
+        ++io.pin_copies;
+        const double t0 = HostIo::now_us();
+        if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(io.d_pin), n * nbins, nullptr)) return false;
         if (!finish_mapped(matrix_bytes(n))) return false;
-        const double t1 = now_us();
-        host_copy_bytes(dfts, h_pin, obytes);
-        pin_us_device += t1 - t0; pin_us_memcpy += now_us() - t1;
+        const double t1 = HostIo::now_us();
+        io.copy_bytes(dfts, io.h_pin, obytes);
+        io.pin_us_device += t1 - t0; io.pin_us_memcpy += HostIo::now_us() - t1;
         return true;
       }
     }
@@ -2485,21 +2116,21 @@ class Plan
     // a hop-sized matrix in host memory: copied into the plan's pinned pieces, which the kernel reads over PCIe
     {
       const size_t ibytes = channels * n * nbins * sizeof(fdx), ybytes = channels * n * sizeof(TD);
-      if (!id && opt_host_copy == 0 && opt_host_direct && ibytes <= 2 * kPinPiece && (yd || ybytes <= kSmallHostBytes) && ensure_pin())
+      if (!id && io.opt_host_copy == 0 && io.opt_host_direct && ibytes <= HostIo::kDirectBytes && (yd || ybytes <= kSmallHostBytes) && io.ensure_pin())
       {
-        if (!pin_wait(0) || !pin_wait(1)) return false;
-        const double t0 = now_us();
-        host_copy_bytes(h_pin, dfts, ibytes);
-        const double t1 = now_us();
-        pin_us_memcpy += t1 - t0;
-        ++pin_copies;
+        if (!io.pin_idle()) return copy_failed();
+        const double t0 = HostIo::now_us();
+        io.copy_bytes(io.h_pin, dfts, ibytes);
+        const double t1 = HostIo::now_us();
+        io.pin_us_memcpy += t1 - t0;
+        ++io.pin_copies;
         TD* ym = y;
         const bool through_io = !yd && ybytes <= kIoBytes && opt_pinned_io && ensure_io();
         if (!yd) { if (through_io) ym = d_io; else { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; } }
-        if (!inverse_device(n, reinterpret_cast<const fdx*>(d_pin), n * nbins, nullptr, ym, n)) return false;
+        if (!inverse_device(n, reinterpret_cast<const fdx*>(io.d_pin), n * nbins, nullptr, ym, n)) return false;
         if (!yd && !through_io && !to_host(y, ym, ybytes)) return false;
         if (!finish_mapped(matrix_bytes(n))) return false;
-        pin_us_device += now_us() - t1;
+        io.pin_us_device += HostIo::now_us() - t1;
         if (through_io) memcpy(y, h_io, ybytes);
         return true;
       }

