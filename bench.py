@@ -661,8 +661,11 @@ def main():
             sync()
             lin = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 0, m, 64, 1, 5)
             grp = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 2, m, 8, max(int(plan.get_option("last_chunk_len")), 1), 5)
+            # (c) the same with every XCD writing a contiguous eighth of the matrix -- the placement the analysis launches take
+            # since round 5 (ForwardArgs::xcd_map): the workgroups running at the same time are spread over the whole matrix
+            spr = lib.sdft_hip_store_ceiling(out.data_ptr(), nbytes, 4, m, 8, max(int(plan.get_option("last_chunk_len")), 1), 5)
             torch.cuda.synchronize()
-            best_ms = min(v for v in (lin, grp) if v > 0)
+            best_ms = min(v for v in (lin, grp, spr) if v > 0)
             ld = lib.sdft_hip_load_ceiling(out.data_ptr(), nbytes, 5)
             torch.cuda.synchronize()
             if ld > 0 and i_avg > 0:
@@ -673,6 +676,7 @@ def main():
             result["roofline"]["store_only_ceiling"] = {
                 "linear_fill_gbs": round(nbytes / (lin * 1e-3) / 1e9, 1),
                 "row_lockstep_gbs": round(nbytes / (grp * 1e-3) / 1e9, 1),
+                "row_lockstep_xcd_contiguous_gbs": round(nbytes / (spr * 1e-3) / 1e9, 1) if spr > 0 else None,
                 "frac_of_best_store_only": round(achieved / (nbytes / (best_ms * 1e-3) / 1e9), 4),
             }
         # fused analysis -> synthesis (sdft_hip_process_n): same input, no matrix traffic; VALU-bound, so

@@ -245,20 +245,36 @@ __global__ __launch_bounds__(kBlock) void store_tiled_kernel(v2f64* dst, size_t 
 }
 
 // pattern 2: one workgroup of row_slots/64 waves per time chunk; the waves write one whole row
-// per step and meet at a barrier every `sync_every` rows (the shape of a row-lockstep kernel)
-template <bool NT>
+// per step and meet at a barrier every `sync_every` rows (the shape of a row-lockstep kernel).
+// Round 5, the store-ceiling study (pattern bits on top of 2): MAP -- which chunk a workgroup takes: 0 = its own number
+// (consecutive workgroups -> consecutive 32 MB regions; the dispatcher deals consecutive workgroups to different XCDs), 1 = every
+// XCD a contiguous eighth of the matrix (chunk = (b % 8) * chunks / 8 + b / 8); STAGGER -- a workgroup starts `(b * 37) % 64`
+// rows into its chunk and wraps around (workgroups in step no longer write the same row phase -- the same address bits above
+// the row size -- at the same time).
+template <bool NT, int MAP, bool STAGGER>
 __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t rows, unsigned row_slots, unsigned chunk_len,
-                                                              unsigned sync_every)
+                                                              unsigned sync_every, unsigned regions)
 {
-  const size_t t0 = (size_t)blockIdx.x * chunk_len;
-  const size_t t1 = t0 + chunk_len < rows ? t0 + chunk_len : rows;
-  v2f64 v; v.x = (double)threadIdx.x; v.y = 2.0;
-  v2f64* p = dst + t0 * row_slots + threadIdx.x;
-  unsigned since = 0;
-  for (size_t t = t0; t < t1; ++t)
+  unsigned chunk = blockIdx.x;
+  if constexpr (MAP == 1)
   {
+    // workgroup b is the (b / R)-th chunk of region b % R (R = 8: every XCD a contiguous eighth); a bijection for any grid
+    const unsigned R = regions, q = gridDim.x / R, r = gridDim.x % R, x = blockIdx.x % R;
+    chunk = x * q + (x < r ? x : r) + blockIdx.x / R;
+  }
+  const size_t t0 = (size_t)chunk * chunk_len;
+  const size_t t1 = t0 + chunk_len < rows ? t0 + chunk_len : rows;
+  if (t0 >= t1) return;
+  v2f64 v; v.x = (double)threadIdx.x; v.y = 2.0;
+  const size_t len = t1 - t0;
+  size_t off = STAGGER ? ((size_t)blockIdx.x * 37u) % 64u % len : 0;
+  unsigned since = 0;
+  for (size_t i = 0; i < len; ++i)
+  {
+    v2f64* p = dst + (t0 + off) * row_slots + threadIdx.x;
     if (threadIdx.x < row_slots) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
-    p += row_slots; v.x += 1.0;
+    v.x += 1.0;
+    if (++off == len) off = 0;
     if (sync_every && ++since == sync_every) { __syncthreads(); since = 0; }
   }
 }
@@ -324,16 +340,17 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
   auto launch = [&]() {
     if (pattern == 0)
       hipLaunchKernelGGL(store_linear_kernel, dim3(256 * 8), dim3(kBlock), 0, 0, (v2f64*)dst, slots);
-    else if (pattern == 2 || pattern == 3)                   // 3: the same with non-temporal stores
+    else if ((pattern >= 2 && pattern <= 6) || pattern >= 100)   // 3: non-temporal stores; 4: XCD-contiguous chunks; 5: staggered row phase; 6: both; 100 + R: R regions
     {
       const size_t rows = slots / row_slots;
       const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
-      if (pattern == 2)
-        hipLaunchKernelGGL(store_rowgroup_kernel<false>, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (v2f64*)dst, rows,
-                           row_slots, chunk_len, lanes /* = sync_every */);
-      else
-        hipLaunchKernelGGL(store_rowgroup_kernel<true>, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (v2f64*)dst, rows,
-                           row_slots, chunk_len, lanes /* = sync_every */);
+      const dim3 b(((row_slots + 63) / 64) * 64), g(chunks);
+      const unsigned sync_every = lanes, regions = pattern >= 100 ? (unsigned)(pattern - 100) : 8u;
+      if (pattern == 2) hipLaunchKernelGGL((store_rowgroup_kernel<false, 0, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
+      else if (pattern == 3) hipLaunchKernelGGL((store_rowgroup_kernel<true, 0, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
+      else if (pattern == 5) hipLaunchKernelGGL((store_rowgroup_kernel<false, 0, true>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
+      else if (pattern == 6) hipLaunchKernelGGL((store_rowgroup_kernel<false, 1, true>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
+      else hipLaunchKernelGGL((store_rowgroup_kernel<false, 1, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
     }
     else
     {

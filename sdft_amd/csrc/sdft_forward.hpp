@@ -108,7 +108,18 @@ template <typename FD> struct ForwardArgs
   unsigned ready_seq, ready_n, ready_channels;
   unsigned* ready_status;     // pinned host word: a workgroup whose wait ran out adds 1 (the host re-runs the call)
   unsigned ready_status_seen; // its value when the call was launched: once it differs (a relay gave up) nobody waits on
+  // Which (channel, chunk) a workgroup takes.  The dispatcher deals consecutive workgroups to different XCDs (b and b + 8 share
+  // one); with xcd_map every XCD takes a CONTIGUOUS eighth of the launch's (channel, chunk) sequence -- of the matrix -- instead
+  // of every eighth region: the store stream of the headline workload runs 4-9 % faster that way (store-only probes,
+  // profiles/r05_store_ceiling_study.txt).  Placement is for speed only: any block-to-XCD assignment gives the same results.
+  unsigned xcd_map;           // 0, or the launch's number of (channel, chunk) workgroups
 };
+// the b-th workgroup's position in the launch's (channel, chunk) sequence: a bijection of [0, total) for any total
+SDFT_D unsigned xcd_contiguous(unsigned b, unsigned total)
+{
+  const unsigned q = total >> 3, r = total & 7u, x = b & 7u;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
 
 // Flow mode: which (chunk, channel) a workgroup takes, and the wait for the chunk's carries.  The relay kernel stores
 // carries write-through (sc1), waits for them, then stores the flag (sc1); here: relaxed agent-scope polls of the flags,
@@ -116,7 +127,11 @@ template <typename FD> struct ForwardArgs
 template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch, unsigned block)
 {
   if (a.ready) { chunk = a.chunk0 + block / a.ready_channels; ch = block % a.ready_channels; }
-  else { chunk = a.chunk0 + block % a.launch_chunks; ch = block / a.launch_chunks; }
+  else
+  {
+    if (a.xcd_map) block = xcd_contiguous(block, a.xcd_map);
+    chunk = a.chunk0 + block % a.launch_chunks; ch = block / a.launch_chunks;
+  }
 }
 template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch) { flow_position(a, chunk, ch, blockIdx.x); }
 constexpr unsigned kFlowPollCap = 1u << 19;                // x (sleep + barrier): about half a second

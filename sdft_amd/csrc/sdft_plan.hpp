@@ -132,6 +132,7 @@ class Plan
   size_t stage_bytes = kDefaultStageBytes;   // host-pointer path: staging segment size
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
   long opt_rows_kernel = 1;      // use the row-group forward kernel when the row fits one workgroup
+  long opt_xcd_map = 1;          // every XCD takes a contiguous eighth of a launch's (channel, chunk) workgroups (ForwardArgs::xcd_map)
   long opt_pinned_io = 1;        // small host sample buffers travel through a pinned scratch the kernels access directly
   long opt_pointers = 0;         // 0 = ask the runtime on every call (hipPointerGetAttributes, ~0.1 us), 1 = all device, 2 = all host
   long opt_inverse_rows = 0;     // rows per wave of the exact inverse (0 = heuristic; 4, 8, 16, 32)
@@ -142,6 +143,9 @@ class Plan
   // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
   // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
   long opt_inverse_nt = -1;
+  // (measured both ways by matrix, scripts/inverse_spread_ab.py: 64 x 48000 x 1024 +6 %, 262144 x 1024 f64f64 +4 %, but 1e6 x 1024
+  // -5.5 %, 600000 x 1024 -5 % -- profiles/r05_store_ceiling_study.txt; off)
+  long opt_inverse_spread = 0;   // InverseArgs::spread
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
@@ -808,6 +812,7 @@ class Plan
     {
       const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
       fa.chunk0 = (unsigned)j0; fa.launch_chunks = (unsigned)(j1 - j0);
+      fa.xcd_map = (opt_xcd_map && !flow && channels * (size_t)(j1 - j0) >= 16) ? (unsigned)(channels * (size_t)(j1 - j0)) : 0u;
       fa.total_waves = (unsigned long long)channels * (unsigned long long)(j1 - j0) * (unsigned long long)ntiles;
       if (segments > 1) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[sg], 0));      // (flow mode: the kernel waits chunk by chunk)
       const unsigned long long blocks = (fa.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1044,6 +1049,7 @@ class Plan
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)tiles();
     fa.interior_lanes = (unsigned)interior_lanes(); fa.cursor0 = (unsigned)cursor; fa.chunk_shift = 0;
     fa.chunk0 = 0; fa.launch_chunks = (unsigned)chunks;
+    fa.xcd_map = (opt_xcd_map && channels * (size_t)chunks >= 16) ? (unsigned)(channels * (size_t)chunks) : 0u;
     fa.vec_store = 0;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
@@ -1123,66 +1129,7 @@ class Plan
     cursor = (cursor + n) % span;
     return true;
   }
-  template <int WIN, bool FUSED, int S>
-  bool launch_forward_rows_self_ws(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads)
-  {
-    auto kern = forward_rows_kernel<FD, 1, WIN, FUSED, S, 0, true, TD, true>;
-    const size_t lds = self_cells() * sizeof(fdx);
-    static thread_local int raised_on = -1;                  // static + dynamic LDS beyond 64 KiB has to be asked for (per device)
-    if (raised_on != device)
-    {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
-      raised_on = device;
-    }
-    const FuseArgs<TD, FD> none{};
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, fa, none, sa);
-    SDFT_TRY(hipGetLastError());
-    return true;
-  }
-  template <bool FUSED>
-  bool launch_forward_rows_self_t(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads)
-  {
-    const bool two = row_slots() != 1;
-    switch (window)
-    {
-      case WIN_HANN:     return two ? launch_forward_rows_self_ws<WIN_HANN, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_HANN, FUSED, 1>(fa, sa, blocks, threads);
-      case WIN_HAMMING:  return two ? launch_forward_rows_self_ws<WIN_HAMMING, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_HAMMING, FUSED, 1>(fa, sa, blocks, threads);
-      case WIN_BLACKMAN: return two ? launch_forward_rows_self_ws<WIN_BLACKMAN, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_BLACKMAN, FUSED, 1>(fa, sa, blocks, threads);
-      default:           return two ? launch_forward_rows_self_ws<WIN_BOXCAR, FUSED, 2>(fa, sa, blocks, threads) : launch_forward_rows_self_ws<WIN_BOXCAR, FUSED, 1>(fa, sa, blocks, threads);
-    }
-  }
-  bool launch_forward_rows_self(const ForwardArgs<FD>& fa, const SelfArgs<TD, FD>& sa, unsigned blocks, unsigned threads, bool fused)
-  {
-    return fused ? launch_forward_rows_self_t<true>(fa, sa, blocks, threads) : launch_forward_rows_self_t<false>(fa, sa, blocks, threads);
-  }
-
   // ---- single-chunk calls (hop-wise streaming): one fused launch, tiles spread over the CUs ----
-  template <bool ROWS, int WPB> void launch_hop_t(const HopArgs<TD, FD>& ha, unsigned blocks)
-  {
-    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    const dim3 g(blocks), b(kWave * WPB);
-    switch (window)
-    {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_HANN, ROWS, WPB>), g, b, 0, stream, ha); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_HAMMING, ROWS, WPB>), g, b, 0, stream, ha); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_BLACKMAN, ROWS, WPB>), g, b, 0, stream, ha); break;
-      default:           hipLaunchKernelGGL((forward_hop_kernel<TD, FD, BPL, WIN_BOXCAR, ROWS, WPB>), g, b, 0, stream, ha); break;
-    }
-  }
-
-  template <bool ROWS> void launch_hop2_t(const HopArgs<TD, FD>& ha, unsigned blocks)
-  {
-    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    const dim3 g(blocks), b(2 * kWave);
-    switch (window)
-    {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_HANN, ROWS>), g, b, 0, stream, ha); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_HAMMING, ROWS>), g, b, 0, stream, ha); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_BLACKMAN, ROWS>), g, b, 0, stream, ha); break;
-      default:           hipLaunchKernelGGL((forward_hop2_kernel<TD, FD, BPL, WIN_BOXCAR, ROWS>), g, b, 0, stream, ha); break;
-    }
-  }
-
   bool forward_hop(size_t n, const TD* x, size_t x_stride, fdx* out, size_t out_stride, fdx* const* rows)
   {
     const size_t nb = nbins, span = 2 * nbins;
@@ -1325,143 +1272,6 @@ class Plan
     return true;
   }
 
-  template <bool FUSED, int S> void launch_forward_rows_ts(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
-  {
-    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    const dim3 g(blocks), b(threads);
-    const FuseArgs<TD, FD> none{};
-    const SelfArgs<TD, FD> noself{};
-    switch (window)
-    {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HANN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_HAMMING, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BLACKMAN, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
-      default:           hipLaunchKernelGGL((forward_rows_kernel<FD, BPL, WIN_BOXCAR, FUSED, S, 0, true, TD>), g, b, 0, stream, fa, none, noself); break;
-    }
-  }
-  template <bool FUSED> void launch_forward_rows_t(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads)
-  {
-    switch (row_slots())
-    {
-      case 1:  launch_forward_rows_ts<FUSED, 1>(fa, blocks, threads); break;
-      default: launch_forward_rows_ts<FUSED, 2>(fa, blocks, threads); break;
-    }
-  }
-  // FD float, rows of a multiple of 128 bins, dense aligned output: the bin-pair kernel (sdft_forward_rows_f32.hpp)
-  long opt_rows_f32 = 1;
-  long last_rows_f32 = 0;
-  // (samples per lockstep group: 4; 2 measured slower -- 25.5 against 27.9 GB/s per CU, profiles/r04_kernels_beside_held_cus.txt)
-  template <int S, bool SPLIT> void launch_forward_rows_f32_s(const ForwardArgs<float>& fa, unsigned blocks, unsigned threads, size_t lds)
-  {
-    const dim3 g(blocks), b(threads);
-    constexpr int G = 4;
-    switch (window)
-    {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HANN, S, G, SPLIT>), g, b, lds, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_HAMMING, S, G, SPLIT>), g, b, lds, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BLACKMAN, S, G, SPLIT>), g, b, lds, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_rows_f32_kernel<WIN_BOXCAR, S, G, SPLIT>), g, b, lds, stream, fa); break;
-    }
-  }
-  // Rows of two slots (2048 < N <= 4096 at FD float) as two one-slot workgroups per row, each computing the one bin pair it
-  // needs of the other half itself (sdft_forward_rows_f32.hpp, SPLIT): 64 registers instead of 96-128, two workgroups to a CU
-  long opt_rows_split = 0, last_rows_split = 0;
-  void launch_forward_rows(const ForwardArgs<FD>& fa, unsigned blocks, unsigned threads, bool fused)
-  {
-    last_rows_f32 = 0; last_rows_split = 0;
-    if constexpr (sizeof(FD) == 4)
-    {
-      if (opt_rows_f32 && nbins % (2 * kWave) == 0 && fa.vec_store && !fa.out_rows)
-      {
-        last_rows_f32 = 1;
-        if (row_slots() == 1) launch_forward_rows_f32_s<1, false>(fa, blocks, threads, 0);
-        else if (opt_rows_split && nbins % (4 * kWave) == 0 && blocks < 0x40000000u && fa.chunk_len <= 3064u)   // (48 KiB of halo image at most)
-        {
-          // (each half: nbins / 2 bins = nbins / 256 waves of 128 bins; the halo image: one quad per sample of a chunk)
-          ForwardArgs<float> fh = fa;
-          if (fh.done.flag) fh.done.total *= 2;            // every half reports
-          last_rows_split = 1;
-          launch_forward_rows_f32_s<1, true>(fh, 2 * blocks, (unsigned)(nbins / (4 * kWave)) * kWave, ((size_t)fa.chunk_len + 8) * 16);
-        }
-        else launch_forward_rows_f32_s<2, false>(fa, blocks, threads, 0);
-        return;
-      }
-    }
-    if constexpr (sizeof(FD) == 8) { if (fused) { launch_forward_rows_t<true>(fa, blocks, threads); return; } }
-    launch_forward_rows_t<false>(fa, blocks, threads);
-  }
-
-  // fused analysis -> operation -> synthesis: the same kernel with SYN = 1 (tree sum over bins) or 2
-  // (the reference's ascending order); the terms image lives in dynamic LDS
-  size_t syn_lds(int syn) const
-  {
-    const size_t group = (size_t)syn_group((int)row_slots(), (int)bins_per_lane(), syn);   // samples per lockstep group (the kernel's G)
-    const size_t padded = (size_t)row_waves() * (size_t)row_slots() * kWave * bins_per_lane();
-    return (size_t)2 * group * (padded + 16 / sizeof(FD)) * sizeof(FD);          // double-buffered
-  }
-  template <int WIN, bool FUSED, int SYN, bool LAT1>
-  bool launch_syn_w(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
-  {
-    return row_slots() == 1 ? launch_syn_ws<WIN, FUSED, SYN, LAT1, 1>(fa, fz, blocks, threads)
-                            : launch_syn_ws<WIN, FUSED, SYN, LAT1, 2>(fa, fz, blocks, threads);
-  }
-  template <int WIN, bool FUSED, int SYN, bool LAT1, int S>
-  bool launch_syn_ws(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
-  {
-    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    auto kern = forward_rows_kernel<FD, BPL, WIN, FUSED, S, SYN, LAT1, TD>;
-    static thread_local int raised_on = -1;                  // dynamic LDS beyond 64 KiB has to be asked for (per device)
-    if (raised_on != device)
-    {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)));
-      raised_on = device;
-    }
-    if (fz.op.kind == OP_USER)
-    {
-      // the host's own operation: this instantiation, compiled at run time with its statements (sdft_common.hip)
-      char name[256];
-      snprintf(name, sizeof(name), "sdfthip::forward_rows_kernel<%s, %d, %d, %s, %d, %d, %s, %s, false>", type_name<FD>(), BPL, WIN,
-               FUSED ? "true" : "false", S, SYN, LAT1 ? "true" : "false", type_name<TD>());
-      hipFunction_t fn = nullptr;
-      if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
-      if (syn_lds(SYN) > (size_t)64 * 1024)
-      {
-        // a module function is not a host-side kernel symbol: hipFuncSetAttribute may refuse the handle (the launch below
-        // then says so itself if the image does not fit); hipModule functions take what the launch asks for on this runtime
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(140 * 1024)) != hipSuccess)
-          (void)hipGetLastError();
-      }
-      ForwardArgs<FD> a1 = fa; FuseArgs<TD, FD> f1 = fz; SelfArgs<TD, FD> s1{};
-      void* args[] = {&a1, &f1, &s1};
-      SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, threads, 1, 1, (unsigned)syn_lds(SYN), stream, args, nullptr));
-      return true;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), syn_lds(SYN), stream, fa, fz, SelfArgs<TD, FD>{});
-    SDFT_TRY(hipGetLastError());
-    return true;
-  }
-  template <bool FUSED, int SYN, bool LAT1>
-  bool launch_syn_t(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads)
-  {
-    switch (window)
-    {
-      case WIN_HANN:     return launch_syn_w<WIN_HANN, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
-      case WIN_HAMMING:  return launch_syn_w<WIN_HAMMING, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
-      case WIN_BLACKMAN: return launch_syn_w<WIN_BLACKMAN, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
-      default:           return launch_syn_w<WIN_BOXCAR, FUSED, SYN, LAT1>(fa, fz, blocks, threads);
-    }
-  }
-  bool launch_syn(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, unsigned threads, bool fused, bool exact_order)
-  {
-    const bool lat1 = (latency == 1);                                           // :639 exact compare
-    if (exact_order) return lat1 ? launch_syn_t<false, 2, true>(fa, fz, blocks, threads) : launch_syn_t<false, 2, false>(fa, fz, blocks, threads);
-    if constexpr (sizeof(FD) == 8)
-    {
-      if (fused) return lat1 ? launch_syn_t<true, 1, true>(fa, fz, blocks, threads) : launch_syn_t<true, 1, false>(fa, fz, blocks, threads);
-    }
-    return lat1 ? launch_syn_t<false, 1, true>(fa, fz, blocks, threads) : launch_syn_t<false, 1, false>(fa, fz, blocks, threads);
-  }
-
   // folded form of the fused call (process_rows_kernel): per-bin coefficients from the plan's window and
   // synthesis tables and the call's operation, then one launch per overlap segment
   DevBuf<double> d_alpha, d_beta;
@@ -1493,182 +1303,10 @@ class Plan
     coeff_ready = true;
     return true;
   }
-  static size_t process_tiles_bytes(unsigned threads) { return (size_t)(threads / kWave) * kProcGroup * kProcRow * sizeof(double); }
-  template <int J, bool FUSED, bool HASB>
-  bool launch_process_j(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, const SelfArgs<TD, FD>* self)
-  {
-    const size_t tiles = process_tiles_bytes(threads);
-    if (self)
-    {
-      if constexpr (sizeof(FD) == 8 && J <= 2)
-      {
-        // the chunk's differences in LDS beside the transpose tiles (at most 4 KiB: several workgroups share a CU)
-        SelfArgs<TD, FD> sa = *self;
-        sa.lds_deltas = fa.chunk_len <= 512 ? fa.chunk_len : 0u;
-        auto kern = process_rows_kernel<TD, FD, J, FUSED, HASB, true>;
-        static thread_local int raised_on = -1;              // dynamic LDS beyond 48 KiB has to be asked for (per device)
-        if (raised_on != device)
-        {
-          SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
-          raised_on = device;
-        }
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), tiles + sa.lds_deltas * sizeof(FD), stream, fa, pz, sa);
-        return true;
-      }
-      set_error("sdft_hip_process_n", "internal: the self-carried form has one or two bins per lane");
-      return false;
-    }
-    auto kern = process_rows_kernel<TD, FD, J, FUSED, HASB>;
-    static thread_local int raised_on = -1;
-    if (raised_on != device)
-    {
-      SDFT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
-      raised_on = device;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), tiles, stream, fa, pz, SelfArgs<TD, FD>{});
-    return true;
-  }
-  template <bool FUSED, bool HASB>
-  bool launch_process_t(const ForwardArgs<FD>& fa, const ProcArgs<TD, FD>& pz, unsigned blocks, unsigned threads, long slots, const SelfArgs<TD, FD>* self)
-  {
-    if (slots <= 1) return launch_process_j<1, FUSED, HASB>(fa, pz, blocks, threads, self);
-    if (slots == 2) return launch_process_j<2, FUSED, HASB>(fa, pz, blocks, threads, self);
-    return launch_process_j<4, FUSED, HASB>(fa, pz, blocks, threads, self);
-  }
-  // waves of a fused-kernel workgroup and bins per lane (1, 2, 4).  FD double in the chunk-parallel path: two bins per lane
-  // from 256 bins on -- the sum over bins (a transpose through LDS per wave and 8 samples) is paid per wave, the recurrence
-  // per bin: n = 1e6, N = 1024: 0.485 -> 0.397 ms with 8 waves of 2 bins instead of 16 of 1
-  // (four bins per lane where the call is long enough to fill the chip with such workgroups: 64 channels x 48000: 1.29 ->
-  // 1.13 ms, n = 1e6: 0.397 -> 0.388 ms; n = 48000 alone: 0.038 -> 0.045 ms, so not there)
-  void process_geometry(bool fused, long& waves, long& slots, size_t n = 0) const
-  {
-    const logic::ProcessGeometry g = logic::process_geometry(nbins, channels, n, fused, sizeof(FD), opt_proc_slots);
-    waves = g.waves; slots = g.slots;
-  }
-  bool launch_process(const ForwardArgs<FD>& fa, const FuseArgs<TD, FD>& fz, unsigned blocks, bool fused, const SelfArgs<TD, FD>* self = nullptr)
-  {
-    ProcArgs<TD, FD> pz;
-    pz.y = fz.y; pz.y_stride = fz.y_stride; pz.alpha = d_alpha.p; pz.beta = d_beta.p; pz.sweight = fz.sweight;
-    pz.rows = coeff_rows; pz.hop = fz.op.hop;
-    long waves, slots;
-    process_geometry(fused, waves, slots, fa.n);
-    const unsigned threads = (unsigned)(waves * kWave);
-    const bool hasb = coeff_has_beta;
-    bool ok;
-    if constexpr (sizeof(FD) == 8)
-    {
-      if (fused)
-      {
-        ok = hasb ? launch_process_t<true, true>(fa, pz, blocks, threads, slots, self) : launch_process_t<true, false>(fa, pz, blocks, threads, slots, self);
-        SDFT_TRY(hipGetLastError());
-        return ok;
-      }
-    }
-    ok = hasb ? launch_process_t<false, true>(fa, pz, blocks, threads, slots, self) : launch_process_t<false, false>(fa, pz, blocks, threads, slots, self);
-    SDFT_TRY(hipGetLastError());
-    return ok;
-  }
-
-  template <bool ROWS> void launch_forward_t(const ForwardArgs<FD>& fa, unsigned blocks)
-  {
-    constexpr int BPL = sizeof(fdx) == 16 ? 1 : 2;
-    const dim3 g(blocks), b(kBlock);
-    switch (window)
-    {
-      case WIN_HANN:     hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_HANN, ROWS>), g, b, 0, stream, fa); break;
-      case WIN_HAMMING:  hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_HAMMING, ROWS>), g, b, 0, stream, fa); break;
-      case WIN_BLACKMAN: hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_BLACKMAN, ROWS>), g, b, 0, stream, fa); break;
-      default:           hipLaunchKernelGGL((forward_kernel<FD, BPL, WIN_BOXCAR, ROWS>), g, b, 0, stream, fa); break;
-    }
-  }
-  void launch_forward(const ForwardArgs<FD>& fa, unsigned blocks)
-  {
-    if (fa.out_rows) launch_forward_t<true>(fa, blocks); else launch_forward_t<false>(fa, blocks);
-  }
+  // ---- the kernel launches: run-time values -> template instantiations -------------------------------------------------
+#include "sdft_plan_launch.inc"
 
   // ---- inverse on device-resident buffers --------------------------------------------------
-  template <bool LAT1, bool OPS> void launch_inverse(const InverseArgs<TD, FD>& ia, size_t total_rows)
-  {
-    size_t blocks = (total_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    blocks = std::min(blocks, (size_t)256 * 8 * 4);
-    flag_pending = false;                                    // only the row form below signals its completion
-    if (!opt_exact_inverse)
-    {
-      hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
-      last_inverse_form = 0;
-      return;
-    }
-    // the reference's summation order.  Measured (n=1e6, N=1024, f64): 32 rows per wave 2.75 ms, 16:
-    // 2.82, 64: 3.6 (130 VGPRs); float bins and medium calls do best with 16; below 64 Ki rows a wave
-    // with 16 rows and one tile of look-ahead is a chain of N/16 memory round trips (~70 us whatever
-    // n is): 4 rows with an 8-deep ring (n = 12000: 33 us against 79, n = 48000: 153 against 178,
-    // n = 131072: 397 against 355); short calls (a hop of 100 rows): one wave per row
-    // float samples from double bins, medium calls: the tree-sum kernel with the rounding-interval test gives the same bits
-    // without the chain of dependent additions (n = 4096: 22.5 -> 11.8 us, 48000: 145 -> 132 us, 200000: 585 -> 550 us;
-    // from about half a million rows on the streaming kernel below is the faster one: 2.64 against 2.78 ms at n = 1e6)
-    if constexpr (sizeof(TD) == 4 && sizeof(FD) == 8)
-    {
-      if (opt_inverse_verify && opt_inverse_rows <= 0 && total_rows > 1024 && total_rows <= (size_t)opt_inverse_verify_max)
-      {
-        hipLaunchKernelGGL((inverse_kernel<TD, FD, LAT1, OPS, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, ia);
-        last_inverse_form = 2;
-        return;
-      }
-    }
-    last_inverse_form = 1;
-    // (rows per wave: logic::inverse_rows_per_wave; the capacities of the 4-row and the 8-row form come from the occupancy API)
-    if constexpr (!OPS)
-    {
-      if (opt_inverse_rows <= 0 && inverse_capacity[0] == 0 && total_rows > 1024 && total_rows < 65536)
-      {
-        int dev_cus = 0, b4 = 0, b8 = 0;
-        if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>, kBlock, 0) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>, kBlock, 0) == hipSuccess)
-        {
-          inverse_capacity[0] = (size_t)std::max(1, b4) * dev_cus * kWavesPerBlock;
-          inverse_capacity[1] = (size_t)std::max(1, b8) * dev_cus * kWavesPerBlock;
-        }
-        else { (void)hipGetLastError(); inverse_capacity[0] = inverse_capacity[1] = (size_t)-1; }
-      }
-    }
-    const long rw = logic::inverse_rows_per_wave(total_rows, sizeof(FD), opt_inverse_rows, inverse_capacity[0], inverse_capacity[1], OPS);
-    size_t eb = ((total_rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
-    eb = std::max<size_t>(1, std::min(eb, (size_t)256 * 32));
-    const dim3 g((unsigned)eb), b(kBlock);
-    if (rw == 1 && total_rows <= 0x7fffffffull)
-    {
-      InverseArgs<TD, FD> ir = ia;
-      ir.done = arm_flag((unsigned)total_rows);
-      if (OPS && ia.op.kind == OP_USER)
-      {
-        // the host's own statements inside the row synthesis of a hop: this instantiation, compiled at run time
-        char name[160];
-        snprintf(name, sizeof(name), "sdfthip::inverse_row_kernel<%s, %s, %s, true>", type_name<TD>(), type_name<FD>(), LAT1 ? "true" : "false");
-        hipFunction_t fn = nullptr;
-        if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) { rtc_failed = true; return; }
-        void* args[] = {&ir};
-        if (hipModuleLaunchKernel(fn, (unsigned)total_rows, 1, 1, kWave, 1, 1, 0, stream, args, nullptr) != hipSuccess) rtc_failed = true;
-        return;
-      }
-      hipLaunchKernelGGL((inverse_row_kernel<TD, FD, LAT1, OPS>), dim3((unsigned)total_rows), dim3(kWave), 0, stream, ir);
-    }
-    else if (rw >= 32)
-    {
-      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 32, 1, false>), g, b, 0, stream, ia);
-    }
-    // (16 rows x 4 tiles in flight was measured in round 4 and lost to 4 x 8 below 64 Ki rows and to 16 x 1 above: scripts/inverse_ab.py)
-    else if (rw >= 16) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 16, 1, OPS>), g, b, 0, stream, ia);
-    else if (rw >= 8)
-    {
-      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 8, 4, false>), g, b, 0, stream, ia);
-    }
-    else
-    {
-      if constexpr (!OPS) hipLaunchKernelGGL((inverse_exact_kernel<TD, FD, LAT1, 4, 8, false>), g, b, 0, stream, ia);
-    }
-  }
-
   bool inverse_device(size_t n, const fdx* in, size_t in_stride, const fdx* const* rows, TD* y, size_t y_stride,
                       const SpectralOp<FD>* op = nullptr)
   {
@@ -1708,6 +1346,7 @@ class Plan
     {
       const size_t matrix_bytes = channels * n * nbins * sizeof(fdx);
       ia.nt = opt_inverse_nt >= 0 ? (int)(opt_inverse_nt != 0) : (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30));
+      ia.spread = (int)(opt_inverse_spread != 0);
     }
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;
@@ -1903,594 +1542,9 @@ class Plan
     return true;
   }
 
-  // ---- public entry points: dense matrices, host or device pointers ---------------------------
-  // x: [channels][n], dfts: [channels][n][N]
-  // x_class: -1 = classify x, 0 = x is host memory whatever option "pointers" says (by-value sample)
-  bool sdft_n(size_t n, const TD* x, fdx* dfts, int x_class = -1)
-  {
-    if (n == 0 || nbins == 0) return true;
-    if (!bind()) return false;
-    const bool xd = x_class < 0 ? on_device(x) : x_class != 0;
-    const bool od = on_device(dfts);
-    if (xd && od)
-    {
-      flag_wanted = true;                                    // a call of one time chunk may signal its own completion
-      pipe_allowed = true;
-      const bool ok = forward_device(n, x, n, dfts, n * nbins, nullptr);
-      flag_wanted = false; pipe_allowed = false;
-      return ok && finish(matrix_bytes(n));
-    }
-
-    // small host samples, device matrix (hop-wise streaming from a host signal, sdft_sdft on a device row): through the
-    // pinned scratch, completion by the kernel's word -- the call is complete on return like every host-pointer call
-    if (!xd && od && channels * n * sizeof(TD) <= kIoBytes && opt_pinned_io && ensure_io())
-    {
-      memcpy(h_io, x, channels * n * sizeof(TD));
-      const bool saved = async; async = false;
-      flag_wanted = true;
-      const bool ok = forward_device(n, d_io, n, dfts, n * nbins, nullptr);
-      flag_wanted = false;
-      const bool done = ok && finish(matrix_bytes(n));
-      async = saved;
-      return done;
-    }
-    // host buffers mapped in place (see map_host): the kernels work on the caller's memory
-    {
-      // (a hop's samples are a different slice of the host's signal every call: a few hundred bytes go through the
-      // staging buffer, only buffers beyond 64 KiB are worth a registration)
-      const bool small_x = channels * n * sizeof(TD) <= kSmallHostBytes;
-      fdx* om = od ? dfts : static_cast<fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx), true));
-      const TD* xm = xd ? x : ((x_class == 0 || small_x) ? nullptr : static_cast<const TD*>(map_host(x, channels * n * sizeof(TD))));
-      if (om && !xm && !xd && small_x)
-      {
-        if (!d_stage_td.reserve(channels * n)) return false;
-        if (!to_device(d_stage_td.p, x, channels * n * sizeof(TD))) return false;
-        xm = d_stage_td.p;
-      }
-      if (xm && om)
-      {
-        const bool ok = forward_device(n, xm, n, om, n * nbins, nullptr);
-        return ok && finish_mapped(matrix_bytes(n));   // host memory: complete on return, through the stream
-      }
-    }
-    // a hop-sized matrix for host memory (the reference driver's 100 x 1000 bins = 1.6 MB, test/test.c:62-83): the kernels
-    // write it into the plan's pinned pieces over PCIe -- no staging matrix, no DMA launch -- and the host copies it out
-    // (scripts/host_hop_paths.py, profiles/r04_host_copy_paths.txt)
-    {
-      const size_t obytes = channels * n * nbins * sizeof(fdx), xbytes = channels * n * sizeof(TD);
-      if (!od && io.opt_host_copy == 0 && io.opt_host_direct && obytes <= HostIo::kDirectBytes && (xd || xbytes <= kSmallHostBytes) && io.ensure_pin())
-      {
-        if (!io.pin_idle()) return copy_failed();
-        const TD* xm = x;
-        if (!xd)
-        {
-          if (xbytes <= kIoBytes && opt_pinned_io && ensure_io()) { memcpy(h_io, x, xbytes); xm = d_io; }
-          else
-          {
-            if (!d_stage_td.reserve(channels * n)) return false;
-            if (!to_device(d_stage_td.p, x, xbytes)) return false;
-            xm = d_stage_td.p;
-          }
-        }
-        ++io.pin_copies;
-        const double t0 = HostIo::now_us();
-        if (!forward_device(n, xm, n, reinterpret_cast<fdx*>(io.d_pin), n * nbins, nullptr)) return false;
-        if (!finish_mapped(matrix_bytes(n))) return false;
-        const double t1 = HostIo::now_us();
-        io.copy_bytes(dfts, io.h_pin, obytes);
-        io.pin_us_device += t1 - t0; io.pin_us_memcpy += HostIo::now_us() - t1;
-        return true;
-      }
-    }
-    // staged path (host pointers): time segments so that the staging matrix stays bounded;
-    // the stream state carries over from segment to segment exactly like hop-wise calls do
-    const size_t row_bytes = channels * nbins * sizeof(fdx);
-    size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
-    seg = std::min(seg, n);
-    if (!xd && !d_stage_td.reserve(channels * seg)) return false;
-    if (!od && !d_stage_fdx.reserve(channels * seg * nbins)) return false;
-    for (size_t t = 0; t < n; t += seg)
-    {
-      const size_t m = std::min(seg, n - t);
-      const TD* xs; size_t xstride;
-      if (xd) { xs = x + t; xstride = n; }
-      else
-      {
-        if (!copy2d(d_stage_td.p, m * sizeof(TD), x + t, n * sizeof(TD), m * sizeof(TD), hipMemcpyHostToDevice)) return false;
-        xs = d_stage_td.p; xstride = m;
-      }
-      if (od)
-      {
-        if (!forward_device(m, xs, xstride, dfts + t * nbins, n * nbins, nullptr)) return false;
-      }
-      else
-      {
-        if (!forward_device(m, xs, xstride, d_stage_fdx.p, m * nbins, nullptr)) return false;
-        if (!copy2d(dfts + t * nbins, n * nbins * sizeof(fdx), d_stage_fdx.p, m * nbins * sizeof(fdx),
-                    m * nbins * sizeof(fdx), hipMemcpyDeviceToHost)) return false;
-      }
-      if (!xd || !od) SDFT_TRY(hipStreamSynchronize(stream));     // staging buffers are reused
-    }
-    return synchronize();
-  }
-
-  // array-of-row-pointers variant (sdft.h:622-628).  Single-channel plans only: the reference's
-  // table has one pointer per sample, a batched layout for it is not defined.
-  bool single_channel(const char* fn)
-  {
-    if (channels == 1) return true;
-    set_error(fn, "row-pointer variants take single-channel plans only (use sdft_sdft_n / sdft_isdft_n with a batched plan)");
-    return false;
-  }
-  bool sdft_nd(size_t n, const TD* x, fdx** dfts)
-  {
-    if (n == 0 || nbins == 0) return true;
-    if (!single_channel("sdft_sdft_nd")) return false;
-    if (!bind()) return false;
-    const bool table_on_device = is_device_pointer(dfts);
-    bool rows_on_device = false;
-    std::vector<fdx*> host_rows;
-    if (!table_on_device) { rows_on_device = is_device_pointer(dfts[0]); }
-    if (table_on_device || rows_on_device)
-    {
-      // rows live on the device: hand the pointer table to the kernel
-      fdx* const* table = dfts;
-      if (!table_on_device)
-      {
-        if (!d_rowptr.reserve(n)) return false;
-        if (!to_device(d_rowptr.p, dfts, n * sizeof(fdx*))) return false;
-        table = d_rowptr.p;
-      }
-      const TD* xs = x;
-      if (!is_device_pointer(x))
-      {
-        if (!d_stage_td.reserve(n)) return false;
-        if (!to_device(d_stage_td.p, x, n * sizeof(TD))) return false;
-        xs = d_stage_td.p;
-      }
-      return forward_device(n, xs, n, nullptr, 0, table) && synchronize();
-    }
-    // host rows: compute dense segments, scatter row by row
-    const size_t seg = std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(nbins * sizeof(fdx), 1)));
-    std::vector<fdx> host(seg * nbins);
-    for (size_t t = 0; t < n; t += seg)
-    {
-      const size_t m = std::min(seg, n - t);
-      const bool saved = async; async = false;
-      const bool ok = sdft_n(m, x + t, host.data());
-      async = saved;
-      if (!ok) return false;
-      for (size_t r = 0; r < m; ++r) memcpy(dfts[t + r], host.data() + r * nbins, nbins * sizeof(fdx));
-    }
-    return true;
-  }
-
-  // y_class: -1 = classify y, 0 = y is host memory whatever option "pointers" says (the by-value result of sdft_isdft)
-  bool isdft_n(size_t n, const fdx* dfts, TD* y, int y_class = -1)
-  {
-    if (n == 0) return true;
-    if (!bind()) return false;
-    const bool id = on_device(dfts);
-    const bool yd = y_class < 0 ? on_device(y) : y_class != 0;
-    if (nbins == 0)
-    {
-      // empty spectrum: the reference returns (td)(0 * 2)
-      if (yd) SDFT_TRY(hipMemsetAsync(y, 0, channels * n * sizeof(TD), stream)); else memset(y, 0, channels * n * sizeof(TD));
-      return finish();
-    }
-    if (id && yd)
-    {
-      flag_wanted = true;
-      pipe_allowed = true;
-      const bool ok = inverse_device(n, dfts, n * nbins, nullptr, y, n);
-      flag_wanted = false; pipe_allowed = false;
-      return ok && finish(matrix_bytes(n));
-    }
-    // device matrix, small host output: the kernel writes the samples into the pinned scratch
-    if (id && !yd && channels * n * sizeof(TD) <= kIoBytes && opt_pinned_io && ensure_io())
-    {
-      const bool saved = async; async = false;
-      flag_wanted = true;
-      const bool ok = inverse_device(n, dfts, n * nbins, nullptr, d_io, n);
-      flag_wanted = false;
-      const bool done = ok && finish(matrix_bytes(n));
-      async = saved;
-      if (done) memcpy(y, h_io, channels * n * sizeof(TD));
-      return done;
-    }
-    {
-      const bool small_y = channels * n * sizeof(TD) <= kSmallHostBytes;
-      const fdx* im = id ? dfts : static_cast<const fdx*>(map_host(dfts, channels * n * nbins * sizeof(fdx)));
-      TD* ym = yd ? y : (small_y ? nullptr : static_cast<TD*>(map_host(y, channels * n * sizeof(TD), true)));
-      if (im && !ym && !yd && small_y) { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; }
-      if (im && ym)
-      {
-        bool ok = inverse_device(n, im, n * nbins, nullptr, ym, n);
-        if (ok && ym == d_stage_td.p && !yd)
-        {
-          ok = to_host(y, ym, channels * n * sizeof(TD));
-        }
-        return ok && finish_mapped(matrix_bytes(n));
-      }
-    }
-    // a hop-sized matrix in host memory: copied into the plan's pinned pieces, which the kernel reads over PCIe
-    {
-      const size_t ibytes = channels * n * nbins * sizeof(fdx), ybytes = channels * n * sizeof(TD);
-      if (!id && io.opt_host_copy == 0 && io.opt_host_direct && ibytes <= HostIo::kDirectBytes && (yd || ybytes <= kSmallHostBytes) && io.ensure_pin())
-      {
-        if (!io.pin_idle()) return copy_failed();
-        const double t0 = HostIo::now_us();
-        io.copy_bytes(io.h_pin, dfts, ibytes);
-        const double t1 = HostIo::now_us();
-        io.pin_us_memcpy += t1 - t0;
-        ++io.pin_copies;
-        TD* ym = y;
-        const bool through_io = !yd && ybytes <= kIoBytes && opt_pinned_io && ensure_io();
-        if (!yd) { if (through_io) ym = d_io; else { if (!d_stage_td.reserve(channels * n)) return false; ym = d_stage_td.p; } }
-        if (!inverse_device(n, reinterpret_cast<const fdx*>(io.d_pin), n * nbins, nullptr, ym, n)) return false;
-        if (!yd && !through_io && !to_host(y, ym, ybytes)) return false;
-        if (!finish_mapped(matrix_bytes(n))) return false;
-        io.pin_us_device += HostIo::now_us() - t1;
-        if (through_io) memcpy(y, h_io, ybytes);
-        return true;
-      }
-    }
-    const size_t row_bytes = channels * nbins * sizeof(fdx);
-    size_t seg = std::max<size_t>(1, stage_bytes / std::max<size_t>(row_bytes, 1));
-    seg = std::min(seg, n);
-    if (!id && !d_stage_fdx.reserve(channels * seg * nbins)) return false;
-    if (!yd && !d_stage_td.reserve(channels * seg)) return false;
-    for (size_t t = 0; t < n; t += seg)
-    {
-      const size_t m = std::min(seg, n - t);
-      const fdx* in; size_t istride;
-      if (id) { in = dfts + t * nbins; istride = n * nbins; }
-      else
-      {
-        if (!copy2d(d_stage_fdx.p, m * nbins * sizeof(fdx), dfts + t * nbins, n * nbins * sizeof(fdx),
-                    m * nbins * sizeof(fdx), hipMemcpyHostToDevice)) return false;
-        in = d_stage_fdx.p; istride = m * nbins;
-      }
-      if (yd)
-      {
-        if (!inverse_device(m, in, istride, nullptr, y + t, n)) return false;
-      }
-      else
-      {
-        if (!inverse_device(m, in, istride, nullptr, d_stage_td.p, m)) return false;
-        if (!copy2d(y + t, n * sizeof(TD), d_stage_td.p, m * sizeof(TD), m * sizeof(TD), hipMemcpyDeviceToHost)) return false;
-      }
-      SDFT_TRY(hipStreamSynchronize(stream));
-    }
-    return synchronize();
-  }
-
-  bool isdft_nd(size_t n, const fdx** dfts, TD* y)
-  {
-    if (n == 0) return true;
-    if (!single_channel("sdft_isdft_nd")) return false;
-    if (!bind()) return false;
-    if (nbins == 0) return isdft_n(n, nullptr, y);
-    const bool table_on_device = is_device_pointer(dfts);
-    const bool rows_on_device = table_on_device || is_device_pointer(dfts[0]);
-    if (rows_on_device)
-    {
-      const fdx* const* table = dfts;
-      if (!table_on_device)
-      {
-        if (!d_rowptr.reserve(n)) return false;
-        if (!to_device(d_rowptr.p, dfts, n * sizeof(fdx*))) return false;
-        table = d_rowptr.p;
-      }
-      TD* yy = y;
-      const bool yd = is_device_pointer(y);
-      if (!yd) { if (!d_stage_td.reserve(n)) return false; yy = d_stage_td.p; }
-      if (!inverse_device(n, nullptr, 0, table, yy, n)) return false;
-      if (!yd && !to_host(y, yy, n * sizeof(TD))) return false;
-      return synchronize();
-    }
-    const size_t seg = std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(nbins * sizeof(fdx), 1)));
-    std::vector<fdx> host(seg * nbins);
-    for (size_t t = 0; t < n; t += seg)
-    {
-      const size_t m = std::min(seg, n - t);
-      for (size_t r = 0; r < m; ++r) memcpy(host.data() + r * nbins, dfts[t + r], nbins * sizeof(fdx));
-      const bool saved = async; async = false;
-      const bool ok = isdft_n(m, host.data(), y + t);
-      async = saved;
-      if (!ok) return false;
-    }
-    return true;
-  }
-
-  // single-sample synthesis (sdft.h:635): the result comes back by value, so a device-resident
-  // row needs a one-element device buffer (owned by the plan, allocated on the plan's device)
-  bool isdft_one(const fdx* dft, TD* y)
-  {
-    if (nbins == 0) { *y = (TD)0; return true; }           // the reference returns (td)(0 * 2)
-    if (!bind()) return false;
-    const bool saved = async; async = false;
-    const bool ok = isdft_n(1, dft, y, 0);                   // (a device row: through the pinned scratch, see isdft_n; y lives on the host stack)
-    async = saved;
-    return ok;
-  }
-
-  // ---- fused analysis -> spectral operation -> synthesis ------------------------
-  // y[t] = sdft_isdft( op( sdft_sdft(x[t]) ) ) with the reference's arithmetic, without the (n, N)
-  // matrix ever reaching HBM unless the caller asks for a copy of the processed spectrum in `dfts`.
-  // params: OP_GAIN -> FD gains[N], OP_CGAIN -> cx<FD> gains[N] (host or device memory), OP_SHIFT -> const long* (host).
-  DevBuf<FD> d_gain;
-  DevBuf<TD> d_stage_y;
-  bool fuse_ok() const { return rows_kernel_ok(false); }
-  // fused call: bins summed in the reference's order?  (-1: exactly when the host asked for exact carries at FD double)
-  bool wants_reference_order() const
-  {
-    return opt_fused_exact < 0 ? (carry_mode == CARRY_EXACT && sizeof(FD) == 8) : opt_fused_exact != 0;
-  }
-
-  bool process_n(size_t n, const TD* x, TD* y, int op_kind, const void* params, fdx* dfts)
-  {
-    if (n == 0) return true;
-    if (!bind()) return false;
-    // public operation numbers (enum sdft_hip_op): 0 identity, 1 gain, 2 shift, 3 cgain, 4 gain_rows, 5 cgain_rows, 6 gate, 7 power,
-    // 8 expression
-    const int op_public = op_kind;
-    if (op_public < 0 || op_public > 8) { set_error("sdft_hip_process_n", "unknown operation"); return false; }
-    if ((op_public != 0) && !params) { set_error("sdft_hip_process_n", "the operation needs parameters"); return false; }
-    op_kind = op_public == 4 ? OP_GAIN : op_public == 5 ? OP_CGAIN : op_public == 6 ? OP_GATE : op_public == 7 ? OP_POWER : op_public == 8 ? OP_USER : op_public;
-    if (op_kind == OP_SHIFT && dfts) { set_error("sdft_hip_process_n", "a copy of the spectrum is not available with the shift operation"); return false; }
-    const bool yd = on_device(y);
-    if (nbins == 0)
-    {
-      if (yd) SDFT_TRY(hipMemsetAsync(y, 0, channels * n * sizeof(TD), stream)); else memset(y, 0, channels * n * sizeof(TD));
-      return finish();
-    }
-    if (dfts && !on_device(dfts)) { set_error("sdft_hip_process_n", "dfts must be device memory (or NULL)"); return false; }
-    SpectralOp<FD> op{}; op.kind = op_kind; op.gain = nullptr; op.shift = 0; op.rows = 1; op.hop = 0; op.t0 = 0;
-    if (op_kind == OP_GAIN || op_kind == OP_CGAIN)
-    {
-      const FD* g = static_cast<const FD*>(params);
-      size_t rows = 1;
-      if (op_public >= 4)
-      {
-        // time-varying gains: { gains, rows, hop } (sdft_hip_gain_rows_t)
-        struct table_t { const void* gains; size_t rows, hop; };
-        const table_t* tb = static_cast<const table_t*>(params);
-        if (!tb->gains || tb->rows == 0 || (tb->rows > 1 && tb->hop == 0)) { set_error("sdft_hip_process_n", "gain table: gains, rows >= 1 and hop >= 1 are required"); return false; }
-        if (tb->rows > 0xffffffffull) { set_error("sdft_hip_process_n", "gain table: too many rows"); return false; }
-        g = static_cast<const FD*>(tb->gains); rows = tb->rows; op.rows = (unsigned)rows; op.hop = tb->hop;
-      }
-      const size_t per_bin = op_kind == OP_CGAIN ? 2 : 1;          // real factors, or (re, im) pairs
-      if (!on_device(g))
-      {
-        if (!d_gain.reserve(rows * nbins * 2)) return false;
-        if (!to_device(d_gain.p, g, rows * nbins * per_bin * sizeof(FD))) return false;
-        g = d_gain.p;
-      }
-      op.gain = g;
-    }
-    else if (op_kind == OP_SHIFT) op.shift = *static_cast<const long*>(params);
-    else if (op_kind == OP_GATE || op_kind == OP_POWER) { const FD* q = static_cast<const FD*>(params); op.p0 = q[0]; op.p1 = q[1]; }   // host memory
-    else if (op_kind == OP_USER)
-    {
-      // { expr, p, np }: the parameters travel to the device with the call (host memory; np may be 0)
-      struct expr_t { const char* expr; const void* p; size_t np; };
-      const expr_t* ex = static_cast<const expr_t*>(params);
-      if (!ex->expr || !*ex->expr) { set_error("sdft_hip_process_n", "expression: no statements"); return false; }
-      user_expr = ex->expr;
-      if (ex->np <= 8)
-      {
-        // up to eight parameters ride in the kernel arguments (SpectralOp::pv)
-        for (size_t i = 0; i < ex->np; ++i) op.pv[i] = static_cast<const FD*>(ex->p)[i];
-        op.gain = nullptr;
-      }
-      else
-      {
-        if (!d_gain.reserve(ex->np)) return false;
-        if (!to_device(d_gain.p, ex->p, ex->np * sizeof(FD))) return false;
-        op.gain = d_gain.p;
-      }
-    }
-    const bool linear = op_is_linear<FD>(op_kind);
-    const bool one_vector = op.rows <= 1;
-
-    // samples: device pointers as they are, host pointers staged (4 bytes per sample each way)
-    const bool xd = on_device(x);
-    const TD* xs = x;
-    if (!xd)
-    {
-      if (!d_stage_td.reserve(channels * n)) return false;
-      if (!to_device(d_stage_td.p, x, channels * n * sizeof(TD))) return false;
-      xs = d_stage_td.p;
-    }
-    TD* ys = y;
-    if (!yd) { if (!d_stage_y.reserve(channels * n)) return false; ys = d_stage_y.p; }
-    // In place (out == samples) or overlapping device buffers: the two reference calls read every sample before the first
-    // output sample is written, the one-launch forms do not (workgroups read the samples of earlier chunks -- fold, delay
-    // line, differences -- while others write their outputs).  The samples are copied aside first: 4-8 bytes per sample.
-    if (xs == x && yd)
-    {
-      const uintptr_t xa = reinterpret_cast<uintptr_t>(xs), ya = reinterpret_cast<uintptr_t>(ys), bytes = channels * n * sizeof(TD);
-      if (xa < ya + bytes && ya < xa + bytes)
-      {
-        if (!d_stage_td.reserve(channels * n)) return false;
-        SDFT_TRY(hipMemcpyAsync(d_stage_td.p, xs, bytes, hipMemcpyDeviceToDevice, stream));
-        xs = d_stage_td.p;
-      }
-    }
-
-    bool ok;
-    long chunks, len;
-    choose_chunks(n, chunks, len, rows_kernel_ok(false));
-    // reference order asked for on two-slot rows at FD float: the ordered walk (N dependent additions shared
-    // by the four samples of a group) costs more than the synthesis pass it saves (N = 4096, n = 262144:
-    // 5.7 ms against 4.1 ms for the two passes, which give the same bits); fused_exact = 2 insists on the kernel
-    const bool walk_loses = row_slots() == 2 && sizeof(FD) == 4 && carry_mode == CARRY_EXACT && opt_fused_exact == 1;
-    // calls of one time chunk: the folded form in one launch (process_hop2_kernel) unless the reference's order
-    // is wanted -- then the hop kernel + row synthesis pair below, which is bit-identical
-    const bool one_chunk_folded = chunks == 1 && n <= (size_t)kHopMax && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && opt_hop_kernel &&
-                                  linear && one_vector;
-    if (one_chunk_folded)
-    {
-      if (!fold_coefficients(op)) return false;
-      last_process_path = 1;
-      flag_wanted = xd && yd;
-      ok = coeff_ready && process_hop(n, xs, n, ys, n);
-      flag_wanted = false;
-    }
-    // the folded form carries up to four bins per lane whatever the bin type is (N <= 4096); the forms that keep the
-    // windowed rows in LDS stop at two slots of the row-group kernel (N <= 2048 double / 4096 float)
-    else if ((fuse_ok() || (linear && op.rows <= 65535u && !wants_reference_order() && !dfts && opt_fold && nbins >= 8 && nbins <= (size_t)4 * kWave * kRowWavesMax))
-             && (chunks > 1 || n > (size_t)kHopMax) && !walk_loses)       // (many channels: one chunk per channel, however long)
-    {
-      FuseArgs<TD, FD> fz{};
-      fz.y = ys; fz.y_stride = n; fz.syn = d_syn.p; fz.sweight = tab.sweight; fz.op = op; fz.store = dfts ? 1 : 0;
-      fz.walked = walked_counter();
-      if (!dfts) { if (!fold_coefficients(op)) return false; } else coeff_ready = false;
-      last_process_path = 1;
-      flag_wanted = xd && yd;
-      ok = forward_device(n, xs, n, dfts, n * nbins, nullptr, &fz);
-      flag_wanted = false;
-    }
-    else
-    {
-      // short calls (one time chunk: the hop kernel and the row-per-wave synthesis, two launches) and
-      // shapes the row-group kernel does not cover: analysis into the caller's matrix or a bounded
-      // workspace, synthesis with the operation applied on the way in
-      const size_t row_elems = channels * nbins;
-      size_t seg = dfts ? n : std::min(n, std::max<size_t>(1, stage_bytes / std::max<size_t>(row_elems * sizeof(fdx), 1)));
-      if (!dfts && seg < n && stage_bytes == kDefaultStageBytes)
-      {
-        // long calls run best in one piece (time segments restart the carry pipeline): unless the host
-        // has bounded it (option stage_bytes), the workspace may take up to half of what the device has free
-        if (d_stage_fdx.cap >= row_elems * n) seg = n;
-        else
-        {
-          size_t free_b = 0, total_b = 0;
-          if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            seg = std::max(seg, std::min(n, (free_b / 2) / std::max<size_t>(row_elems * sizeof(fdx), 1)));
-          (void)hipGetLastError();
-        }
-      }
-      // (batched plans take segments too: the workspace's channel stride is the segment, mstride below)
-      if (!dfts && !d_stage_fdx.reserve(row_elems * seg)) return false;
-      last_process_path = (chunks == 1) ? 2 : 3;
-      last_fused_exact = 0; last_fused_fold = 0;
-      if (op_kind == OP_USER)
-      {
-        // every run-time-compiled kernel the segments below will ask for is resolved BEFORE the first launch: statements
-        // that do not compile must not leave the stream advanced by an analysis whose synthesis then fails
-        const size_t m_first = std::min(seg, n), m_last = n - ((n - 1) / seg) * seg;
-        const bool hop_form = opt_exact_inverse && opt_inverse_rows <= 0;
-        const bool any_hop = hop_form && (channels * m_first <= 1024 || channels * m_last <= 1024);
-        const bool any_rows = !hop_form || channels * m_first > 1024 || channels * m_last > 1024 || dfts != nullptr;
-        hipFunction_t fn = nullptr;
-        char name[160];
-        if (any_hop)
-        {
-          snprintf(name, sizeof(name), "sdfthip::inverse_row_kernel<%s, %s, %s, true>", type_name<TD>(), type_name<FD>(), latency == 1 ? "true" : "false");
-          if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
-        }
-        if (any_rows)
-        {
-          snprintf(name, sizeof(name), "sdfthip::user_rows_kernel<%s>", type_name<FD>());
-          if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
-        }
-      }
-      ok = true;
-      for (size_t t = 0; t < n && ok; t += seg)
-      {
-        const size_t m = std::min(seg, n - t);
-        fdx* mat = dfts ? dfts + t * nbins : d_stage_fdx.p;
-        const size_t mstride = dfts ? n * nbins : m * nbins;
-        SpectralOp<FD> ops = op; ops.t0 = t;                  // gain vectors count from the start of the call
-        if (op_kind == OP_USER && opt_exact_inverse && opt_inverse_rows <= 0 && channels * m <= 1024)
-        {
-          // a hop: the statements run inside the row synthesis (two launches); a copy of the spectrum is processed afterwards
-          ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &ops);
-          if (ok && dfts) ok = user_rows(mat, mstride, m, ops);
-        }
-        else if (op_kind == OP_USER)                          // the host's operation rewrites the rows in place, then plain synthesis
-          ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && user_rows(mat, mstride, m, ops) && inverse_device(m, mat, mstride, nullptr, ys + t, n, nullptr);
-        else
-        {
-        ok = forward_device(m, xs + t, n, mat, mstride, nullptr) && inverse_device(m, mat, mstride, nullptr, ys + t, n, &ops);
-        if (ok && (op_kind == OP_GAIN || op_kind == OP_CGAIN || op_kind >= OP_GATE) && dfts) ok = scale_rows(mat, mstride, m, ops);
-        }
-      }
-    }
-    if (!ok) return false;
-    if (!yd)
-    {
-      if (!to_host(y, ys, channels * n * sizeof(TD))) return false;
-      return synchronize();
-    }
-    // (the fused call moves the samples only -- unless the host asked for a copy of the spectrum or the shape took the two passes)
-    return finish((dfts || last_process_path != 1) ? matrix_bytes(n) : std::max<size_t>(1, channels * n * 2 * sizeof(TD)));
-  }
-
-  // the host's own operation on stored rows (two-pass route): user_rows_kernel compiled at run time with its statements
-  bool user_rows(fdx* mat, size_t stride, size_t rows, const SpectralOp<FD>& op)
-  {
-    char name[96];
-    snprintf(name, sizeof(name), "sdfthip::user_rows_kernel<%s>", type_name<FD>());
-    hipFunction_t fn = nullptr;
-    if (!rtc_kernel(user_expr.c_str(), name, device, &fn)) return false;
-    if (!pipe_join()) return false;
-    const size_t total = channels * rows * nbins;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
-    fdx* a0 = mat; size_t a1 = stride, a2 = rows; unsigned a3 = (unsigned)nbins, a4 = (unsigned)channels; SpectralOp<FD> a5 = op;
-    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5};
-    SDFT_TRY(hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
-    return true;
-  }
-
-  // processed copy of the spectrum on the two-pass path: rows *= gain (the fused kernel stores them scaled)
-  bool scale_rows(fdx* mat, size_t stride, size_t rows, const SpectralOp<FD>& op)
-  {
-    if (!pipe_join()) return false;
-    const size_t total = channels * rows * nbins;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
-    hipLaunchKernelGGL((scale_rows_kernel<FD>), dim3(blocks), dim3(kBlock), 0, stream, mat, stride, rows, (unsigned)nbins, (unsigned)channels, op);
-    SDFT_TRY(hipGetLastError());
-    return true;
-  }
-
-  // checkpoint / resume: install a state previously read with get_state (any plan of the same
-  // dftsize, window, latency, types and channel count -- also on another GPU)
-  bool set_state(const fdx* acc, const fdx* fid, const TD* hist, size_t cur)
-  {
-    if (!bind()) return false;
-    if (!pipe_join()) return false;
-    SDFT_TRY(hipStreamSynchronize(stream));
-    if (nbins)
-    {
-      if (cur >= 2 * nbins) { set_error("sdft_hip_set_state", "cursor out of range"); return false; }
-      if (acc && !to_device(acc_p(), acc, channels * nbins * sizeof(fdx))) return false;
-      if (fid) { if (!to_device(fid_p(), fid, channels * nbins * sizeof(fdx))) return false; fid_canonical = false; }
-      if (hist && !to_device(d_hist[hist_cur].p, hist, channels * 2 * nbins * sizeof(TD))) return false;
-      SDFT_TRY(hipStreamSynchronize(stream));
-    }
-    cursor = cur;
-    return true;
-  }
-
-  // state read-back for tests: acc, fid [channels][N]; hist [channels][2N] in time order
-  bool get_state(fdx* acc, fdx* fid, TD* hist, size_t* cur)
-  {
-    if (!bind()) return false;
-    if (!pipe_join()) return false;
-    SDFT_TRY(hipStreamSynchronize(stream));
-    if (nbins)
-    {
-      if (acc && !to_host(acc, acc_p(), channels * nbins * sizeof(fdx))) return false;
-      if (fid && !to_host(fid, fid_p(), channels * nbins * sizeof(fdx))) return false;
-      if (hist && !to_host(hist, d_hist[hist_cur].p, channels * 2 * nbins * sizeof(TD))) return false;
-      SDFT_TRY(hipStreamSynchronize(stream));
-    }
-    if (cur) *cur = cursor;
-    return true;
-  }
+  // the entry points of the C-ABI (sdft_n / isdft_n / _nd / single samples / the fused call / state access) and the routes
+  // host memory takes through them
+#include "sdft_plan_entry.inc"
 };
 
 }  // namespace sdfthip
