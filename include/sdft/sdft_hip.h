@@ -134,7 +134,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        arithmetic does, but NOT within 1e-4 of the float reference (which itself drifts about 2e-4
                        of the largest bin per 262144 samples); the state then differs from the reference's by the same
    "exact_inverse" 1 (default) = synthesis gives the reference's bits (bins of a row added in the reference's order, or --
-                       float samples from double bins, option "inverse_verify" = 1 (default), up to "inverse_verify_max"
+                       float samples from double bins, option "inverse_verify" = 1 (default), up to 500 000
                        rows -- a tree sum whose rounding interval proves the reference's float, rows it cannot prove
                        added in order), 0 = wave-parallel tree sum, unverified
    "chunk"         samples per time chunk (0 = heuristic)
@@ -145,7 +145,6 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "fft_carry"     1 (default) = chunk partial sums by FFT when 2*dftsize is a power of two
    "interior"      bin-owning lanes per wave of the independent-tile kernel
    "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
-   "target_waves"  waves the time chunking aims for
    "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis)
    "hop_parts"     0 (default) = a hop-sized call's samples are cut into up to 8 time parts, every (tile of bins, part) a
                        workgroup on a CU of its own; a part's recurrence wave first runs the stream state through the samples
@@ -170,7 +169,6 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        what any summation order can differ by; only samples whose bound straddles a rounding boundary of the
                        float are summed in order -- get_option "ordered_walks" counts them)
    "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
-   "fuse_delta"    1 (default) = chunk-parallel calls form the sample differences inside the carry kernel
    "pointers"      0 (default) = every call asks the runtime what each pointer is (hipPointerGetAttributes: 0.06-0.16 us,
                        nothing is cached -- a buffer that was freed and whose address came back as the other kind of memory
                        is classified as what it is now), 1 = all device, 2 = all host (no query)
@@ -181,7 +179,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        reference): a registration does not survive free() + malloc() handing the same address out again.
    "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
                        launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
-                       0 = carries by a pre-pass (two more launches); "self_carry_max" = longest call that takes it
+                       0 = carries by a pre-pass (two more launches); calls of up to 2^19 samples per channel take it
    "rows_f32"      1 (default) = FD float rows of a multiple of 128 bins are analysed by the bin-pair kernel (a lane's two
                        adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
    "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB

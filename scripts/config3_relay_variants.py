@@ -37,6 +37,6 @@ if __name__ == "__main__":
     for m, window, n in ((4096, "blackman", 262144), (2048, "hann", 262144), (1024, "hann", 262144)):
         run(m, window, n)
         for waves, groups in ((6, 2), (4, 2), (4, 1), (6, 1)):
-            run(m, window, n, relay_waves=waves, relay_groups=groups)
+            run(m, window, n, relay_waves=waves)
         run(m, window, n, chunk=256)
         run(m, window, n, chunk=512)

@@ -21,8 +21,6 @@ for n in sizes:
             p = SDFT(m, "hann", 1.0, "f32f64")
             p.set_option("async", 1)
             p.set_option("pipeline", pipe)
-            if os.environ.get("SELF_MAX"):
-                p.set_option("self_carry_max", int(os.environ["SELF_MAX"]))
             xp = C.c_void_p(x.data_ptr())
             op = [C.c_void_p(o[0].data_ptr()), C.c_void_p(o[(bufs - 1)].data_ptr())]
             for i in range(6):

@@ -69,6 +69,7 @@ UNTYPED = {
     "sdft_hip_check_expr": (C.c_int, [C.c_char_p, C.c_char_p]),
     "sdft_hip_store_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int]),
     "sdft_hip_load_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_int]),
+    "sdft_hip_load_rows_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_int]),
     "sdft_hip_hold_cus": (C.c_int, [C.c_uint, C.c_double]),
 }
 

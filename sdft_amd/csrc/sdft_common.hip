@@ -279,6 +279,33 @@ __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t
   }
 }
 
+// load-only counterpart of store_rowgroup_kernel (the synthesis' ceiling by access shape): one workgroup of row_slots/64 waves per
+// chunk of rows reads whole rows in step (16 bytes per lane), `depth` rows in flight per lane; regions as above (0: workgroup b
+// -> chunk b)
+__global__ __launch_bounds__(1024) void load_rowgroup_kernel(const v2f64* src, size_t rows, unsigned row_slots, unsigned chunk_len, unsigned regions, double* sink)
+{
+  unsigned chunk = blockIdx.x;
+  if (regions)
+  {
+    const unsigned R = regions, q = gridDim.x / R, r = gridDim.x % R, x = blockIdx.x % R;
+    chunk = x * q + (x < r ? x : r) + blockIdx.x / R;
+  }
+  const size_t t0 = (size_t)chunk * chunk_len;
+  const size_t t1 = t0 + chunk_len < rows ? t0 + chunk_len : rows;
+  if (t0 >= t1 || threadIdx.x >= row_slots) return;
+  const v2f64* p = src + t0 * row_slots + threadIdx.x;
+  double acc = 0.0;
+  size_t t = t0;
+  for (; t + 4 <= t1; t += 4)
+  {
+    const v2f64 a = p[0], b = p[row_slots], c = p[2 * (size_t)row_slots], d = p[3 * (size_t)row_slots];
+    acc += (a.x + b.x) + (c.x + d.x) + (a.y + b.y) + (c.y + d.y);
+    p += 4 * (size_t)row_slots;
+  }
+  for (; t < t1; ++t) { const v2f64 a = *p; acc += a.x + a.y; p += row_slots; }
+  if (acc == 12345.678) *sink = acc;
+}
+
 // measurement aid: holds one CU per workgroup (159 of the 160 KiB of LDS: no workgroup of the library shares the CU) for `ticks` of the 100 MHz clock
 // without touching memory
 __global__ __launch_bounds__(512) void hold_cu_kernel(unsigned long long ticks, unsigned* sink)
@@ -384,6 +411,28 @@ double sdft_hip_load_ceiling(const void* src, size_t bytes, int reps)
   if (hipMalloc((void**)&sink, 8) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); return -1.0; }
   auto launch = [&]() { hipLaunchKernelGGL(load_linear_kernel, dim3(256 * 16), dim3(kBlock), 0, 0, (const v2f64*)src, slots, sink); };
+  launch();
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1, 0);
+  float ms = -1.f;
+  if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1); else (void)hipGetLastError();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  return ms < 0.f ? -1.0 : (double)ms / (reps > 0 ? reps : 1);
+}
+
+// the same for whole rows read in step by one workgroup per chunk of rows (load_rowgroup_kernel); regions: see store patterns
+double sdft_hip_load_rows_ceiling(const void* src, size_t bytes, unsigned row_slots, unsigned chunk_len, unsigned regions, int reps)
+{
+  using namespace sdfthip;
+  const size_t slots = bytes / 16, rows = slots / row_slots;
+  const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
+  hipEvent_t e0, e1;
+  double* sink = nullptr;
+  if (hipMalloc((void**)&sink, 8) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); return -1.0; }
+  auto launch = [&]() { hipLaunchKernelGGL(load_rowgroup_kernel, dim3(chunks), dim3(((row_slots + 63) / 64) * 64), 0, 0, (const v2f64*)src, rows, row_slots, chunk_len, regions, sink); };
   launch();
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0, 0);

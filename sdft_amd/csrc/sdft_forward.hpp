@@ -113,6 +113,7 @@ template <typename FD> struct ForwardArgs
   // of every eighth region: the store stream of the headline workload runs 4-9 % faster that way (store-only probes,
   // profiles/r05_store_ceiling_study.txt).  Placement is for speed only: any block-to-XCD assignment gives the same results.
   unsigned xcd_map;           // 0, or the launch's number of (channel, chunk) workgroups
+  unsigned inv_chunks, inv_channels;   // floor(2^32 / launch_chunks) + 1 and floor(2^32 / ready_channels) + 1 (0 for a divisor of 1): flow_position
 };
 // the b-th workgroup's position in the launch's (channel, chunk) sequence: a bijection of [0, total) for any total
 SDFT_D unsigned xcd_contiguous(unsigned b, unsigned total)
@@ -124,13 +125,25 @@ SDFT_D unsigned xcd_contiguous(unsigned b, unsigned total)
 // Flow mode: which (chunk, channel) a workgroup takes, and the wait for the chunk's carries.  The relay kernel stores
 // carries write-through (sc1), waits for them, then stores the flag (sc1); here: relaxed agent-scope polls of the flags,
 // one agent-scope acquire, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility, form R1).
+// block / d and block % d for a wave-uniform block and a divisor the host knows (inv = floor(2^32 / d) + 1, 0 for d = 1): scalar
+// integer instructions only -- the compiler's own sequence for a division by a run-time value goes through the vector unit's
+// reciprocal and keeps vector registers alive for it (these kernels have none to spare)
+SDFT_D void uniform_divmod(unsigned block, unsigned d, unsigned inv, unsigned& q, unsigned& r)
+{
+  if (inv == 0) { q = block; r = 0; return; }
+  q = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)block * inv) >> 32));
+  r = block - q * d;
+  if (r >= d) { --q; r += d; }                               // (floor(2^32 / d) + 1 over-estimates by at most one)
+}
 template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch, unsigned block)
 {
-  if (a.ready) { chunk = a.chunk0 + block / a.ready_channels; ch = block % a.ready_channels; }
+  unsigned q, r;
+  if (a.ready) { uniform_divmod(block, a.ready_channels, a.inv_channels, q, r); chunk = a.chunk0 + q; ch = r; }
   else
   {
     if (a.xcd_map) block = xcd_contiguous(block, a.xcd_map);
-    chunk = a.chunk0 + block % a.launch_chunks; ch = block / a.launch_chunks;
+    uniform_divmod(block, a.launch_chunks, a.inv_chunks, q, r);
+    chunk = a.chunk0 + r; ch = q;
   }
 }
 template <typename FD> SDFT_D void flow_position(const ForwardArgs<FD>& a, unsigned& chunk, size_t& ch) { flow_position(a, chunk, ch, blockIdx.x); }

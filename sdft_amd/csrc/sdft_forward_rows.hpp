@@ -131,13 +131,13 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
       {
         s[q][b].acc = sa.acc_in[ch * a.nbins + kk];
         if (dft) s[q][b].acc = cadd(s[q][b].acc, dft[self_slot(sa, (unsigned)kk)]);
-        s[q][b].fid = a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+        s[q][b].fid = a.wtab[((unsigned)kk * c) % span];
       }
       else
       {
       s[q][b].acc = a.carry[cbase + kk];
       s[q][b].fid = a.fseed ? fid_from_table(a.fseed, a.fseed_L, a.nbins, kk, c, s[q][b].tw)
-                  : a.seed  ? a.seed[cbase + kk] : a.wtab[(size_t)(((unsigned long long)kk * c) % span)];
+                  : a.seed  ? a.seed[cbase + kk] : a.wtab[((unsigned)kk * c) % span];
       }
 
       pub[q][b] = &edgeL[0][0][0][0];

@@ -62,7 +62,7 @@ class HostIo
   // pages are pinned and mapped, the driver follows the mapping with MMU notifiers) lets the kernels read and write it
   // over PCIe directly -- no staging copy, one synchronisation.  Buffers of 1 MiB and more only (smaller ones share
   // pages with their heap neighbours), at most 8 ranges that never share a page; anything the runtime refuses
-  // falls back to the staged path.  Option "host_register" = 1 turns it on, "host_register_max" bounds the
+  // falls back to the staged path.  Option "host_register" = 1 turns it on, a buffer of more than 256 MiB is never registered: the
   // bytes of one buffer (default 256 MiB: longer calls run at PCIe speed through the staged path anyway).
   static constexpr size_t kSmallHostBytes = (size_t)64 << 10;
   static constexpr size_t kHostRegisterMin = (size_t)1 << 20;       // smaller buffers share pages with their heap neighbours: staged
@@ -71,7 +71,7 @@ class HostIo
   // (measured: "Memory access fault" on the second call) -- the driver does not re-attach it.  A C host that allocates
   // its buffers once, like the reference's driver, sets option "host_register" = 1.
   long opt_host_register = 0;
-  size_t opt_host_register_max = (size_t)256 << 20;
+  static constexpr size_t kHostRegisterMax = (size_t)256 << 20;
   // A registration covers exactly the caller's bytes [a, b) -- NOT the whole pages around them: a long-lived process gets
   // its megabyte buffers from the heap (glibc raises its mmap threshold as buffers are freed), where the neighbours share
   // the first and last page; with whole pages registered, a later copy from or to such a neighbour -- inside the
@@ -91,7 +91,7 @@ class HostIo
   // device-side address of a host buffer of `bytes` bytes, or nullptr (not used / not possible: take the staged path)
   void* map_host(const void* p, size_t bytes, bool will_write = false)
   {
-    if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > opt_host_register_max) return nullptr;
+    if (!opt_host_register || !p || bytes < kHostRegisterMin || bytes > kHostRegisterMax) return nullptr;
     const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p), b = a + bytes;
     const uintptr_t plo = a & ~(page - 1), phi = (b + page - 1) & ~(page - 1);
     for (HostReg& e : host_regs)

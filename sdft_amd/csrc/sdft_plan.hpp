@@ -117,7 +117,8 @@ class Plan
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
   long opt_flag_max = (long)1 << 24;                       // bin-samples up to which a row-group analysis call signals its own completion
   long opt_self_stamps = 0;                                // development builds (SDFT_SELF_STAMPS): device address of 8 stamp words
-  long opt_inverse_verify = 1, opt_inverse_verify_max = 500000, last_inverse_form = 0;   // launch_inverse
+  long opt_inverse_verify = 1, last_inverse_form = 0;      // launch_inverse
+  static constexpr size_t kInverseVerifyMax = 500000;      // rows up to which the tree sum with the rounding-interval proof serves sdft_isdft_n (beyond: the streaming kernel)
   bool rtc_failed = false;                                 // launch_inverse returns void: a failed run-time compilation is reported here
   std::string user_expr;                                   // sdft_hip_process_n with an expression: the statements of the call in flight
   template <typename T> static const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
@@ -127,7 +128,6 @@ class Plan
   long opt_float_parallel = 0;
   long opt_chunk = 0;            // forced chunk length (0 = heuristic)
   long opt_interior = 0;         // forced interior lanes per wave (0 = maximum)
-  long opt_target_waves = 0;     // waves to aim for when chunking time (0 = default)
   static constexpr size_t kDefaultStageBytes = (size_t)1 << 30;
   size_t stage_bytes = kDefaultStageBytes;   // host-pointer path: staging segment size
   int profile = 0;               // 0 off, 1 = events around every stage, 2 = forward/inverse kernels only
@@ -157,9 +157,8 @@ class Plan
                                  // -1 = in order exactly when the host asked for exact carries at FD double (carry = 1)
   long last_fused_exact = 0, last_fused_fold = 0, last_process_path = 0;   // last_process_path: 1 fused kernel, 2 hop pair, 3 two-pass segments
   long opt_spin = 1;             // synchronous short calls poll the stream instead of sleeping on it
-  long opt_proc_slots = 0;       // fused kernel, development option: bins per lane (0 = as few as the row needs)
   long opt_self = 1;             // chunk-parallel FD double calls, 2N a power of two: self-carried chunks (no pre-pass launches)
-  long opt_self_max = (long)1 << 19;   // ... for calls of up to this many samples per channel (the fold of a chunk's past grows with n)
+  static constexpr size_t kSelfMax = (size_t)1 << 19;      // ... for calls of up to this many samples per channel (the fold of a chunk's past grows with n)
   long last_self = 0;
 
   long last_kernel = 0;          // 1 = forward_kernel (independent tiles), 2 = forward_rows_kernel
@@ -196,7 +195,6 @@ class Plan
   long opt_hop_pipe = 1;         // calls of one time chunk, small launches: two waves per tile (forward_hop2_kernel)
   long last_hop_pipe = 0;
   long opt_hop_parts = 0, last_hop_parts = 1;   // ... in time parts (0 = by the launch's size, 1 = never, n = that many)
-  long opt_fuse_delta = 1;       // chunk-parallel carries, FFT form: the differences are formed by the carry kernel (one launch less)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
   long opt_relay_waves = 0;      // waves per workgroup of the relay form (0 = default)
   DevBuf<unsigned long long> d_chain_stats;
@@ -234,7 +232,6 @@ class Plan
     if (sizeof(FD) == 4) carry_mode = CARRY_EXACT;         // float FD follows the reference's rounding (unless "float_carry_parallel")
     if (const char* e = getenv("SDFT_HIP_CHUNK")) opt_chunk = atol(e);
     if (const char* e = getenv("SDFT_HIP_INTERIOR")) opt_interior = atol(e);
-    if (const char* e = getenv("SDFT_HIP_TARGET_WAVES")) opt_target_waves = atol(e);
     if (nbins == 0) return true;
     const size_t nb = nbins, span = 2 * nbins;
     if (!d_tw.reserve(nb) || !d_syn.reserve(nb) || !d_wtab.reserve(span)) return false;
@@ -376,11 +373,13 @@ class Plan
   {
     logic::ChunkQuery q;
     q.n = n; q.channels = channels; q.nbins = nbins; q.rows_kernel = rows_kernel; q.exact = carry_mode == CARRY_EXACT; q.pipelined = pipe_this;
-    q.forced_chunk = opt_chunk; q.target_waves = opt_target_waves; q.row_waves = row_waves(); q.tiles = tiles(); q.compute_units = compute_units;
+    q.forced_chunk = opt_chunk; q.row_waves = row_waves(); q.tiles = tiles(); q.compute_units = compute_units;
     const logic::Chunking c = logic::choose_chunks(q);
     chunks = c.chunks; len = c.len;
   }
 
+  // floor(2^32 / d) + 1, 0 for d <= 1: what flow_position divides a workgroup number by (ForwardArgs::inv_chunks, inv_channels)
+  static unsigned inv32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1) << 32) / d) + 1u; }
   // every launch is a 1-D grid (channels ride on grid.x); refuse what would not fit it
   static bool grid_fits(size_t blocks)
   {
@@ -409,22 +408,15 @@ class Plan
     started_target = 0;
     return true;
   }
-  // relays (32 bins of a channel each), waves per relay; two relays may share a workgroup (FD float, option relay_groups;
-  // measured slower: 12 waves of products and two chains on one CU contend for issue -- config 3 shape, 1.5 against 1.05 ms)
-  long opt_relay_groups = 1;     // relays per workgroup
+  // relays (32 bins of a channel each), waves per relay.  (Two relays per workgroup -- the kernel has the form -- were measured
+  // slower, 12 waves of products and two chains on one CU contend for issue: config 3 shape, 1.5 against 1.05 ms; the option is gone)
   static unsigned relay_waves_default() { return 8u; }
   unsigned relay_waves() const
   {
     const long mx = relay_limits<FD>::waves;
     return (unsigned)std::max(1L, std::min(mx, opt_relay_waves > 0 ? opt_relay_waves : (long)relay_waves_default()));
   }
-  unsigned relay_groups(unsigned relays) const
-  {
-    const unsigned fit = (unsigned)relay_limits<FD>::waves / relay_waves();
-    unsigned g = opt_relay_groups > 0 ? (unsigned)opt_relay_groups : (unsigned)relay_limits<FD>::groups;
-    g = std::max(1u, std::min({g, fit, (unsigned)relay_limits<FD>::groups}));
-    return relays >= 2 ? g : 1u;
-  }
+  static unsigned relay_groups(unsigned) { return 1u; }
   template <int L> bool launch_relay(ChainArgs<FD> cc, unsigned relays, hipStream_t on)
   {
     const unsigned waves = relay_waves(), groups = relay_groups(relays);
@@ -607,7 +599,7 @@ class Plan
       else if (opt_fft_carry && !short_chunks && rl.count > 0 && 2 * span_bytes <= (size_t)64 * 1024) sums_form = SUMS_FFT_MIXED;
     }
     // K0: differences + delay line -- unless the chunk-parallel carry kernel forms them itself
-    const bool delta_in_carry = !exact && chunks > 1 && opt_fuse_delta;
+    const bool delta_in_carry = !exact && chunks > 1;
     if (!delta_in_carry)
     {
     if (!prof_begin(ST_DELTA)) return false;
@@ -795,6 +787,7 @@ class Plan
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
     fa.ready = nullptr; fa.ready_seq = 0; fa.ready_n = 0; fa.ready_channels = (unsigned)channels; fa.ready_status = nullptr; fa.ready_status_seen = 0;
+    fa.inv_channels = inv32((unsigned)channels);
     if (flow)
     {
       fa.ready = d_ready.p; fa.ready_seq = ready_seq; fa.ready_n = (unsigned)((nb + kWave / 2 - 1) / (kWave / 2));
@@ -811,7 +804,7 @@ class Plan
     for (long sg = 0; sg < segments; ++sg)
     {
       const long j0 = chunks * sg / segments, j1 = chunks * (sg + 1) / segments;
-      fa.chunk0 = (unsigned)j0; fa.launch_chunks = (unsigned)(j1 - j0);
+      fa.chunk0 = (unsigned)j0; fa.launch_chunks = (unsigned)(j1 - j0); fa.inv_chunks = inv32(fa.launch_chunks);
       fa.xcd_map = (opt_xcd_map && !flow && channels * (size_t)(j1 - j0) >= 16) ? (unsigned)(channels * (size_t)(j1 - j0)) : 0u;
       fa.total_waves = (unsigned long long)channels * (unsigned long long)(j1 - j0) * (unsigned long long)ntiles;
       if (segments > 1) SDFT_TRY(hipStreamWaitEvent(stream, seg_events[sg], 0));      // (flow mode: the kernel waits chunk by chunk)
@@ -866,7 +859,7 @@ class Plan
   // n = 1e6: 77.3 against 75.5 % of peak, but two matrices in turn, pipelined: 82.4 %)
   bool self_eligible(size_t n, bool fused_call, bool any_length = false) const
   {
-    const size_t self_max = fused_call ? std::min<size_t>((size_t)opt_self_max, (size_t)1 << 16) : (size_t)opt_self_max;
+    const size_t self_max = fused_call ? std::min<size_t>(kSelfMax, (size_t)1 << 16) : kSelfMax;
     return sizeof(FD) == 8 && carry_mode != CARRY_EXACT && opt_self && self_cells() != 0 && (n <= self_max || any_length);
   }
 
@@ -1048,7 +1041,7 @@ class Plan
     fa.total_waves = 0;
     fa.nbins = (unsigned)nb; fa.chunks = (unsigned)chunks; fa.chunk_len = (unsigned)len; fa.tiles = (unsigned)tiles();
     fa.interior_lanes = (unsigned)interior_lanes(); fa.cursor0 = (unsigned)cursor; fa.chunk_shift = 0;
-    fa.chunk0 = 0; fa.launch_chunks = (unsigned)chunks;
+    fa.chunk0 = 0; fa.launch_chunks = (unsigned)chunks; fa.inv_chunks = inv32(fa.launch_chunks);
     fa.xcd_map = (opt_xcd_map && channels * (size_t)chunks >= 16) ? (unsigned)(channels * (size_t)chunks) : 0u;
     fa.vec_store = 0;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
