@@ -19,13 +19,15 @@ for label, m, n, ch, combo, reps in (("n=1e6 m=1024 f32f64", 1024, 1_000_000, 1,
     cdt = torch.complex128 if esz == 16 else torch.complex64
     d = torch.randn((ch, n, m) if ch > 1 else (n, m), dtype=torch.float32 if esz == 8 else torch.float64, device="cuda").to(cdt)
     plans = []
-    for vl, v in (("spread", 1), ("window", 0)):
+    for vl, v, rpi, rows, tune in (("tuned", 0, 4, 0, 1), ("static", 0, 4, 0, 0), ("spread", 1, 4, 0, 0), ("16r 512B", 0, 2, 16, 0), ("16r 256B", 0, 4, 16, 0)) + ((("32r 256B", 0, 4, 32, 0),) if esz == 16 else ()):
         p = SDFT(m, "hann", 1.0, combo, channels=ch)
-        p.set_option("async", 1); p.set_option("inverse_spread", v)
+        p.set_option("async", 1); p.set_option("inverse_spread", v); p.set_option("inverse_rpi", rpi); p.set_option("inverse_rows", rows); p.set_option("inverse_tune", tune)
+        for _ in range(10):
+            p.isdft(d)
         y = p.isdft(d)
         p.synchronize()
         plans.append((vl, p, y))
-    same = bool(torch.equal(plans[0][2], plans[1][2]))
+    same = all(bool(torch.equal(plans[0][2], q[2])) for q in plans[1:])
     res = {vl: [] for vl, _, _ in plans}
     for r in range(rounds):
         for vl, p, y in plans:
@@ -38,7 +40,7 @@ for label, m, n, ch, combo, reps in (("n=1e6 m=1024 f32f64", 1024, 1_000_000, 1,
     b = ch * n * (m * esz + 4)
     for vl, p, y in plans:
         w = float(np.median(res[vl]))
-        print(f"{label:30s} {vl:8s} {w * 1e3:8.3f} ms = {b / w / 1e9:6.0f} GB/s = {b / w / 8e12:5.1%} of peak  form {p.get_option('last_inverse_form')}  same bits: {same}")
+        print(f"{label:30s} {vl:8s} {w * 1e3:8.3f} ms = {b / w / 1e9:6.0f} GB/s = {b / w / 8e12:5.1%} of peak  form {p.get_option('last_inverse_form')} tuned {p.get_option('last_inverse_tuned')}  same bits: {same}")
         p.close()
     del d, plans
     torch.cuda.empty_cache()

@@ -138,12 +138,13 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 // double calls, 16 for FD float and medium calls, 4 with an 8-deep ring for short calls (a hop of
 // 100 rows has too few rows to hide latency with row-parallelism alone).
 // ------------------------------------------------------------------------------------------
-template <typename TD, typename FD, bool LAT1, int RW, int DEPTH, bool OPS = false>
+// RPI: rows per load instruction = 4 (a row segment of 256 bytes per instruction), 2 (512 bytes) or 1 (a whole KiB of one row)
+template <typename TD, typename FD, bool LAT1, int RW, int DEPTH, bool OPS = false, int RPI = 4>
 __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, FD> a)
 {
   constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load (1 for f64, 2 for f32)
-  constexpr int C = 16 * BPL;                            // bins per tile row = 256 bytes
-  constexpr int RPI = 4;                                 // rows per load instruction (16 lanes each)
+  constexpr int LPR = kWave / RPI;                       // lanes per row segment
+  constexpr int C = LPR * BPL;                           // bins per tile row = 256 bytes (RPI = 4) ... 1 KiB (RPI = 1)
   constexpr int NI = RW / RPI;                           // load instructions per tile
   using V = typename StoreVec<FD, (sizeof(cx<FD>) == 16 ? 1 : 2)>::type;   // 16-byte vector
   __shared__ FD tile[kWavesPerBlock][RW][C + 1];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
   const size_t ngroups_per_ch = (a.n + RW - 1) / RW;
   const size_t ngroups = ngroups_per_ch * a.channels;
   const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
-  const int sub = lane >> 4, seg = lane & 15;            // load phase: row within the instruction, 16-byte slot
+  const int sub = lane / LPR, seg = lane % LPR;          // load phase: row within the instruction, 16-byte slot
   const bool vec_ok = (BPL == 1) || ((a.nbins % 2 == 0) && !a.in_rows && (a.in_stride % 2 == 0));
 
   // row groups are taken from the END of the matrix first: a round trip calls this right after the

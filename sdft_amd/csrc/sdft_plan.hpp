@@ -146,6 +146,24 @@ class Plan
   // (measured both ways by matrix, scripts/inverse_spread_ab.py: 64 x 48000 x 1024 +6 %, 262144 x 1024 f64f64 +4 %, but 1e6 x 1024
   // -5.5 %, 600000 x 1024 -5 % -- profiles/r05_store_ceiling_study.txt; off)
   long opt_inverse_spread = 0;   // InverseArgs::spread
+  // long synthesis calls: the fastest of the bit-identical streaming forms is found on the host's own calls (launch_inverse)
+  long opt_inverse_tune = 1, last_inverse_tuned = 0;
+  logic::FormTuner inv_tune;
+  hipEvent_t tune_ev[logic::FormTuner::kMax][2] = {};         // a pair of events per candidate form
+  bool ensure_tune_events()
+  {
+    if (tune_ev[0][0]) return true;
+    for (auto& pair : tune_ev)
+      for (hipEvent_t& e : pair)
+        if (hipEventCreate(&e) != hipSuccess)
+        {
+          (void)hipGetLastError(); e = nullptr;
+          for (auto& q : tune_ev) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
+          return false;
+        }
+    return true;
+  }
+  long opt_inverse_rpi = 4;      // development: rows per load instruction of the streaming synthesis (4: 256-byte row segments, 2, 1: a KiB)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
@@ -268,6 +286,7 @@ class Plan
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
     seg_events.clear();
     if (ev_delta) { (void)hipEventDestroy(ev_delta); ev_delta = nullptr; }
+    for (auto& pair : tune_ev) for (hipEvent_t& e : pair) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (int st = 0; st < ST_COUNT; ++st)
     {
       for (hipEvent_t e : ev_pool[st]) (void)hipEventDestroy(e);

@@ -311,6 +311,60 @@ inline long inverse_rows_per_wave(size_t total_rows, size_t fd_bytes, long force
   return rw;
 }
 
+// ---- which of several bit-identical kernel forms is the fastest HERE: measured on the calls themselves ---------------------
+// The streaming synthesis has forms that give the same bits and differ by a few per cent either way from box to box (rows per
+// wave, bytes per row segment, tree sum with the rounding-interval proof): round 4's fixed switch points were right on one
+// lease and wrong on the next.  A host that repeats a call shape lets the plan find out: the first calls of the shape take
+// the candidate forms in turn, each bracketed by a pair of events (two samples per form, the smaller one counts), then the
+// fastest form serves the shape.  Until a sample's events have completed no new trial starts (the calls in between take
+// form 0, the static choice, untimed); a new shape starts over.
+struct FormTuner
+{
+  static constexpr int kMax = 4, kSamples = 2;
+  size_t key = 0;
+  int count = 0, chosen = -1;
+  int samples[kMax] = {0, 0, 0, 0};
+  bool inflight[kMax] = {false, false, false, false};      // a timed call of this form has been launched and not yet reported
+  float best[kMax] = {0, 0, 0, 0};
+  void reset(size_t k, int candidates)
+  {
+    key = k; count = candidates < 1 ? 1 : (candidates > kMax ? kMax : candidates); chosen = count == 1 ? 0 : -1;
+    for (int i = 0; i < kMax; ++i) { samples[i] = 0; best[i] = 0.f; inflight[i] = false; }
+  }
+  // the form this call takes; timed: the caller brackets the launch with the form's pair of events, calls launched() and
+  // reports the time once the events have completed (a host that queues calls faster than they run has several trials in
+  // flight, one per form)
+  int next(bool can_time, bool& timed)
+  {
+    timed = false;
+    if (chosen >= 0) return chosen;
+    int want = -1, open = 0;
+    for (int i = 0; i < count; ++i)
+    {
+      if (samples[i] < kSamples) ++open;
+      if (samples[i] < kSamples && !inflight[i] && (want < 0 || samples[i] < samples[want])) want = i;
+    }
+    if (open == 0)
+    {
+      chosen = 0;
+      for (int i = 1; i < count; ++i) if (best[i] < best[chosen]) chosen = i;
+      return chosen;
+    }
+    if (!can_time || want < 0) return 0;                      // (every open form is in flight: the static form, untimed)
+    timed = true;
+    return want;
+  }
+  void launched(int form) { if (form >= 0 && form < count) inflight[form] = true; }
+  void report(int form, float ms)
+  {
+    if (form < 0 || form >= count) return;
+    inflight[form] = false;
+    if (!(ms > 0.f)) return;
+    best[form] = samples[form] == 0 ? ms : (ms < best[form] ? ms : best[form]);
+    ++samples[form];
+  }
+};
+
 // ---- fused call: waves of a workgroup and bins per lane (1, 2, 4) -----------------------------------------------------------
 struct ProcessGeometry { long waves = 1, slots = 1; };
 inline ProcessGeometry process_geometry(size_t nbins, size_t channels, size_t n, bool fused, size_t fd_bytes, long forced_slots)

@@ -222,6 +222,36 @@ static void test_small_decisions()
   CHECK(stage_rows(1000, 16384, (size_t)1 << 30) == 1000 && stage_rows(1000000, 16384, (size_t)1 << 30) == 65536 && stage_rows(5, 0, 100) == 5 && stage_rows(10, 1000, 10) == 1, "staging segments");
 }
 
+static void test_form_tuner()
+{
+  FormTuner t;
+  t.reset(1000, 3);
+  bool timed = false;
+  // a host that waits for every call: the candidates in turn, two samples each, the smaller one counts
+  const float ms[3][2] = {{2.0f, 1.9f}, {1.5f, 1.6f}, {1.8f, 3.0f}};
+  int seen[3] = {0, 0, 0};
+  for (int i = 0; i < 6; ++i)
+  {
+    const int f = t.next(true, timed);
+    CHECK(timed && f >= 0 && f < 3 && seen[f] < 2, "trial %d: form %d", i, f);
+    t.launched(f); t.report(f, ms[f][seen[f]]); ++seen[f];
+  }
+  int f = t.next(true, timed);
+  CHECK(!timed && f == 1 && t.chosen == 1, "the fastest form (by its smaller sample) is chosen: %d", f);
+  CHECK(t.next(false, timed) == 1 && !timed, "and stays");
+  // a host that queues calls faster than they run: one trial per form in flight, then the static form untimed
+  t.reset(5000, 3);
+  for (int i = 0; i < 3; ++i) { f = t.next(true, timed); CHECK(timed && f == i, "flood: form %d in flight", f); t.launched(f); }
+  f = t.next(true, timed); CHECK(!timed && f == 0 && t.chosen < 0, "every open form in flight: the static form, untimed");
+  t.report(1, 1.0f);
+  f = t.next(true, timed); CHECK(timed && f == 1, "a form that has reported takes its second sample");
+  t.reset(2000, 1); CHECK(t.next(true, timed) == 0 && !timed && t.chosen == 0, "one candidate: nothing to measure");
+  t.reset(3000, 9); CHECK(t.count == FormTuner::kMax, "capped");
+  t.reset(3000, 2);
+  CHECK(t.next(false, timed) == 0 && !timed, "no timing possible: the static form");
+  t.launched(1); t.report(7, 1.0f); t.report(1, -1.0f); CHECK(t.samples[1] == 0 && !t.inflight[1], "a failed sample frees the form and counts nothing");
+}
+
 static void test_piece_ring()
 {
   for (int it = 0; it < 20000; ++it)
@@ -252,6 +282,7 @@ int main()
   test_inverse_streams();
   test_small_decisions();
   test_piece_ring();
+  test_form_tuner();
   if (failures) { fprintf(stderr, "%d failure(s)\n", failures); return 1; }
   printf("plan logic: all properties hold\n");
   return 0;

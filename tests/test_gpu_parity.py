@@ -352,6 +352,11 @@ def test_inverse_is_bit_identical(combo, latency):
             for rows in (4, 8, 16) + ((32,) if combo[3:] == "f64" else ()):
                 p.set_option("inverse_rows", rows)
                 assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want), (combo, latency, m, n, rows)
+            # (round 5: row segments of 512 bytes and of a KiB per load instruction)
+            for rows, rpi in ((16, 2), (16, 1)) + (((32, 2),) if combo[3:] == "f64" else ()):
+                p.set_option("inverse_rows", rows); p.set_option("inverse_rpi", rpi)
+                assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want), (combo, latency, m, n, rows, rpi)
+            p.set_option("inverse_rpi", 4)
             p.set_option("inverse_rows", 0)
             p.set_option("exact_inverse", 0)                       # wave-parallel sum: inside the bar, not identical
             assert rel_err(p.isdft(d), want) <= TOL[combo[3:]]
@@ -363,6 +368,36 @@ def test_inverse_is_bit_identical(combo, latency):
         yb = p.isdft(db)
     for c in range(ch):
         assert np.array_equal(yb[c], refs[c].isdft(db[c]))
+
+
+@pytest.mark.parametrize("combo,m,n,channels", [("f32f64", 1024, 70000, 1), ("f64f64", 1000, 66000, 1), ("f32f32", 2048, 66000, 1), ("f32f64", 256, 9000, 8)])
+def test_long_synthesis_calls_find_their_form_and_keep_their_bits(combo, m, n, channels):
+    """Round 5: from 64 Ki rows on the plan measures the bit-identical streaming forms of the synthesis (16 / 32 rows per wave,
+    256- / 512-byte row segments, the tree sum with the rounding-interval proof) on the host's own calls and keeps the
+    fastest (logic::FormTuner).  Every call of the trial phase and after it gives the same samples -- the reference's."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    rng = np.random.default_rng(m + n)
+    shape = (channels, n, m) if channels > 1 else (n, m)
+    d = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(fdx)
+    d[..., ::9, :] *= 1e-6
+    refs = [O.best(m, "hann", 1.0, combo) for _ in range(channels)]
+    want = np.stack([refs[c].isdft(d[c]) for c in range(channels)]) if channels > 1 else refs[0].isdft(d)
+    dd = torch.from_numpy(d).cuda()
+    with make(m, "hann", 1.0, combo, channels) as p:
+        forms = []
+        for call in range(12):
+            y = p.isdft(dd).cpu().numpy()
+            assert np.array_equal(y, want), (combo, call, p.get_option("last_inverse_tuned"))
+            forms.append(p.get_option("last_inverse_tuned"))
+        assert forms[-1] >= 10 and forms[-1] == forms[-2], forms       # decided (tens digit), and stays decided
+        assert len(set(f % 10 for f in forms)) >= 2, forms             # more than one form was tried on the way
+        # another shape starts over; a forced form is not tuned
+        p.isdft(dd[..., : n - 16, :].contiguous())
+        assert p.get_option("last_inverse_tuned") < 10
+        p.set_option("inverse_rows", 16)
+        before = p.get_option("last_inverse_tuned")
+        assert np.array_equal(p.isdft(dd).cpu().numpy(), want) and p.get_option("last_inverse_tuned") == before
 
 
 @pytest.mark.parametrize("m,n,latency,channels", [(1024, 30000, 1.0, 1), (1000, 12000, 0.5, 1), (77, 50000, 1.0, 1), (2050, 3000, 1.0, 1), (256, 9000, 0.7, 3)])
