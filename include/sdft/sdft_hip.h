@@ -184,11 +184,11 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
    "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB
                        and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back), 0 / 1
-   "inverse_tune"  1 (default) = long synthesis calls (from 64 Ki rows) find the fastest of their bit-identical forms -- 16 or 32 rows
+   "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
                        per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof -- on the host's own
                        calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape
                        (which form wins differs from lease to lease by a few per cent either way); 0 = the static choice.
-                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B)
+                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B, 4 8 rows, 5 4 rows)
    "xcd_map"       1 (default) = every XCD takes a contiguous eighth of an analysis launch's (channel, chunk) workgroups, so that the
                        workgroups that run at the same time are spread over the whole matrix (n = 1e6: 77.6 -> 83.9 % of the HBM peak)
    "copy_threads"  2 (default) = worker threads of the copies between the caller's host memory and the plan's pinned slots (the host's

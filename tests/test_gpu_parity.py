@@ -370,10 +370,11 @@ def test_inverse_is_bit_identical(combo, latency):
         assert np.array_equal(yb[c], refs[c].isdft(db[c]))
 
 
-@pytest.mark.parametrize("combo,m,n,channels", [("f32f64", 1024, 70000, 1), ("f64f64", 1000, 66000, 1), ("f32f32", 2048, 66000, 1), ("f32f64", 256, 9000, 8)])
+@pytest.mark.parametrize("combo,m,n,channels", [("f32f64", 1024, 70000, 1), ("f64f64", 1000, 66000, 1), ("f32f32", 2048, 66000, 1), ("f32f64", 256, 9000, 8),
+                                                ("f64f64", 1000, 20000, 1), ("f32f64", 512, 30000, 1)])
 def test_long_synthesis_calls_find_their_form_and_keep_their_bits(combo, m, n, channels):
-    """Round 5: from 64 Ki rows on the plan measures the bit-identical streaming forms of the synthesis (16 / 32 rows per wave,
-    256- / 512-byte row segments, the tree sum with the rounding-interval proof) on the host's own calls and keeps the
+    """Round 5: from 8 Ki rows on the plan measures the bit-identical streaming forms of the synthesis (4 / 8 / 16 / 32 rows per
+    wave, 256- / 512-byte row segments, the tree sum with the rounding-interval proof) on the host's own calls and keeps the
     fastest (logic::FormTuner).  Every call of the trial phase and after it gives the same samples -- the reference's."""
     import torch
     td, fd, fdx = O.combo_types(combo)
