@@ -40,7 +40,9 @@ int         sdft_hip_check_expr(const char* expr, const char* arch);
 /* measurement aid: average ms of a store-only kernel over `bytes` of device memory.
    pattern 0 = linear fill; pattern 1 = the forward kernel's tiling (rows of `row_slots` 16-byte
    slots, `lanes` slots per wave, `chunk_len` consecutive rows per wave); pattern 2 = one workgroup per time chunk writing
-   whole rows in lockstep (`lanes` = rows per barrier); pattern 3 = the same with non-temporal stores */
+   whole rows in lockstep (`lanes` = rows per barrier); pattern 3 = the same with non-temporal stores; 4 = every XCD a contiguous
+   eighth of the chunks (what ForwardArgs::xcd_map does in the analysis kernels); 5 = workgroups started at different row phases;
+   6 = both; 100 + R = workgroup b takes the (b / R)-th chunk of region b mod R */
 double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
                                    unsigned chunk_len, int reps);
 /* measurement aid: occupies `cus` CUs (nothing shares them) for `milliseconds` on a stream of its own and returns at once;
@@ -48,6 +50,9 @@ double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigne
 int         sdft_hip_hold_cus(unsigned cus, double milliseconds);
 /* the same for a load-only kernel (16-byte loads, four in flight per thread) */
 double      sdft_hip_load_ceiling(const void* src, size_t bytes, int reps);
+/* ... and for whole rows of `row_slots` 16-byte slots read in step by one workgroup per chunk of `chunk_len` rows
+   (regions = 0: workgroup b -> chunk b; R: regions in turn, as store pattern 100 + R) */
+double      sdft_hip_load_rows_ceiling(const void* src, size_t bytes, unsigned row_slots, unsigned chunk_len, unsigned regions, int reps);
 
 /* ---- batched plans: `channels` independent streams with one launch per call ----------------
    The unit of sharding in the reference is the plan (no shared mutable state, sdft.h:145-182);

@@ -1,25 +1,25 @@
-"""Copies what scripts/r04_profile.sh left under gpurun_out/r04/ into profiles/ (the tracked copies the documents cite) and
+"""Copies what scripts/r05_profile.sh left under gpurun_out/r05/ into profiles/ (the tracked copies the documents cite) and
 rebuilds profiles/hbm_traffic.json (one entry per benchmark workload) from the counter passes.  Touches no document."""
 import csv, glob, json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(R, "gpurun_out", "r04")
+O = os.path.join(R, "gpurun_out", "r05")
 P = os.path.join(R, "profiles")
-for src, dst in (("bench_n1e6_m1024.json", "r04_bench_n1e6_m1024.json"), ("bench_under_rocprof.json", "r04_bench_n1e6_m1024_under_rocprof.json"),
-                 ("trace/bench_kernel_stats.csv", "r04_bench_n1e6_m1024_kernel_stats.csv"),
-                 ("trace_cfg/cfg_kernel_stats.csv", "r04_all_configs_kernel_stats.csv"),
-                 ("configs.md", "r04_configs.md"), ("configs_under_rocprof.md", "r04_configs_under_rocprof.md"),
-                 ("f32_rows_ab.txt", "r04_float_analysis_kernels_ab.txt"), ("held_cus.txt", "r04_kernels_beside_held_cus.txt"),
-                 ("relay_alone.txt", "r04_relay_alone_vs_flow.txt"), ("roundtrip_pattern.txt", "r04_synthesis_after_the_write.txt"),
-                 ("store_ceiling_rows.txt", "r04_store_ceiling_by_row_geometry.txt"), ("north_star_ab.txt", "r04_north_star_n48000_ab.txt")):
+for src, dst in (("bench_n1e6_m1024.json", "r05_bench_n1e6_m1024.json"), ("bench_under_rocprof.json", "r05_bench_n1e6_m1024_under_rocprof.json"),
+                 ("trace/bench_kernel_stats.csv", "r05_bench_n1e6_m1024_kernel_stats.csv"),
+                 ("trace_cfg/cfg_kernel_stats.csv", "r05_all_configs_kernel_stats.csv"),
+                 ("configs.md", "r05_configs.md"), ("configs_under_rocprof.md", "r05_configs_under_rocprof.md"),
+                 ("north_star_ab.txt", "r05_north_star_n48000_ab.txt"), ("hop_parts.txt", "r05_hop_time_parts_session.txt"),
+                 ("host_hop_paths.txt", "r05_host_copy_paths.txt"), ("host_rate.txt", "r05_host_copy_rate.txt"),
+                 ("store_study.txt", "r05_store_ceiling_study_session.txt"), ("xcd_map.txt", "r05_xcd_map_ab_session.txt")):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 # kernel trace of config-3 calls: the relay beside the forward launch (start / end / duration in microseconds from the first row)
 tr = glob.glob(os.path.join(O, "trace_c3", "**", "*kernel_trace.csv"), recursive=True)
 if tr:
-    rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))[-15:]
+    rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))[-18:]
     t0 = int(rows[0]["Start_Timestamp"])
-    with open(os.path.join(P, "r04_config3_kernel_trace.txt"), "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace of scripts/config3_calls.py (m = 4096, Blackman, FD float, n = 262144; synchronous calls): kernel, start us, end us, duration us\n")
+    with open(os.path.join(P, "r05_config2_kernel_trace.txt"), "w") as fh:
+        fh.write("# rocprofv3 --kernel-trace of scripts/config3_calls.py (BASELINE configs[2]: m = 4096, Blackman, FD float, n = 262144; synchronous calls), per launch: kernel, start us, end us, duration us\n")
         for r in rows:
             fh.write("%-72s %10.1f %10.1f %9.1f\n" % (r["Kernel_Name"][:72], (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
@@ -39,14 +39,14 @@ for label, wf, ff, n, channels in (("single", "pmc_w/w_counter_collection.csv", 
     entries.append({"workload": label, "n": n, "m": 1024, "channels": channels, "bytes_per_launch": int(W * 1024 + 2 * F * 1024),
                     "WRITE_SIZE_KiB": W, "FETCH_SIZE_KiB_raw": F, "launches": len(w),
                     "algorithmic_bytes_per_launch": channels * n * (1024 * 16 + 4),
-                    "note": "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over bench.py --no-extras (round 4, forward_rows_kernel "
+                    "note": "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over bench.py --no-extras (round 5, forward_rows_kernel "
                             "dispatches only, average per launch); counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)",
-                    "source": "profiles/r04_bench_pmc.csv"})
-with open(os.path.join(P, "r04_bench_pmc.csv"), "w", newline="") as fh:
+                    "source": "profiles/r05_bench_pmc.csv"})
+with open(os.path.join(P, "r05_bench_pmc.csv"), "w", newline="") as fh:
     wr = csv.writer(fh); wr.writerow(cols); wr.writerows([[x[k] for k in cols] for x in keep])
 json.dump(entries, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
 for e in entries:
     print(e["workload"], "launches", e["launches"], "traffic", e["bytes_per_launch"], "algorithmic", e["algorithmic_bytes_per_launch"], "ratio %.4f" % (e["bytes_per_launch"] / e["algorithmic_bytes_per_launch"]))
-b = json.loads(open(os.path.join(P, "r04_bench_n1e6_m1024.json")).read())
+b = json.loads(open(os.path.join(P, "r05_bench_n1e6_m1024.json")).read())
 print("value", b["value"], "frac", b["roofline"]["frac"], "north star", b["north_star_n48000"]["sync"]["frac_of_peak_wall"], b["north_star_n48000"]["async"]["frac_of_peak_wall"])
 print(json.dumps(b["configs"], indent=1)[:1500])

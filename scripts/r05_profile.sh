@@ -1,10 +1,10 @@
-# Round-4 measurements on one MI355X: bench line, rocprofv3 kernel stats of the headline workload alone, of the bench line's
+# Round-5 measurements on one MI355X (one lease: the numbers of one session belong together): bench line, rocprofv3 kernel stats of the headline workload alone, of the bench line's
 # `configs` block (configs[2], configs[3], single-sample calls) and of every BASELINE shape, a kernel TRACE of config-3 calls
 # (relay beside the forward launch), HBM traffic counters (separate --pmc passes, single and batch workload), probes.
-# Outputs -> gpurun_out/r04/ (copied into profiles/ by scripts/r04_collect.py).
+# Outputs -> gpurun_out/r05/ (copied into profiles/ by scripts/r05_collect.py).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/r05
 mkdir -p $O
 cd $R
 python3 $R/bench.py --steps 20 2>/dev/null | tail -1 > $O/bench_n1e6_m1024.json
@@ -16,10 +16,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wb -o wb -- python3 $R/bench.py --workload batch --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fb -o fb -- python3 $R/bench.py --workload batch --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>&1
 python3 $R/scripts/config_report.py > $O/configs.md 2>/dev/null
-python3 $R/scripts/f32_rows_ab.py > $O/f32_rows_ab.txt 2>/dev/null
-python3 $R/scripts/held_cus_ab.py > $O/held_cus.txt 2>/dev/null
-python3 $R/scripts/relay_alone.py > $O/relay_alone.txt 2>/dev/null
-python3 $R/scripts/roundtrip_pattern.py > $O/roundtrip_pattern.txt 2>/dev/null
-python3 $R/scripts/store_ceiling_rows.py > $O/store_ceiling_rows.txt 2>/dev/null
 python3 $R/scripts/ns_ab.py 2>/dev/null > $O/north_star_ab.txt
+python3 $R/scripts/hop_parts_ab.py 3 2>/dev/null > $O/hop_parts.txt
+python3 $R/scripts/host_hop_paths.py 2>/dev/null > $O/host_hop_paths.txt
+python3 $R/scripts/host_rate.py 2>/dev/null > $O/host_rate.txt
+python3 $R/scripts/store_ceiling_study.py 3 2>/dev/null > $O/store_study.txt
+python3 $R/scripts/xcd_map_ab.py 3 2>/dev/null > $O/xcd_map.txt
 ls -la $O

@@ -1,6 +1,8 @@
-"""Synthesis (reference order, streaming kernel) with the concurrently running waves spread over the whole matrix (option
-inverse_spread = 1) against one moving window of it (0); interleaved, asynchronous calls.
-    python scripts/inverse_spread_ab.py [rounds]"""
+"""Synthesis in the reference's order by form: the plan's own choice on the host's calls (logic::FormTuner, default) against the
+static choice (inverse_tune = 0) and forced forms (rows per wave, bytes per row segment); interleaved, asynchronous calls.
+(Round 5 also measured the waves that run together reading from eight regions of the matrix in turn -- what xcd_map is to the
+analysis: +6 % / +4 % / -5.5 % / -5 % by matrix, profiles/r05_store_ceiling_study.txt; not kept.)
+    python scripts/synthesis_forms_ab.py [rounds]"""
 import sys
 import time
 
@@ -19,9 +21,9 @@ for label, m, n, ch, combo, reps in (("n=1e6 m=1024 f32f64", 1024, 1_000_000, 1,
     cdt = torch.complex128 if esz == 16 else torch.complex64
     d = torch.randn((ch, n, m) if ch > 1 else (n, m), dtype=torch.float32 if esz == 8 else torch.float64, device="cuda").to(cdt)
     plans = []
-    for vl, v, rpi, rows, tune in (("tuned", 0, 4, 0, 1), ("static", 0, 4, 0, 0), ("spread", 1, 4, 0, 0), ("16r 512B", 0, 2, 16, 0), ("16r 256B", 0, 4, 16, 0)) + ((("32r 256B", 0, 4, 32, 0),) if esz == 16 else ()):
+    for vl, v, rpi, rows, tune in (("tuned", 0, 4, 0, 1), ("static", 0, 4, 0, 0), ("16r 512B", 0, 2, 16, 0), ("16r 256B", 0, 4, 16, 0)) + ((("32r 256B", 0, 4, 32, 0),) if esz == 16 else ()):
         p = SDFT(m, "hann", 1.0, combo, channels=ch)
-        p.set_option("async", 1); p.set_option("inverse_spread", v); p.set_option("inverse_rpi", rpi); p.set_option("inverse_rows", rows); p.set_option("inverse_tune", tune)
+        p.set_option("async", 1); p.set_option("inverse_rpi", rpi); p.set_option("inverse_rows", rows); p.set_option("inverse_tune", tune)
         for _ in range(10):
             p.isdft(d)
         y = p.isdft(d)

@@ -68,8 +68,6 @@ template <typename TD, typename FD> struct InverseArgs
   SpectralOp<FD> op;          // applied to every bin on the way in (identity for sdft_isdft_n)
   DoneSignal done;            // inverse_row_kernel only: total = rows
   int nt;                     // loads of the matrix are non-temporal (streamed past the caches: see Plan::opt_inverse_nt)
-  int spread;                 // the waves that run at the same time read row groups spread over the whole matrix (eight regions
-                              // in turn) instead of one moving window of it: what xcd_map is to the analysis (ForwardArgs)
 };
 
 // VERIFY (float samples from double bins): the reference's bits from the tree sum -- the rounding-interval test of
@@ -162,9 +160,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
   // is dirty there: reading the head first makes the cache write the tail back while HBM is being read)
   for (size_t gi = (size_t)blockIdx.x * kWavesPerBlock + wib; gi < ngroups; gi += nwaves)
   {
-    // (spread: wave gi takes the (gi / 8)-th group of region gi % 8 -- a bijection of [0, ngroups) for any count)
-    const size_t gs = a.spread ? (gi % 8) * (ngroups / 8) + ((gi % 8) < (ngroups % 8) ? (gi % 8) : (ngroups % 8)) + gi / 8 : gi;
-    const size_t g = ngroups - 1 - gs;
+    const size_t g = ngroups - 1 - gi;
     const size_t ch = g / ngroups_per_ch;
     const size_t r0 = (g - ch * ngroups_per_ch) * RW;
     const cx<FD>* base = a.in + ch * a.in_stride;

@@ -116,7 +116,9 @@ class Plan
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
   long opt_flag_max = (long)1 << 24;                       // bin-samples up to which a row-group analysis call signals its own completion
-  long opt_self_stamps = 0;                                // development builds (SDFT_SELF_STAMPS): device address of 8 stamp words
+#ifdef SDFT_SELF_STAMPS
+  long opt_self_stamps = 0;                                // development builds: device address of 8 stamp words
+#endif
   long opt_inverse_verify = 1, last_inverse_form = 0;      // launch_inverse
   static constexpr size_t kInverseVerifyMax = 500000;      // rows up to which the tree sum with the rounding-interval proof serves sdft_isdft_n (beyond: the streaming kernel)
   bool rtc_failed = false;                                 // launch_inverse returns void: a failed run-time compilation is reported here
@@ -143,9 +145,6 @@ class Plan
   // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
   // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
   long opt_inverse_nt = -1;
-  // (measured both ways by matrix, scripts/inverse_spread_ab.py: 64 x 48000 x 1024 +6 %, 262144 x 1024 f64f64 +4 %, but 1e6 x 1024
-  // -5.5 %, 600000 x 1024 -5 % -- profiles/r05_store_ceiling_study.txt; off)
-  long opt_inverse_spread = 0;   // InverseArgs::spread
   // long synthesis calls: the fastest of the bit-identical streaming forms is found on the host's own calls (launch_inverse)
   long opt_inverse_tune = 1, last_inverse_tuned = 0;
   logic::FormTuner inv_tune;
@@ -1358,7 +1357,6 @@ class Plan
     {
       const size_t matrix_bytes = channels * n * nbins * sizeof(fdx);
       ia.nt = opt_inverse_nt >= 0 ? (int)(opt_inverse_nt != 0) : (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30));
-      ia.spread = (int)(opt_inverse_spread != 0);
     }
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;

@@ -1,5 +1,5 @@
 """The documents follow the artefacts mechanically (round-3 review, item 6): a number a document quotes from a file under
-profiles/ is written  ⟨number unit · profiles/file⟩  and must be IN that file -- some numeric token of the file, scaled by a
+profiles/ (or from a driver record BENCH_r0N.json) is written  ⟨number unit · profiles/file⟩  and must be IN that file -- some numeric token of the file, scaled by a
 power of 1000 (ns / us / ms, B / KB / MB / GB) or by 100 (fractions quoted as per cent), rounds to the quoted digits.
 Every profiles/ path a document mentions must exist."""
 import os
@@ -9,7 +9,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("scripts", "README.md")]
-CLAIM = re.compile(r"⟨([^⟩·]+)·\s*(profiles/[A-Za-z0-9_./-]+)\s*⟩")
+# a claim cites a file under profiles/ (the builder's sessions) or one of the DRIVER's records at the repository root
+# (BENCH_r0N.json: the line the driver's own run of bench.py produced at the end of round N -- round-4 review, item 10)
+CLAIM = re.compile(r"⟨([^⟩·]+)·\s*((?:profiles/[A-Za-z0-9_./-]+)|(?:BENCH_r\d+\.json))\s*⟩")
 NUMBER = re.compile(r"(?<![A-Za-z0-9_.])[-+]?\d+(?:\.\d+)?(?:[eE][-+]?\d+)?")
 SCALES = [1.0, 1e3, 1e6, 1e9, 1e-3, 1e-6, 1e-9, 100.0, 0.01]
 
@@ -83,6 +85,19 @@ def test_quoted_numbers_are_in_the_files_they_cite():
             if not in_file(q, dec, pool):
                 bad.append((doc, line, value, path, f"{q} not found"))
     assert not bad, bad
+
+
+def test_the_drivers_last_record_is_quoted():
+    """README.md and DESIGN.md put the DRIVER's numbers of the last judged round beside the builder's own (the review found the
+    documents quoting the best box while the driver had seen the worst).  The record of the round in progress appears only
+    after the documents were written, so the newest record or the one before it counts."""
+    records = sorted(f for f in os.listdir(ROOT) if re.fullmatch(r"BENCH_r\d+\.json", f))
+    if not records:
+        pytest.skip("no driver record in this tree")
+    recent = set(records[-2:])
+    for doc in ("README.md", "DESIGN.md"):
+        cited = {path for d, _, _, path in claims() if d == doc and path in recent}
+        assert cited, (doc, sorted(recent))
 
 
 def test_the_checker_catches_a_stale_number(tmp_path):
