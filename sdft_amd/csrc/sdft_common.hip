@@ -1,6 +1,7 @@
 // sdft_common.hip -- untyped part of the C-ABI: error channel, device selection, self test.
 
 #include "sdft_plan.hpp"
+#include "sdft_keyed_once.hpp"
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
@@ -54,10 +55,7 @@ struct Rtc
   decltype(&hiprtcGetCodeSize) code_size = nullptr;
   decltype(&hiprtcGetCode) code = nullptr;
   std::once_flag once;
-  std::map<std::string, hipFunction_t> kernels;            // device | expression | name expression -> function
-  std::set<std::string> in_flight;                         // keys some thread is compiling right now (outside the lock)
-  std::mutex mu;
-  std::condition_variable cv;
+  KeyedOnce<hipFunction_t> kernels;                        // device | expression | name expression -> function (sdft_keyed_once.hpp)
 
   // host threads may arrive together (sdft_hip_check_expr takes no lock): the library is opened exactly once
   bool open()
@@ -127,21 +125,9 @@ bool rtc_compile(const char* expr, const char* name_expr, const char* arch, std:
 bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction_t* fn)
 {
   // The second-long compilation runs OUTSIDE the cache lock (other plans' expression calls go on); a key being compiled is
-  // marked in flight, and a thread that wants the same key waits for that compilation instead of starting its own.
+  // marked in flight, and a thread that wants the same key waits for that compilation instead of starting its own (KeyedOnce).
   const std::string key = std::to_string(device) + "|" + expr + "|" + name_expr;
-  {
-    std::unique_lock<std::mutex> lock(g_rtc.mu);
-    for (;;)
-    {
-      auto it = g_rtc.kernels.find(key);
-      if (it != g_rtc.kernels.end()) { *fn = it->second; return true; }
-      if (!g_rtc.in_flight.count(key)) break;
-      g_rtc.cv.wait(lock);
-    }
-    g_rtc.in_flight.insert(key);
-  }
-  hipFunction_t f = nullptr;
-  const bool ok = [&]() -> bool
+  return g_rtc.kernels.get(key, *fn, [&](hipFunction_t& f) -> bool
   {
     hipDeviceProp_t prop;
     SDFT_TRY(hipGetDeviceProperties(&prop, device));
@@ -153,15 +139,7 @@ bool rtc_kernel(const char* expr, const char* name_expr, int device, hipFunction
     SDFT_TRY(hipModuleLoadData(&module, code.data()));
     SDFT_TRY(hipModuleGetFunction(&f, module, lowered.c_str()));
     return true;
-  }();
-  {
-    std::lock_guard<std::mutex> lock(g_rtc.mu);
-    g_rtc.in_flight.erase(key);
-    if (ok) g_rtc.kernels[key] = f;
-  }
-  g_rtc.cv.notify_all();
-  if (ok) *fn = f;
-  return ok;
+  });
 }
 
 __global__ void lane_selftest_kernel(int* out)

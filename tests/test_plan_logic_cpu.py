@@ -41,6 +41,13 @@ def test_copy_engine_under_tsan(tmp_path):
     assert "all copies arrived" in out
 
 
+def test_run_time_compilation_cache_under_tsan(tmp_path):
+    """sdft_keyed_once.hpp (the cache of run-time-compiled kernels: one compilation per key, outside the lock, same-key callers
+    wait for it) with sixteen threads on eight keys."""
+    out = build_and_run(tmp_path, "keyed_once_test.cpp", "thread")
+    assert "every key made once" in out
+
+
 def test_copy_engine_under_asan_ubsan(tmp_path):
     out = build_and_run(tmp_path, "copy_engine_test.cpp", "address,undefined", args=(60,))
     assert "all copies arrived" in out
@@ -49,7 +56,7 @@ def test_copy_engine_under_asan_ubsan(tmp_path):
 def test_logic_header_has_no_hip_dependency():
     """The point of the split: these two headers compile without the HIP toolchain (the compile steps above prove it for the
     tests' include set; this pins the source text)."""
-    for name in ("sdft_plan_logic.hpp", "sdft_copy_engine.hpp"):
+    for name in ("sdft_plan_logic.hpp", "sdft_copy_engine.hpp", "sdft_keyed_once.hpp"):
         text = open(os.path.join(CSRC, name)).read()
         assert "#include <hip" not in text and "hipStream" not in text and "__global__" not in text, name
     plan = open(os.path.join(CSRC, "sdft_plan.hpp")).read()
