@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--cpu-samples", type=int, default=200000)
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements outside the timed regions")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the many-core CPU baseline of the batch share")
+    ap.add_argument("--no-placement", action="store_true", help="take the output matrix as the first allocation comes (no store-only probe of candidates)")
+    ap.add_argument("--placement-candidates", type=int, default=6)
     return ap.parse_args()
 
 
@@ -450,6 +452,41 @@ def launch_ranks(args) -> int:
     return r.returncode
 
 
+def place_matrix(torch, shape, cdt, m, esz, candidates):
+    """The output matrix, in memory that streams well.  Round 5 found that how fast a large buffer can be WRITTEN depends on which
+    physical memory backs it: of twelve 16.4 GB buffers allocated one after the other in one process, seven take the row-lockstep
+    store stream at 6.4-7.1 TB/s, four at 5.85 and one in between, the same ones on every pass; loads do not care
+    (profiles/r05_buffer_placement.txt) -- a property
+    of the allocation, not of the kernel (which reaches 96-98 % of either).  A host that cares allocates a few candidates, probes each
+    with a store-only kernel (2 x 2.5 ms) and keeps the best; this function does exactly that, UNTIMED and before anything is measured,
+    and the line says so (`buffer_placement`).  `--no-placement` (or one candidate) takes the first allocation as it comes."""
+    import math
+    from sdft_amd import capi
+    lib = capi.load()
+    nbytes = math.prod(shape) * esz
+    probe_ok = esz == 16 and m % 64 == 0 and m <= 1024 and candidates > 1
+    kept, rates = [], []
+    for i in range(max(1, candidates) if probe_ok else 1):
+        free, _ = torch.cuda.mem_get_info()
+        if i > 0 and free < nbytes * 1.1:
+            break
+        t = torch.empty(shape, dtype=cdt, device="cuda")
+        kept.append(t)
+        if not probe_ok:
+            break
+        torch.cuda.synchronize()
+        ms = lib.sdft_hip_store_ceiling(t.data_ptr(), nbytes, 4, m, 8, 1960, 2)
+        torch.cuda.synchronize()
+        rates.append(round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0)
+    best = max(range(len(kept)), key=lambda i: rates[i]) if rates else 0
+    out = kept[best]
+    del kept, t
+    torch.cuda.empty_cache()
+    info = {"policy": "best of up to %d allocations by a store-only probe, untimed, before the warm-up (--no-placement: the first allocation)" % candidates,
+            "probed_store_only_gbs": rates, "chosen": best} if probe_ok else {"policy": "first allocation (no probe for this shape)" if candidates > 1 else "first allocation (--no-placement)"}
+    return out, info
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -510,7 +547,7 @@ def main():
         xh = np.stack([sine_sweep(n, channel=c, channels=channels_total, dtype=td) for c in range(first, first + count)])
     x = torch.from_numpy(xh).cuda()
     shape = (n, m) if count == 1 else (count, n, m)
-    out = torch.empty(shape, dtype=cdt, device="cuda")
+    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates)
 
     stream = torch.cuda.Stream()
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
@@ -617,6 +654,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64" if esz == 16 else "f32",
         "data": "synthetic",
+        "buffer_placement": placement,
         "config": {
             "workload": name,
             "channels_total": channels_total,

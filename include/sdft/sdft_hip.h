@@ -45,6 +45,12 @@ int         sdft_hip_check_expr(const char* expr, const char* arch);
    6 = both; 100 + R = workgroup b takes the (b / R)-th chunk of region b mod R */
 double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row_slots, unsigned lanes,
                                    unsigned chunk_len, int reps);
+/* Device memory for a DFT matrix, chosen for how fast it can be written: which physical memory backs a large allocation decides what
+   the analysis' store stream reaches in it (5.85, 6.4 or 7.1 TB/s for 16 GB buffers of one process; reads do not care) and nothing
+   can move a buffer afterwards.  Allocates up to `candidates` buffers of `bytes` (as many as fit beside each other), probes each with
+   the store-only kernel above (2 launches), keeps the best and frees the others; *gbs (may be NULL) = the kept buffer's probe rate.
+   Free with hipFree.  NULL on failure. */
+void*       sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs);
 /* measurement aid: occupies `cus` CUs (nothing shares them) for `milliseconds` on a stream of its own and returns at once;
    cus = 0 waits for the release.  What a kernel keeps of its speed beside a kernel that holds part of the chip. */
 int         sdft_hip_hold_cus(unsigned cus, double milliseconds);

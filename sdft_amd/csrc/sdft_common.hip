@@ -422,6 +422,43 @@ double sdft_hip_load_rows_ceiling(const void* src, size_t bytes, unsigned row_sl
   return ms < 0.f ? -1.0 : (double)ms / (reps > 0 ? reps : 1);
 }
 
+// Device memory for a DFT matrix, chosen for how fast it can be WRITTEN.  Which physical memory backs a large allocation decides
+// what the row-lockstep store stream reaches in it -- 5.85, 6.4 or 7.1 TB/s for 16 GB buffers of one process, the same buffer the same
+// rate on every pass, reads unaffected (profiles/r05_buffer_placement.txt) -- and neither the runtime nor the library can move a
+// buffer afterwards.  So: up to `candidates` allocations of `bytes` (as many as fit beside each other), each probed with the
+// store-only kernel of the analysis' shape (rows of 16 KiB, every XCD a contiguous eighth: 2 launches), the best kept, the others
+// freed.  *gbs (may be NULL) receives the kept buffer's probe rate.  Free with hipFree.  NULL on failure (sdft_hip_last_error).
+void* sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs)
+{
+  using namespace sdfthip;
+  if (bytes == 0) return nullptr;
+  void* best = nullptr;
+  double best_ms = 0.0;
+  std::vector<void*> others;
+  const int tries = candidates < 1 ? 1 : (candidates > 16 ? 16 : candidates);
+  for (int i = 0; i < tries; ++i)
+  {
+    size_t free_b = 0, total_b = 0;
+    if (i > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 3))) { (void)hipGetLastError(); break; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    double ms = 0.0;
+    if (tries > 1 && bytes >= ((size_t)64 << 20))
+    {
+      const size_t rows = bytes / 16384;
+      const unsigned chunk_len = (unsigned)std::max<size_t>(8, (rows + 510) / 511);       // two rounds of the chip, as the analysis cuts time
+      ms = sdft_hip_store_ceiling(p, rows * 16384, 4, 1024, 8, chunk_len, 2);
+      if (ms <= 0.0) ms = 1e30;
+    }
+    if (!best || ms < best_ms) { if (best) others.push_back(best); best = p; best_ms = ms; }
+    else others.push_back(p);
+  }
+  for (void* p : others) (void)hipFree(p);
+  if (!best) { set_error("sdft_hip_malloc_matrix", "out of device memory"); return nullptr; }
+  if (gbs) *gbs = best_ms > 0.0 && best_ms < 1e29 ? (double)((bytes / 16384) * 16384) / (best_ms * 1e-3) / 1e9 : 0.0;
+  return best;
+}
+
 // NULL when no error has been recorded on this thread since the last clear
 const char* sdft_hip_last_error(void) { return sdfthip::g_has_error ? sdfthip::g_error.c_str() : nullptr; }
 void sdft_hip_clear_error(void) { sdfthip::g_has_error = false; sdfthip::g_error.clear(); }

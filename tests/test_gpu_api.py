@@ -903,6 +903,43 @@ def test_host_pointer_calls_never_leave_the_plans_stream():
     assert rel(res[1], r2.sdft(xl)) <= 1e-11
 
 
+def test_matrix_memory_chosen_for_its_store_rate():
+    """sdft_hip_malloc_matrix (round 5): up to K allocations, each probed with the store-only kernel of the analysis' shape, the best
+    kept and the others freed.  The pointer is ordinary device memory: sdft_sdft_n writes the reference's rows into it, hipFree
+    releases it, and nothing leaks."""
+    import torch
+    from sdft_amd import capi
+    from sdft_amd.sdft import SDFT
+    lib = capi.load()
+    hip = C.CDLL(capi.hip_runtime)
+    hip.hipFree.argtypes = [C.c_void_p]
+    m, n = 1024, 6000                                          # 98 MB: above the 64 MiB below which nothing is probed
+    nbytes = n * m * 16
+    free0, _ = torch.cuda.mem_get_info()
+    gbs = C.c_double(0.0)
+    ptr = lib.sdft_hip_malloc_matrix(nbytes, 3, C.byref(gbs))
+    assert ptr and gbs.value > 100.0                           # (a probe of 98 MB is launch-bound: any plausible rate)
+    free1, _ = torch.cuda.mem_get_info()
+    ptr2 = lib.sdft_hip_malloc_matrix(nbytes, 3, None)         # (the first call also pays the runtime's own first allocations)
+    free2, _ = torch.cuda.mem_get_info()
+    assert ptr2 and ptr2 != ptr and free1 - free2 < 1.5 * nbytes and free0 - free1 < 3 * nbytes      # the losing candidates are gone
+    assert hip.hipFree(C.c_void_p(ptr2)) == 0
+    x = noise(n, seed=3)
+    want = O.best(m, "hann", 1.0, "f32f64").sdft(x)
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        xd = torch.from_numpy(x).cuda()
+        p.api.sdft_n(p._p, n, C.c_void_p(xd.data_ptr()), C.c_void_p(ptr)); p.api.check()
+        got = np.empty((n, m), dtype=np.complex128)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+    assert rel(got, want) <= 1e-11
+    assert hip.hipFree(C.c_void_p(ptr)) == 0
+    small = lib.sdft_hip_malloc_matrix(4096, 4, None)          # small buffers: one allocation, no probe
+    assert small and hip.hipFree(C.c_void_p(small)) == 0
+    assert lib.sdft_hip_malloc_matrix(1 << 50, 2, None) is None and b"out of device memory" in lib.sdft_hip_last_error()
+    lib.sdft_hip_clear_error()
+
+
 def test_driver_entry_point_smoke():
     """__graft_entry__.smoke() is what the driver runs on a fresh box before the bench: it has to pass in the suite too
     (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""
