@@ -205,6 +205,9 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "copy_threads"  2 (default) = worker threads of the copies between the caller's host memory and the plan's pinned slots (the host's
                        copy of one piece overlaps the DMA of the next; a hop-sized matrix is copied by the workers and the caller
                        together); 0 = the calling thread alone
+   "copy_streams"  2 (default) = the DMAs of such copies of 16 MiB and more alternate between the plan's stream and a second stream
+                       of the plan (every DMA costs ~15 us beside its bytes; two queues fill each other's gaps: 50 -> 54.5 GB/s);
+                       to what the caller queues before and after, the copy stays one operation of the plan's stream; 1 = one stream
    "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
                        result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
    "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a

@@ -171,16 +171,63 @@ class HostIo
   static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
   // the device side of the copy engine: DMAs on the plan's stream, an event per slot
+  // Copies of 16 MiB and more alternate between the plan's stream and a stream of their own: every DMA costs ~15 us beside
+  // its bytes (completion of one, start of the next), and two queues fill each other's gaps: 1.6 GB 50 -> 54.5 GB/s (the
+  // runtime's own path: 55), 31 MiB 925 -> 810 us, 19 MiB 600 -> 555; no gain below (profiles/r05_host_copy_streams.txt).
+  // The second stream starts behind everything the plan's stream holds (fork) and the plan's stream continues behind the
+  // second one's copies (join): to the work before and after it, the copy is still one operation on the plan's stream.
   struct HipDev
   {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, aux = nullptr, last = nullptr;
     hipEvent_t ev[kPinSlots] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool recorded[kPinSlots] = {};
-    bool dma_to_device(void* dst, const void* slot, size_t len) { SDFT_TRY(hipMemcpyAsync(dst, slot, len, hipMemcpyHostToDevice, stream)); return true; }
-    bool dma_to_host(void* slot, const void* src, size_t len) { SDFT_TRY(hipMemcpyAsync(slot, src, len, hipMemcpyDeviceToHost, stream)); return true; }
-    bool record(unsigned slot) { SDFT_TRY(hipEventRecord(ev[slot], stream)); recorded[slot] = true; return true; }
+    bool two = false;                                        // this copy uses both streams
+    unsigned turn = 0;
+    hipStream_t next_stream() { last = (two && (turn++ & 1u)) ? aux : stream; return last; }
+    bool dma_to_device(void* dst, const void* slot, size_t len) { SDFT_TRY(hipMemcpyAsync(dst, slot, len, hipMemcpyHostToDevice, next_stream())); return true; }
+    bool dma_to_host(void* slot, const void* src, size_t len) { SDFT_TRY(hipMemcpyAsync(slot, src, len, hipMemcpyDeviceToHost, next_stream())); return true; }
+    bool record(unsigned slot) { SDFT_TRY(hipEventRecord(ev[slot], last ? last : stream)); recorded[slot] = true; return true; }   // (right after the slot's DMA, same thread)
     bool wait(unsigned slot) { if (recorded[slot]) SDFT_TRY(hipEventSynchronize(ev[slot])); return true; }      // (any thread)
+    bool fork(hipStream_t s, bool both)
+    {
+      stream = s; last = s; turn = 0; two = false;
+      if (!both) return true;
+      if (!aux)
+      {
+        hipStream_t ns = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess)
+        {
+          (void)hipGetLastError();
+          if (e0) (void)hipEventDestroy(e0);
+          if (ns) (void)hipStreamDestroy(ns);
+          return true;                                       // (one stream then)
+        }
+        aux = ns; ev_fork = e0; ev_join = e1;
+      }
+      SDFT_TRY(hipEventRecord(ev_fork, stream));
+      SDFT_TRY(hipStreamWaitEvent(aux, ev_fork, 0));
+      two = true;
+      return true;
+    }
+    bool join()
+    {
+      if (!two) return true;
+      two = false;
+      SDFT_TRY(hipEventRecord(ev_join, aux));
+      SDFT_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+      return true;
+    }
+    void destroy_aux()
+    {
+      if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
+      if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+      if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+    }
   };
+  long opt_copy_streams = 2;                                 // copies from 16 MiB on: 2 = alternate between the plan's stream and a second one, 1 = the plan's stream only
+  static constexpr size_t kTwoStreamBytes = (size_t)16 << 20;
   HipDev dev;
   CopyPool pool;
 
@@ -226,6 +273,7 @@ class HostIo
       if (dev.ev[k]) { if (dev.recorded[k]) (void)hipEventSynchronize(dev.ev[k]); (void)hipEventDestroy(dev.ev[k]); dev.ev[k] = nullptr; }
       dev.recorded[k] = false;
     }
+    dev.destroy_aux();
     free_pin_pages();
     (void)hipGetLastError();
   }
@@ -254,10 +302,11 @@ class HostIo
       return true;
     }
     ++pin_copies;
-    dev.stream = stream;
     size_t piece; char* mem = slots_for(bytes, piece);
+    if (!dev.fork(stream, opt_copy_streams >= 2 && bytes >= kTwoStreamBytes)) return false;
     PieceCopier<HipDev> copier(dev, bytes > piece ? workers() : nullptr, mem, piece, kPinSlots);
-    return copier.to_device(dst, src, bytes);                // the pieces still in flight are waited for before their slots' next use
+    const bool ok = copier.to_device(dst, src, bytes);       // the pieces still in flight are waited for before their slots' next use
+    return dev.join() && ok;                                 // (what follows on the plan's stream follows the second stream's copies too)
   }
   bool to_host(void* dst, const void* src, size_t bytes, hipStream_t stream)
   {
@@ -268,10 +317,11 @@ class HostIo
       return true;
     }
     ++pin_copies;
-    dev.stream = stream;
     size_t piece; char* mem = slots_for(bytes, piece);
+    if (!dev.fork(stream, opt_copy_streams >= 2 && bytes >= kTwoStreamBytes)) return false;
     PieceCopier<HipDev> copier(dev, bytes > piece ? workers() : nullptr, mem, piece, kPinSlots);
-    return copier.to_host(dst, src, bytes);
+    const bool ok = copier.to_host(dst, src, bytes);         // (every piece drained: nothing left on either stream)
+    return dev.join() && ok;
   }
 };
 

@@ -945,3 +945,34 @@ def test_driver_entry_point_smoke():
     (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""
     import __graft_entry__ as entry
     entry.smoke()
+
+
+@pytest.mark.gpu
+def test_long_host_copies_on_two_dma_streams_are_the_same_calls():
+    """Copies of 16 MiB and more between the caller's host memory and the device alternate their DMAs between the plan's stream
+    and a second one (option copy_streams = 2, the default).  To what is queued before and after, the copy is still one
+    operation of the plan's stream: a matrix analysed into host memory, synthesised from host memory, and a kernel that
+    follows a host -> device copy at once (asynchronous plan) give the bits of the one-stream path (copy_streams = 1)."""
+    from sdft_amd.sdft import SDFT
+    m, n = 1024, 2500                                           # 39 MiB per matrix: pieces of the ring in flight on both streams
+    x = noise(n, seed=321)
+    res = {}
+    for streams in (2, 1):
+        with SDFT(m, "hann", 1.0, "f32f64") as p:
+            p.set_option("copy_streams", streams)
+            assert p.get_option("copy_streams") == streams
+            out = np.zeros((n, m), dtype=np.complex128)
+            y = np.zeros(n, dtype=np.float32)
+            y2 = np.zeros(n, dtype=np.float32)
+            p.api.sdft_n(p._p, n, C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data)); p.api.check()      # device -> host, 39 MiB
+            p.api.isdft_n(p._p, n, C.c_void_p(out.ctypes.data), C.c_void_p(y.ctypes.data)); p.api.check()      # host -> device, then the kernel
+            p.set_option("async", 1)
+            p.api.isdft_n(p._p, n, C.c_void_p(out.ctypes.data), C.c_void_p(y2.ctypes.data)); p.api.check()     # the same with nothing waiting in between
+            p.synchronize()
+            res[streams] = (out.copy(), y.copy(), y2.copy())
+    for a, b in zip(res[2], res[1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.array_equal(res[2][1], res[2][2])
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    want = ref.sdft(x)
+    assert rel(res[2][0], want) <= 1e-9 and rel(res[2][1], ref.isdft(want)) <= 1e-6
