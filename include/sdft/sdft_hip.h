@@ -199,7 +199,12 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof -- on the host's own
                        calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape
                        (which form wins differs from lease to lease by a few per cent either way); 0 = the static choice.
-                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B, 4 8 rows, 5 4 rows)
+                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B, 4 8 rows, 5 4 rows,
+                       6 whole rows in step)
+   "inverse_step"  0 (default) = float samples from double bins at latency 1: the form that reads whole rows of a chunk of the matrix in
+                       step (one workgroup per chunk, tree sums with the rounding-interval proof; 6.55-6.66 TB/s against 6.2 for the
+                       streaming forms on matrices of 8 GB and more) is the static choice from 6 GB on and a candidate of the tuner
+                       below; 1 = always where it applies, -1 = never.  Same bits either way.
    "xcd_map"       1 (default) = every XCD takes a contiguous eighth of an analysis launch's (channel, chunk) workgroups, so that the
                        workgroups that run at the same time are spread over the whole matrix (n = 1e6: 77.6 -> 83.9 % of the HBM peak)
    "copy_threads"  2 (default) = worker threads of the copies between the caller's host memory and the plan's pinned slots (the host's

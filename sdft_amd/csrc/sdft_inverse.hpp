@@ -126,6 +126,167 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
 }
 
 // ------------------------------------------------------------------------------------------
+// K2 (rows in step; round 5)  float samples from double bins, long calls.  The streaming forms read the matrix at 6.1 TB/s;
+// a load-only kernel whose workgroups each read WHOLE ROWS of a contiguous chunk of the matrix, one after the other, with
+// non-temporal 16-byte loads reaches 6.7-7.0 (scripts/load_forms_probe.hip, profiles/r05_load_forms.txt) -- the shape the
+// analysis writes in.  So here a workgroup of N/64 waves owns a chunk of consecutive rows, every lane ONE bin of every row
+// (its synthesis twiddle stays in registers), G rows in flight; the terms of a row meet in a tree sum -- lanes, then the
+// eight sums of a group (G sums, G sums of magnitudes) transposed through the wave in 10 exchanges instead of 48, then
+// the waves' partial sums through LDS -- and the rounding-interval proof of inverse_kernel<VERIFY> decides the sample:
+// the tree sum and 2.5e-16 * (N + 64) * sum|term| bound the reference's ordered sum (sdft.h:641-651) whatever the tree; when
+// both ends of the interval round to the same float that float is the reference's, else the row is read again and added
+// in ascending bin order by one wave.  Same bits as every other form.
+// ------------------------------------------------------------------------------------------
+// J: bins per lane (1: rows of up to 1024 bins, 64 registers, two workgroups of 16 waves to a CU; 2: up to 2048 bins)
+template <typename TD, typename FD, bool LAT1, int J, int G = 4>
+SDFT_D void inverse_rows_body(const InverseArgs<TD, FD>& a, unsigned chunk_len)
+{
+  static_assert(sizeof(TD) == 4 && sizeof(FD) == 8, "the interval test needs a rounding to hide behind");
+  static_assert(LAT1, "latency 1 only: the term of a bin is +-re, one register per bin in flight");
+  static_assert(G == 4, "the transposed reduction below is written for four rows");
+  static_assert(J == 1 || J == 2, "one or two bins per lane");
+  constexpr int SG = 16;                                   // groups between two barriers (64 rows: the waves drift that far apart)
+  __shared__ FD red[2][SG * G][2][kRowWavesMax];           // [buffer][row of the super-group][sum | sum of magnitudes][wave]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const size_t rows = (size_t)a.channels * a.n;
+  // chunks are taken from the END of the matrix first (what the analysis wrote last still sits in the Infinity Cache)
+  const size_t nchunks = (rows + chunk_len - 1) / chunk_len;
+  const size_t cidx = nchunks - 1 - blockIdx.x;
+  const size_t r0 = cidx * (size_t)chunk_len;
+  const size_t r1 = r0 + chunk_len < rows ? r0 + chunk_len : rows;
+
+  unsigned kb[J]; bool live[J];
+  FD sgn[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+  {
+    kb[j] = threadIdx.x + (unsigned)j * blockDim.x;
+    live[j] = kb[j] < a.nbins;
+    sgn[j] = (kb[j] & 1u) ? (FD)(-1) : (FD)(+1);
+  }
+  auto row_of = [&](size_t r) -> const cx<FD>* { const size_t ch = r / a.n, t = r - ch * a.n; return a.in + ch * a.in_stride + t * (size_t)a.nbins; };
+  auto fetch = [&](size_t r, cx<FD> (&x)[G][J])
+  {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+      const size_t rr = r + g < r1 ? r + g : r1 - 1;       // (past the chunk: the last row again, its sum is not used)
+      const cx<FD>* row = row_of(rr);
+#pragma unroll
+      for (int j = 0; j < J; ++j) x[g][j] = live[j] ? load_bin(row + kb[j], 1) : cmake<FD>((FD)0, (FD)0);
+    }
+  };
+  auto term = [&](const cx<FD>& v, int j) -> FD { return v.re * sgn[j]; };             // sdft.h:643
+
+  cx<FD> xa[G][J], xb[G][J], xc[G][J];                     // a ring of three groups: two in flight while one is summed
+  int buf = 0;
+  unsigned slot = 0;                                       // group of the super-group
+  // the sums of the group at row r (in x) and the samples they decide
+  auto finish = [&](size_t r, const cx<FD> (&x)[G][J])
+  {
+    FD v[2 * G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+      const FD t0 = term(x[g][0], 0);                     // (a bin past N-1 holds +0)
+      v[g] = t0; v[G + g] = __builtin_fabs(t0);
+      if constexpr (J == 2) { const FD t1 = term(x[g][1], 1); v[g] += t1; v[G + g] += __builtin_fabs(t1); }
+    }
+    // eight sums over the 64 lanes, transposed: after the exchange with lane ^ 32 a lane keeps four of them, after ^ 16 two,
+    // after ^ 8 one -- value (lane >> 3) -- which the last three exchanges complete
+    FD w4[4], w2[2], w1;
+    {
+      const bool hi = (lane & 32) != 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const FD send = hi ? v[i] : v[i + 4], keep = hi ? v[i + 4] : v[i]; w4[i] = keep + __shfl_xor(send, 32, 64); }
+    }
+    {
+      const bool hi = (lane & 16) != 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const FD send = hi ? w4[i] : w4[i + 2], keep = hi ? w4[i + 2] : w4[i]; w2[i] = keep + __shfl_xor(send, 16, 64); }
+    }
+    {
+      const bool hi = (lane & 8) != 0;
+      const FD send = hi ? w2[0] : w2[1], keep = hi ? w2[1] : w2[0];
+      w1 = keep + __shfl_xor(send, 8, 64);
+    }
+    w1 += __shfl_xor(w1, 4, 64);
+    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    // value index = lane >> 3 (bits 5, 4, 3 chose i of 4, i of 2, i of 1): 0 .. 3 the sums of rows 0 .. 3, 4 .. 7 their magnitudes
+    if ((lane & 7) == 0) red[buf][slot * G + ((lane >> 3) & 3)][lane >> 5][wave] = w1;
+    ++slot;
+    if (slot < (unsigned)SG && r + G < r1) return;
+    // ---- every SG groups (and at the chunk's end): the waves' partial sums meet ----
+    __syncthreads();
+    const unsigned nrows = slot * G;                       // rows of this super-group (the last group may reach past the chunk)
+    const size_t rs = r + G - nrows;                       // its first row
+    for (unsigned q = (unsigned)wave; q < nrows; q += (unsigned)nwaves)
+    {
+      const size_t rr = rs + q;
+      if (rr >= r1) break;
+      // lanes 0 .. 15: the waves' sums of the row, lanes 16 .. 31: their magnitudes (waves past nwaves: +0)
+      const int wsrc = lane & 15;
+      FD qv = (lane < 32 && wsrc < nwaves) ? red[buf][q][lane >> 4][wsrc] : (FD)0;
+      qv += __shfl_xor(qv, 8, 64); qv += __shfl_xor(qv, 4, 64); qv += __shfl_xor(qv, 2, 64); qv += __shfl_xor(qv, 1, 64);
+      const FD sum = __shfl(qv, 0, 64), all = __shfl(qv, 16, 64);
+      const FD e = all * ((FD)2.5e-16 * (FD)(a.nbins + 2 * kWave));
+      const TD ylo = (TD)((sum - e) * a.sweight), yhi = (TD)((sum + e) * a.sweight);
+      TD out = ylo;
+      if (!(ylo == yhi))                                   // wave-uniform
+      {
+        const cx<FD>* row = row_of(rr);
+        FD ordered = (FD)0;
+        for (unsigned k0 = 0; k0 < a.nbins; k0 += kWave)
+        {
+          const unsigned k = k0 + (unsigned)lane;
+          FD tv = (FD)0;
+          if (k < a.nbins)
+          {
+            tv = row[k].re * ((k & 1u) ? (FD)(-1) : (FD)(+1));
+          }
+          const int lo = __double2loint(tv), hi2 = __double2hiint(tv);
+          const unsigned cnt = a.nbins - k0 < (unsigned)kWave ? a.nbins - k0 : (unsigned)kWave;
+          for (unsigned jj = 0; jj < cnt; ++jj)            // sdft.h:641-651: one accumulator, ascending bins
+            ordered += __hiloint2double(__builtin_amdgcn_readlane(hi2, (int)jj), __builtin_amdgcn_readlane(lo, (int)jj));
+        }
+        out = (TD)(ordered * a.sweight);
+      }
+      if (lane == 0) { const size_t ch = rr / a.n, t = rr - ch * a.n; a.y[ch * a.y_stride + t] = out; }
+    }
+    slot = 0;
+    buf ^= 1;                                              // (the other buffer is written next: its readers pass the next barrier first)
+  };
+  fetch(r0, xa);
+  if (r0 + G < r1) fetch(r0 + G, xb);
+  for (size_t r = r0; r < r1; r += 3 * G)                  // (all quantities wave-uniform and the same in every wave)
+  {
+    if (r + 2 * G < r1) fetch(r + 2 * G, xc);
+    finish(r, xa);
+    if (r + G >= r1) break;
+    if (r + 3 * G < r1) fetch(r + 3 * G, xa);
+    finish(r + G, xb);
+    if (r + 2 * G >= r1) break;
+    if (r + 4 * G < r1) fetch(r + 4 * G, xb);
+    finish(r + 2 * G, xc);
+  }
+}
+
+// (one bin per lane: held to 64 registers, so that two workgroups of 16 waves share a CU -- 8 waves per SIMD)
+template <typename TD, typename FD, bool LAT1>
+__global__ __launch_bounds__(kWave * kRowWavesMax) __attribute__((amdgpu_waves_per_eu(8, 8))) void inverse_rows1_kernel(InverseArgs<TD, FD> a, unsigned chunk_len)
+{
+  inverse_rows_body<TD, FD, LAT1, 1>(a, chunk_len);
+}
+template <typename TD, typename FD, bool LAT1>
+__global__ __launch_bounds__(kWave * kRowWavesMax) void inverse_rows2_kernel(InverseArgs<TD, FD> a, unsigned chunk_len)
+{
+  inverse_rows_body<TD, FD, LAT1, 2>(a, chunk_len);
+}
+
+// ------------------------------------------------------------------------------------------
 // K2 (exact order)  inverse with the reference's summation order (sdft.h:641-651: one accumulator
 // per row, bins added in ascending order), at streaming bandwidth: a wave owns RW consecutive rows
 // and, in the summation phase, lane r adds row r's terms strictly in bin order.  Tiles of RW rows x

@@ -469,6 +469,10 @@ def test_rows_on_a_rounding_boundary(m, latency):
         assert p.get_option("last_inverse_form") == 2 and np.array_equal(got, wbig)                # verified tree sum
         p.set_option("inverse_verify", 0)
         assert np.array_equal(p.isdft(torch.from_numpy(big).cuda()).cpu().numpy(), wbig)           # streaming kernel
+        if latency == 1.0:
+            p.set_option("inverse_verify", 1); p.set_option("inverse_step", 1)
+            got = p.isdft(torch.from_numpy(big).cuda()).cpu().numpy()
+            assert p.get_option("last_inverse_form") == 3 and np.array_equal(got, wbig)            # whole rows in step (round 5)
 
 
 @pytest.mark.parametrize("combo,m,opts", [("f32f64", 2500, {"carry": 0, "chunk": 256}), ("f32f64", 2500, {"carry": 1, "chunk": 96, "segments": 3}),
@@ -748,3 +752,36 @@ def test_streaming_loads_change_no_bit(combo, m, n):
         with make(m, "hann", 0.5, combo, inverse_nt=nt) as p:
             outs.append(p.isdft(dd).cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,channels", [(1024, 70000, 1), (1000, 9001, 1), (2048, 5003, 2), (320, 20001, 3), (64, 70, 1), (1536, 4097, 1)])
+def test_synthesis_by_whole_rows_in_step_keeps_the_bits(m, n, channels):
+    """Round 5: float samples from double bins at latency 1 can be synthesised by workgroups that read WHOLE ROWS of a chunk of the
+    matrix in step (inverse_rows_body: one bin per lane, tree sums through the wave and through LDS, the rounding-interval proof,
+    rows on a rounding boundary added again in the reference's order).  Forced (inverse_step = 1) on shapes that exercise one and
+    two bins per lane, partly filled waves, ragged chunk ends, channels, and a matrix of 64 rows: the bits of the streaming form
+    and of the reference."""
+    import torch
+    x = noise(n * channels, seed=400 + m).reshape(channels, n) if channels > 1 else noise(n, seed=400 + m)
+    with make(m, "hann", 1.0, "f32f64", channels=channels) as p:
+        d = p.sdft(torch.from_numpy(x).cuda())
+        p.set_option("inverse_step", -1); p.set_option("inverse_tune", 0)
+        y0 = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") != 3
+        p.set_option("inverse_step", 1)
+        y1 = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 3
+        assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
+        ref = O.best(m, "hann", 1.0, "f32f64")
+        dh = d.cpu().numpy()
+        rows = dh if channels == 1 else dh[channels - 1]
+        want = ref.isdft(rows[: min(n, 3000)])
+        got = y1 if channels == 1 else y1[channels - 1]
+        assert np.array_equal(got[: len(want)], want)
+        # other latencies and type pairs do not take the form
+        p.set_option("inverse_step", 1)
+    with make(m, "hann", 0.5, "f32f64") as q:
+        q.set_option("inverse_step", 1)
+        q.isdft(q.sdft(torch.from_numpy(noise(2000, seed=5)).cuda()))
+        assert q.get_option("last_inverse_form") != 3
