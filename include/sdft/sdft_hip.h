@@ -194,7 +194,10 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "rows_f32"      1 (default) = FD float rows of a multiple of 128 bins are analysed by the bin-pair kernel (a lane's two
                        adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
    "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB
-                       and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back), 0 / 1
+                       and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back) and from
+                       32 GiB on; between 4 and 32 GiB the form tuner tries both kinds of load on the host's own calls (a matrix
+                       that is only read streams 3-10 % faster past the caches, one the analysis has just written up to 5 %
+                       slower); 0 / 1 = never / always.  get_option "last_inverse_nt" = what the last synthesis launch used
    "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
                        per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof -- on the host's own
                        calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape

@@ -147,20 +147,28 @@ class Plan
   long opt_inverse_nt = -1;
   // long synthesis calls: the fastest of the bit-identical streaming forms is found on the host's own calls (launch_inverse)
   long opt_inverse_tune = 1, last_inverse_tuned = 0;
-  logic::FormTuner inv_tune;
-  hipEvent_t tune_ev[logic::FormTuner::kMax][2] = {};         // a pair of events per candidate form
+  // (two tuners: a synthesis that follows an analysis call reads a matrix whose tail is still dirty in the Infinity Cache, one that
+  // follows another synthesis does not -- which form and which kind of load is fastest differs between the two, and a host may do both)
+  logic::FormTuner inv_tunes[2];
+  bool inv_after_write = false;                              // the synthesis call being launched directly follows an analysis call
+  hipEvent_t tune_evs[2][logic::FormTuner::kMax][2] = {};     // a pair of events per candidate form and tuner
   bool ensure_tune_events()
   {
-    if (tune_ev[0][0]) return true;
-    for (auto& pair : tune_ev)
-      for (hipEvent_t& e : pair)
-        if (hipEventCreate(&e) != hipSuccess)
-        {
-          (void)hipGetLastError(); e = nullptr;
-          for (auto& q : tune_ev) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
-          return false;
-        }
+    if (tune_evs[0][0][0]) return true;
+    for (auto& tuner : tune_evs)
+      for (auto& pair : tuner)
+        for (hipEvent_t& e : pair)
+          if (hipEventCreate(&e) != hipSuccess)
+          {
+            (void)hipGetLastError(); e = nullptr;
+            destroy_tune_events();
+            return false;
+          }
     return true;
+  }
+  void destroy_tune_events()
+  {
+    for (auto& tuner : tune_evs) for (auto& q : tuner) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
   }
   long opt_inverse_rpi = 4;      // development: rows per load instruction of the streaming synthesis (4: 256-byte row segments, 2, 1: a KiB)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
@@ -285,7 +293,7 @@ class Plan
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
     seg_events.clear();
     if (ev_delta) { (void)hipEventDestroy(ev_delta); ev_delta = nullptr; }
-    for (auto& pair : tune_ev) for (hipEvent_t& e : pair) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    destroy_tune_events();
     for (int st = 0; st < ST_COUNT; ++st)
     {
       for (hipEvent_t e : ev_pool[st]) (void)hipEventDestroy(e);
@@ -1326,6 +1334,7 @@ class Plan
     const bool ops_wanted = op && op->kind != OP_IDENTITY;
     last_inverse_pipelined = 0;
     // (whatever FD is: the synthesis has no state to carry from call to call)
+    inv_after_write = calls.prev_was_analysis;
     calls.on_synthesis_begin();
     const bool inv_pipe = calls.inverse_batch && pipe_allowed && !rows && !ops_wanted && async && own_stream && !stream_exposed && opt_pipeline && profile == 0 &&
                           channels * n * nbins >= ((size_t)6 << 20) && ensure_pipe();
@@ -1356,7 +1365,7 @@ class Plan
     ia.done.flag = nullptr; ia.done.count = nullptr; ia.done.seq = 0; ia.done.total = 0;
     {
       const size_t matrix_bytes = channels * n * nbins * sizeof(fdx);
-      ia.nt = opt_inverse_nt >= 0 ? (int)(opt_inverse_nt != 0) : (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30));
+      ia.nt = (int)logic::inverse_streaming_loads(matrix_bytes, opt_inverse_nt);
     }
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;

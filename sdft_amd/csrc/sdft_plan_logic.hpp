@@ -320,12 +320,12 @@ inline long inverse_rows_per_wave(size_t total_rows, size_t fd_bytes, long force
 // form 0, the static choice, untimed); a new shape starts over.
 struct FormTuner
 {
-  static constexpr int kMax = 4, kSamples = 2;
+  static constexpr int kMax = 6, kSamples = 2;
   size_t key = 0;
   int count = 0, chosen = -1;
-  int samples[kMax] = {0, 0, 0, 0};
-  bool inflight[kMax] = {false, false, false, false};      // a timed call of this form has been launched and not yet reported
-  float best[kMax] = {0, 0, 0, 0};
+  int samples[kMax] = {};
+  bool inflight[kMax] = {};                                // a timed call of this form has been launched and not yet reported
+  float best[kMax] = {};
   void reset(size_t k, int candidates)
   {
     key = k; count = candidates < 1 ? 1 : (candidates > kMax ? kMax : candidates); chosen = count == 1 ? 0 : -1;
@@ -364,6 +364,19 @@ struct FormTuner
     ++samples[form];
   }
 };
+
+// ---- synthesis: are the matrix' loads non-temporal? ------------------------------------------------------------------------------
+// Between 256 MiB and 4 GiB (round 4: ordinary loads of a matrix the analysis has just written push its dirty tail out of the
+// Infinity Cache while they read) and from 32 GiB on (round 5: 50 GB stream 5 % faster past the caches whether they were just written
+// or not).  In between it depends on the host: a matrix that is only read streams 3-10 % faster with non-temporal loads, one the
+// analysis has just written up to 5 % slower (20 % at 6.5 GB) -- which the form tuner finds out on the host's own calls, with one
+// tuner for syntheses that follow an analysis and one for those that do not (profiles/r05_synthesis_streaming_loads_big.txt).
+// forced: the option (-1 = by size).
+inline bool inverse_streaming_loads(size_t matrix_bytes, long forced)
+{
+  if (forced >= 0) return forced != 0;
+  return (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30)) || matrix_bytes >= ((size_t)32 << 30);
+}
 
 // ---- fused call: waves of a workgroup and bins per lane (1, 2, 4) -----------------------------------------------------------
 struct ProcessGeometry { long waves = 1, slots = 1; };

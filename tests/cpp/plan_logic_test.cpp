@@ -250,6 +250,11 @@ static void test_form_tuner()
   t.reset(3000, 2);
   CHECK(t.next(false, timed) == 0 && !timed, "no timing possible: the static form");
   t.launched(1); t.report(7, 1.0f); t.report(1, -1.0f); CHECK(t.samples[1] == 0 && !t.inflight[1], "a failed sample frees the form and counts nothing");
+  // the kind of load of the synthesis by the size of the matrix: the window of round 4, the very large matrices of round 5, the option
+  const size_t MiB = (size_t)1 << 20, GiB = (size_t)1 << 30;
+  CHECK(!inverse_streaming_loads(200 * MiB, -1) && inverse_streaming_loads(300 * MiB, -1) && inverse_streaming_loads(4 * GiB, -1), "the window");
+  CHECK(!inverse_streaming_loads(4 * GiB + 1, -1) && !inverse_streaming_loads(16 * GiB, -1) && inverse_streaming_loads(32 * GiB, -1) && inverse_streaming_loads(50 * GiB, -1), "beyond it");
+  CHECK(inverse_streaming_loads(1, 1) && !inverse_streaming_loads(GiB, 0), "forced");
 }
 
 static void test_piece_ring()
