@@ -328,10 +328,12 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         d = torch.empty((n, m), dtype=torch.complex64, device="cuda")
         y = torch.empty(n, dtype=torch.float32, device="cuda")
         p = SDFT(m, window, 1.0, combo, device=device)
-        for _ in range(2):
+        # (the synthesis finds its form and its kind of load on the first calls of a shape -- up to six candidates, two timed calls each, one
+        # tuner for syntheses that follow an analysis and one for those that do not: logic::FormTuner; none of that inside a timed region)
+        for _ in range(TUNER_CALLS):
             p.sdft(x, d); p.isdft(d, y)
-        for _ in range(8):
-            p.isdft(d, y)                                    # (the synthesis finds its form: logic::FormTuner)
+        for _ in range(TUNER_CALLS):
+            p.isdft(d, y)
         fwd = timed(lambda: p.sdft(x, d), p.synchronize, 5)
         inv = timed(lambda: p.isdft(d, y), p.synchronize, 5)
         p.set_option("async", 1)
@@ -370,7 +372,7 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         y = None
         for _ in range(2):
             p.sdft(x, d); y = p.isdft(d, y)
-        for _ in range(8):
+        for _ in range(TUNER_CALLS):
             y = p.isdft(d, y)
         fwd = timed(lambda: p.sdft(x, d), p.synchronize, 3)
         inv = timed(lambda: p.isdft(d, y), p.synchronize, 3)
@@ -450,6 +452,9 @@ def launch_ranks(args) -> int:
     print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr)
     r = subprocess.run(cmd, env=env, cwd=ROOT)
     return r.returncode
+
+
+TUNER_CALLS = 14        # untimed calls of a shape before its synthesis is timed (FormTuner: up to 6 candidates x 2 samples)
 
 
 def place_matrix(torch, shape, cdt, m, esz, candidates):
@@ -596,8 +601,11 @@ def main():
             kern_ms.append(pf[0] / pf[1])
 
     # second bracketed region, every rank: analysis + synthesis pairs (the metric string names both)
+    # (long synthesis calls find the fastest of their bit-identical forms and kinds of load on the first calls of a shape -- the ones that follow an
+    # analysis call separately from the ones that do not: logic::FormTuner; the pairs below are of the first kind, so pairs are what settles it)
     y = plan.isdft(out)
-    for _ in range(10):                  # (long synthesis calls find the fastest of their bit-identical forms on the first calls of a shape: logic::FormTuner)
+    for _ in range(TUNER_CALLS):
+        plan.sdft(x, out)
         plan.isdft(out, y)
         sync()
     sync(); plan.profile()
@@ -616,6 +624,16 @@ def main():
     i_ms, i_calls = prof_rt["inverse"]
     i_avg = i_ms / max(i_calls, 1)
     syn_rate = shard.sum_over_ranks(count * n / (i_avg * 1e-3) if i_avg > 0 else 0.0, local_rank)
+    # (outside both bracketed regions: the synthesis of a matrix that is only read -- call after call, no analysis in between; this rank's calls)
+    for _ in range(TUNER_CALLS):
+        plan.isdft(out, y)
+        sync()
+    plan.profile()
+    for _ in range(5):
+        plan.isdft(out, y)
+    sync()
+    ro_ms, ro_calls = plan.profile()["inverse"]
+    syn_read_only = count * n / (ro_ms / max(ro_calls, 1) * 1e-3) if ro_ms > 0 else 0.0
 
     # roofline of the dominant kernel (this rank's launches; every rank runs the same shape)
     f_ms, f_calls = prof["forward"]
@@ -643,6 +661,9 @@ def main():
         "value_is": "analysis only (sdft_sdft_n), as configs[1] states; the analysis+synthesis pair rate is the next field",
         "analysis_plus_synthesis_msamples_s": round(rate_rt / 1e6, 3),
         "synthesis_msamples_s": round(syn_rate / 1e6, 3),
+        "synthesis_is": "the synthesis calls of the analysis + synthesis pairs (each reads the matrix the analysis has just written), by the plan's events; "
+                        "synthesis_matrix_only_read_msamples_s: call after call on a matrix nobody writes (this rank, outside the timed regions)",
+        "synthesis_matrix_only_read_msamples_s": round(syn_read_only / 1e6, 3),
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -844,10 +865,14 @@ def main():
         hp = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
         hout = np.empty((npci, m) if count == 1 else (count, npci, m), dtype=np.complex128 if esz == 16 else np.complex64)
         hp.sdft(hx, hout)
-        hp.reset()
-        tp = time.perf_counter()
-        hp.sdft(hx, hout)
-        extras["host_pointer_pcie_inclusive_msamples_s"] = round(count * npci / (time.perf_counter() - tp) / 1e6, 3)
+        tpci = []
+        for _ in range(3):
+            hp.reset()
+            tp = time.perf_counter()
+            hp.sdft(hx, hout)
+            tpci.append(time.perf_counter() - tp)
+        extras["host_pointer_pcie_inclusive_msamples_s"] = round(count * npci / min(tpci) / 1e6, 3)
+        extras["host_pointer_pcie_inclusive_is"] = f"one synchronous sdft_sdft_n call, host samples in, host matrix out ({count * npci * m * esz / 1e9:.2f} GB over PCIe), best of 3 (median {count * npci / sorted(tpci)[1] / 1e6:.3f})"
         hp.close()
 
         if workload == "single":
@@ -865,7 +890,7 @@ def main():
                 yb = None
                 for _ in range(2):
                     pb.sdft(xb, ob); yb = pb.isdft(ob, yb)
-                for _ in range(8):
+                for _ in range(TUNER_CALLS):
                     yb = pb.isdft(ob, yb); pb.synchronize()
                 pb.synchronize(); torch.cuda.synchronize()
                 reps = 5
