@@ -283,9 +283,9 @@ def reference_bench_shape(torch, np, SDFT, device, with_cpu=True):
     y = torch.empty(n, dtype=torch.float64, device="cuda")
     p = SDFT(m, "hann", 1.0, "f64f64", device=device)
     fw, iv = [], []
-    for r in range(runs + 2):
+    for r in range(runs + TUNER_CALLS):                      # (the first calls of a shape settle the synthesis' form: untimed)
         t0 = time.perf_counter(); p.sdft(x, d); t1 = time.perf_counter(); p.isdft(d, y); t2 = time.perf_counter()
-        if r >= 2:
+        if r >= TUNER_CALLS:
             fw.append(t1 - t0); iv.append(t2 - t1)
     p.close()
     res = {"shape": "dftsize 1000, 44100 samples of zeros, TD = FD = double, hann, 10 runs (cpp/examples/bench.cpp:15-48)",
