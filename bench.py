@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements outside the timed regions")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the many-core CPU baseline of the batch share")
     ap.add_argument("--no-placement", action="store_true", help="take the output matrix as the first allocation comes (no store-only probe of candidates)")
-    ap.add_argument("--placement-candidates", type=int, default=6)
+    ap.add_argument("--placement-candidates", type=int, default=12)     # (a third of the allocations are of the fast kind: profiles/r05_arena_probe.txt)
     return ap.parse_args()
 
 
