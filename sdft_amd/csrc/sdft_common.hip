@@ -345,7 +345,7 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
   auto launch = [&]() {
     if (pattern == 0)
       hipLaunchKernelGGL(store_linear_kernel, dim3(256 * 8), dim3(kBlock), 0, 0, (v2f64*)dst, slots);
-    else if ((pattern >= 2 && pattern <= 6) || pattern >= 100)   // 3: non-temporal stores; 4: XCD-contiguous chunks; 5: staggered row phase; 6: both; 100 + R: R regions
+    else if ((pattern >= 2 && pattern <= 7) || pattern >= 100)   // 3: non-temporal stores (7: and XCD-contiguous chunks); 4: XCD-contiguous chunks; 5: staggered row phase; 6: both; 100 + R: R regions
     {
       const size_t rows = slots / row_slots;
       const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
@@ -355,6 +355,7 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
       else if (pattern == 3) hipLaunchKernelGGL((store_rowgroup_kernel<true, 0, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
       else if (pattern == 5) hipLaunchKernelGGL((store_rowgroup_kernel<false, 0, true>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
       else if (pattern == 6) hipLaunchKernelGGL((store_rowgroup_kernel<false, 1, true>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
+      else if (pattern == 7) hipLaunchKernelGGL((store_rowgroup_kernel<true, 1, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
       else hipLaunchKernelGGL((store_rowgroup_kernel<false, 1, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
     }
     else

@@ -429,7 +429,8 @@ template <> struct StoreVec<float, 2>  { using type = sdft_v4f32; };
 template <> struct StoreVec<float, 1>  { using type = sdft_v2f32; };
 
 // (a non-temporal variant of this store was measured on MI355X: 3.205 vs 3.217 ms at n=1e6, N=1024 --
-// no effect on a pure write stream -- and removed)
+// no effect on a pure write stream -- and removed; round 5, store-only kernels at 7 TB/s: 1-3 % slower,
+// profiles/r05_nt_stores.txt)
 template <typename V> SDFT_D void store_vec(V* p, V v) { *p = v; }
 
 template <typename FD, int BPL, int WIN, bool ROWS>
