@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements outside the timed regions")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the many-core CPU baseline of the batch share")
     ap.add_argument("--no-placement", action="store_true", help="take the output matrix as the first allocation comes (no store-only probe of candidates)")
+    ap.add_argument("--placement", choices=("arena", "candidates"), default="arena",
+                    help="how the output matrix of the headline workload is placed: the best window of one large allocation, or the best of several allocations")
     ap.add_argument("--placement-candidates", type=int, default=12)     # (a third of the allocations are of the fast kind: profiles/r05_arena_probe.txt)
     return ap.parse_args()
 
@@ -457,7 +459,7 @@ def launch_ranks(args) -> int:
 TUNER_CALLS = 14        # untimed calls of a shape before its synthesis is timed (FormTuner: up to 6 candidates x 2 samples)
 
 
-def place_matrix(torch, shape, cdt, m, esz, candidates):
+def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False):
     """The output matrix, in memory that streams well.  Round 5 found that how fast a large buffer can be WRITTEN depends on which
     physical memory backs it: of twelve 16.4 GB buffers allocated one after the other in one process, seven take the row-lockstep
     store stream at 6.4-7.1 TB/s, four at 5.85 and one in between, the same ones on every pass; loads do not care
@@ -470,6 +472,32 @@ def place_matrix(torch, shape, cdt, m, esz, candidates):
     lib = capi.load()
     nbytes = math.prod(shape) * esz
     probe_ok = candidates > 1 and nbytes >= (64 << 20)         # (the probe writes rows of 16 KiB whatever the matrix's own rows are)
+    if arena and probe_ok and (4 << 30) <= nbytes < (32 << 30):
+        # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of device memory (profiles/r05_split_matrix.txt), and
+        # where the stretches meet inside one large allocation a window of the matrix' size straddles them (profiles/r05_arena_probe.txt).  So: ONE large
+        # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Matrices of
+        # 32 GiB and more span several stretches wherever they are.
+        step = 4 << 30
+        free, _ = torch.cuda.mem_get_info()
+        abytes = (min(free - (90 << 30), 12 * nbytes) // step) * step
+        if abytes >= nbytes + 2 * step:
+            try:
+                block = torch.empty(abytes, dtype=torch.uint8, device="cuda")
+            except RuntimeError:
+                block = None
+            if block is not None:
+                offs = list(range(0, abytes - nbytes + 1, step))
+                rates = []
+                for o in offs:
+                    ms = lib.sdft_hip_store_ceiling(block.data_ptr() + o, (nbytes // 16384) * 16384, 4, 1024, 8, 1960, 2)
+                    rates.append(round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0)
+                torch.cuda.synchronize()
+                best = max(range(len(offs)), key=lambda i: rates[i])
+                out = block[offs[best]:offs[best] + nbytes].view(cdt).view(shape)
+                info = {"policy": "the best window of ONE allocation of %.0f GB (a window of the matrix' size every 4 GiB) by a store-only probe, untimed, before the warm-up "
+                                  "(--placement candidates: separate allocations; --no-placement: the first allocation)" % (abytes / 1e9),
+                        "probed_store_only_gbs": rates, "chosen": best}
+                return out, info
     kept, rates = [], []
     for i in range(max(1, candidates) if probe_ok else 1):
         free, _ = torch.cuda.mem_get_info()
@@ -552,7 +580,7 @@ def main():
         xh = np.stack([sine_sweep(n, channel=c, channels=channels_total, dtype=td) for c in range(first, first + count)])
     x = torch.from_numpy(xh).cuda()
     shape = (n, m) if count == 1 else (count, n, m)
-    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates)
+    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates, arena=args.placement == "arena")
 
     stream = torch.cuda.Stream()
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)

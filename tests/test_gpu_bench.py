@@ -92,7 +92,7 @@ def test_single_rank_bench_line_contract():
     assert res["ranks"] is None                                                    # the census belongs to N > 1 lines
     # round 5: the output matrix is the best of a few allocations by a store-only probe, untimed, and the line says so
     bp = res["buffer_placement"]
-    assert "untimed" in bp["policy"] and 1 <= len(bp["probed_store_only_gbs"]) <= 12 and bp["probed_store_only_gbs"][bp["chosen"]] == max(bp["probed_store_only_gbs"])
+    assert "untimed" in bp["policy"] and 1 <= len(bp["probed_store_only_gbs"]) <= 64 and bp["probed_store_only_gbs"][bp["chosen"]] == max(bp["probed_store_only_gbs"])
     # the headline workload as asynchronous calls into two matrices in turn (pipelined calls), and the north star's shape likewise
     two = res["two_matrices_in_turn"]
     assert "error" in two or (two["pipelined_calls"] >= 10 and 0 < two["frac_of_peak_wall"] < 1 and
