@@ -476,7 +476,8 @@ def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False):
         # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of device memory (profiles/r05_split_matrix.txt), and
         # where the stretches meet inside one large allocation a window of the matrix' size straddles them (profiles/r05_arena_probe.txt).  So: ONE large
         # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Matrices of
-        # 32 GiB and more span several stretches wherever they are.
+        # 32 GiB and more span several stretches wherever they are.  (What the library offers a C host as sdft_hip_malloc_matrix_in_arena; spelled out here so
+        # that the line can list every window's rate.)
         step = 4 << 30
         free, _ = torch.cuda.mem_get_info()
         abytes = (min(free - (90 << 30), 12 * nbytes) // step) * step

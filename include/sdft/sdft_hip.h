@@ -51,6 +51,14 @@ double      sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigne
    the store-only kernel above (2 launches), keeps the best and frees the others; *gbs (may be NULL) = the kept buffer's probe rate.
    Free with hipFree.  NULL on failure. */
 void*       sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs);
+/* The same choice made inside ONE allocation (round 5: a matrix is written fast exactly when its halves lie in different stretches of
+   device memory, and where two stretches meet inside a large allocation a window of the matrix' size straddles them --
+   profiles/r05_split_matrix.txt, r05_arena_probe.txt): allocates `arena_bytes` (>= bytes; the larger, the surer: 64 GiB beyond the
+   matrix have always held a meeting point so far), probes a window of `bytes` every 4 GiB, returns the best window and keeps the
+   whole allocation until sdft_hip_free_matrix(window) -- NOT hipFree: the window is not the start of the allocation.
+   *gbs (may be NULL) = the window's probe rate.  NULL on failure; free: 0, or -1 for a pointer this call did not return. */
+void*       sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs);
+int         sdft_hip_free_matrix(void* window);
 /* measurement aid: occupies `cus` CUs (nothing shares them) for `milliseconds` on a stream of its own and returns at once;
    cus = 0 waits for the release.  What a kernel keeps of its speed beside a kernel that holds part of the chip. */
 int         sdft_hip_hold_cus(unsigned cus, double milliseconds);

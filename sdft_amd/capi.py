@@ -72,6 +72,8 @@ UNTYPED = {
     "sdft_hip_load_rows_ceiling": (C.c_double, [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_int]),
     "sdft_hip_hold_cus": (C.c_int, [C.c_uint, C.c_double]),
     "sdft_hip_malloc_matrix": (C.c_void_p, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "sdft_hip_malloc_matrix_in_arena": (C.c_void_p, [C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]),
+    "sdft_hip_free_matrix": (C.c_int, [C.c_void_p]),
 }
 
 

@@ -460,6 +460,50 @@ void* sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs)
   return best;
 }
 
+// the same choice inside one allocation: window -> allocation base, for sdft_hip_free_matrix
+namespace sdfthip {
+static std::mutex g_arena_mutex;
+static std::vector<std::pair<void*, void*>> g_arenas;       // (window, base)
+}
+void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs)
+{
+  using namespace sdfthip;
+  if (gbs) *gbs = 0.0;
+  if (bytes == 0 || arena_bytes < bytes) { set_error("sdft_hip_malloc_matrix_in_arena", "the arena is smaller than the matrix"); return nullptr; }
+  char* base = nullptr;
+  if (hipMalloc((void**)&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_malloc_matrix_in_arena", "out of device memory"); return nullptr; }
+  const size_t step = (size_t)4 << 30;
+  size_t best_off = 0;
+  double best_ms = 0.0;
+  if (bytes >= ((size_t)64 << 20))
+  {
+    const size_t rows = bytes / 16384;
+    const unsigned chunk_len = (unsigned)std::max<size_t>(8, (rows + 510) / 511);       // two rounds of the chip, as the analysis cuts time
+    for (size_t off = 0; off + bytes <= arena_bytes; off += step)
+    {
+      const double ms = sdft_hip_store_ceiling(base + off, rows * 16384, 4, 1024, 8, chunk_len, 2);
+      if (ms > 0.0 && (best_ms == 0.0 || ms < best_ms)) { best_ms = ms; best_off = off; }
+    }
+  }
+  if (gbs && best_ms > 0.0) *gbs = (double)((bytes / 16384) * 16384) / (best_ms * 1e-3) / 1e9;
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  g_arenas.emplace_back((void*)(base + best_off), (void*)base);
+  return base + best_off;
+}
+int sdft_hip_free_matrix(void* window)
+{
+  using namespace sdfthip;
+  void* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    for (size_t i = 0; i < g_arenas.size(); ++i)
+      if (g_arenas[i].first == window) { base = g_arenas[i].second; g_arenas.erase(g_arenas.begin() + (long)i); break; }
+  }
+  if (!base) { set_error("sdft_hip_free_matrix", "not a window of sdft_hip_malloc_matrix_in_arena"); return -1; }
+  if (hipFree(base) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_free_matrix", "hipFree failed"); return -1; }
+  return 0;
+}
+
 // NULL when no error has been recorded on this thread since the last clear
 const char* sdft_hip_last_error(void) { return sdfthip::g_has_error ? sdfthip::g_error.c_str() : nullptr; }
 void sdft_hip_clear_error(void) { sdfthip::g_has_error = false; sdfthip::g_error.clear(); }

@@ -940,6 +940,46 @@ def test_matrix_memory_chosen_for_its_store_rate():
     lib.sdft_hip_clear_error()
 
 
+def test_matrix_as_the_best_window_of_one_allocation():
+    """sdft_hip_malloc_matrix_in_arena (round 5): one allocation, the store-only probe on a window of the matrix' size every 4 GiB, the best
+    window returned; sdft_hip_free_matrix releases the whole allocation, knows its windows from other pointers, and nothing leaks.  The
+    window is ordinary device memory: sdft_sdft_n writes the reference's rows into it."""
+    import torch
+    from sdft_amd import capi
+    from sdft_amd.sdft import SDFT
+    lib = capi.load()
+    hip = C.CDLL(capi.hip_runtime)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    m, n = 1024, 6000                                          # 98 MB
+    nbytes = n * m * 16
+    arena = nbytes + (9 << 30)                                 # three windows: offsets 0, 4 and 8 GiB
+    free0, _ = torch.cuda.mem_get_info()
+    gbs = C.c_double(0.0)
+    ptr = lib.sdft_hip_malloc_matrix_in_arena(nbytes, arena, C.byref(gbs))
+    assert ptr and gbs.value > 100.0
+    free1, _ = torch.cuda.mem_get_info()
+    assert 0.9 * arena < free0 - free1 < 1.1 * arena + (64 << 20)
+    x = noise(n, seed=3)
+    want = O.best(m, "hann", 1.0, "f32f64").sdft(x)
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        xd = torch.from_numpy(x).cuda()
+        p.api.sdft_n(p._p, n, C.c_void_p(xd.data_ptr()), C.c_void_p(ptr)); p.api.check()
+        got = np.empty((n, m), dtype=np.complex128)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+    assert rel(got, want) <= 1e-11
+    assert lib.sdft_hip_free_matrix(C.c_void_p(ptr + 16)) == -1 and b"not a window" in lib.sdft_hip_last_error()
+    lib.sdft_hip_clear_error()
+    assert lib.sdft_hip_free_matrix(C.c_void_p(ptr)) == 0
+    assert lib.sdft_hip_free_matrix(C.c_void_p(ptr)) == -1      # once
+    lib.sdft_hip_clear_error()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 > free0 - (64 << 20)                          # the whole allocation is gone
+    assert lib.sdft_hip_malloc_matrix_in_arena(1 << 20, 1 << 10, None) is None and b"smaller than the matrix" in lib.sdft_hip_last_error()
+    lib.sdft_hip_clear_error()
+    small = lib.sdft_hip_malloc_matrix_in_arena(4096, 8192, None)      # small matrices: no probe, the start of the allocation
+    assert small and lib.sdft_hip_free_matrix(C.c_void_p(small)) == 0
+
+
 def test_driver_entry_point_smoke():
     """__graft_entry__.smoke() is what the driver runs on a fresh box before the bench: it has to pass in the suite too
     (round 4: retiring the chain kernel broke one of its assertions and only a manual run noticed)."""
