@@ -44,8 +44,10 @@ def run(combo, m, n, ch, label, **opts):
 
 if __name__ == "__main__":
     print(f"device: {torch.cuda.get_device_name(0)}")
-    for combo, m, n, ch in (("f32f64", 1024, 1000000, 1), ("f64f64", 1024, 1000000, 1), ("f64f64", 1024, 500000, 1), ("f32f64", 1024, 400000, 1), ("f32f64", 1024, 48000, 64),
-                            ("f32f64", 2048, 48000, 64)):
+    shapes = (("f32f64", 1024, 1000000, 1), ("f64f64", 1024, 1000000, 1), ("f64f64", 1024, 500000, 1), ("f32f64", 1024, 400000, 1), ("f32f64", 1024, 48000, 64), ("f32f64", 2048, 48000, 64))
+    if len(sys.argv) > 1:
+        shapes = tuple(shapes[int(i)] for i in sys.argv[1].split(","))
+    for combo, m, n, ch in shapes:
         for rep in range(2):
             run(combo, m, n, ch, "ordinary loads", inverse_nt=0)
             run(combo, m, n, ch, "non-temporal loads", inverse_nt=1)

@@ -175,7 +175,7 @@ SDFT_D void inverse_rows_body(const InverseArgs<TD, FD>& a, unsigned chunk_len)
       const size_t rr = r + g < r1 ? r + g : r1 - 1;       // (past the chunk: the last row again, its sum is not used)
       const cx<FD>* row = row_of(rr);
 #pragma unroll
-      for (int j = 0; j < J; ++j) x[g][j] = live[j] ? load_bin(row + kb[j], 1) : cmake<FD>((FD)0, (FD)0);
+      for (int j = 0; j < J; ++j) x[g][j] = live[j] ? load_bin(row + kb[j], a.nt) : cmake<FD>((FD)0, (FD)0);
     }
   };
   auto term = [&](const cx<FD>& v, int j) -> FD { return v.re * sgn[j]; };             // sdft.h:643
