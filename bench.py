@@ -459,7 +459,7 @@ def launch_ranks(args) -> int:
 TUNER_CALLS = 14        # untimed calls of a shape before its synthesis is timed (FormTuner: up to 6 candidates x 2 samples)
 
 
-def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False):
+def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False, reserve=90 << 30, chunk_len=1960):
     """The output matrix, in memory that streams well.  Round 5 found that how fast a large buffer can be WRITTEN depends on which
     physical memory backs it: of twelve 16.4 GB buffers allocated one after the other in one process, seven take the row-lockstep
     store stream at 6.4-7.1 TB/s, four at 5.85 and one in between, the same ones on every pass; loads do not care
@@ -472,15 +472,15 @@ def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False):
     lib = capi.load()
     nbytes = math.prod(shape) * esz
     probe_ok = candidates > 1 and nbytes >= (64 << 20)         # (the probe writes rows of 16 KiB whatever the matrix's own rows are)
-    if arena and probe_ok and (4 << 30) <= nbytes < (32 << 30):
+    if arena and probe_ok and (4 << 30) <= nbytes < (96 << 30):
         # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of device memory (profiles/r05_split_matrix.txt), and
         # where the stretches meet inside one large allocation a window of the matrix' size straddles them (profiles/r05_arena_probe.txt).  So: ONE large
-        # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Matrices of
-        # 32 GiB and more span several stretches wherever they are.  (What the library offers a C host as sdft_hip_malloc_matrix_in_arena; spelled out here so
+        # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Larger
+        # matrices are less at risk but not safe: 50 GB inside the first 64 GiB of an allocation take 5.9 TB/s, elsewhere 6.9-7.2 (profiles/r05_arena_probe.txt).  (What the library offers a C host as sdft_hip_malloc_matrix_in_arena; spelled out here so
         # that the line can list every window's rate.)
         step = 4 << 30
         free, _ = torch.cuda.mem_get_info()
-        abytes = (min(free - (90 << 30), 12 * nbytes) // step) * step
+        abytes = (min(free - reserve, max(12 * nbytes, 200 << 30)) // step) * step
         if abytes >= nbytes + 2 * step:
             try:
                 block = torch.empty(abytes, dtype=torch.uint8, device="cuda")
@@ -490,7 +490,7 @@ def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False):
                 offs = list(range(0, abytes - nbytes + 1, step))
                 rates = []
                 for o in offs:
-                    ms = lib.sdft_hip_store_ceiling(block.data_ptr() + o, (nbytes // 16384) * 16384, 4, 1024, 8, 1960, 2)
+                    ms = lib.sdft_hip_store_ceiling(block.data_ptr() + o, (nbytes // 16384) * 16384, 4, 1024, 8, chunk_len, 2)
                     rates.append(round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0)
                 torch.cuda.synchronize()
                 best = max(range(len(offs)), key=lambda i: rates[i])
@@ -581,7 +581,9 @@ def main():
         xh = np.stack([sine_sweep(n, channel=c, channels=channels_total, dtype=td) for c in range(first, first + count)])
     x = torch.from_numpy(xh).cuda()
     shape = (n, m) if count == 1 else (count, n, m)
-    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates, arena=args.placement == "arena")
+    # (beside the headline matrix the single workload later places a second one of its size, the batch workload nothing large)
+    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates, arena=args.placement == "arena",
+                                  reserve=(90 << 30) if count == 1 else (24 << 30), chunk_len=1960 if count == 1 else 6000)
 
     stream = torch.cuda.Stream()
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
@@ -913,7 +915,8 @@ def main():
             free, _ = torch.cuda.mem_get_info()
             if free > chs * nb_ * m * esz * 1.05:
                 xb = torch.from_numpy(np.stack([sine_sweep(nb_, channel=c, channels=chs, dtype=td) for c in range(chs)])).cuda()
-                ob, share_placement = place_matrix(torch, (chs, nb_, m), cdt, m, esz, 1 if args.no_placement else 4)
+                ob, share_placement = place_matrix(torch, (chs, nb_, m), cdt, m, esz, 1 if args.no_placement else 4, arena=args.placement == "arena",
+                                                   reserve=24 << 30, chunk_len=6000)
                 pb = SDFT(m, window, 1.0, combo, channels=chs, device=local_rank)
                 pb.set_option("async", 1)
                 yb = None
