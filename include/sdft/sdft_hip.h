@@ -201,11 +201,12 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        0 = carries by a pre-pass (two more launches); calls of up to 2^19 samples per channel take it
    "rows_f32"      1 (default) = FD float rows of a multiple of 128 bins are analysed by the bin-pair kernel (a lane's two
                        adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
-   "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = for matrices between 256 MiB
-                       and 4 GiB (where they keep what the analysis left in the Infinity Cache from being written back) and from
-                       32 GiB on; between 4 and 32 GiB the form tuner tries both kinds of load on the host's own calls (a matrix
-                       that is only read streams 3-10 % faster past the caches, one the analysis has just written up to 5 %
-                       slower); 0 / 1 = never / always.  get_option "last_inverse_nt" = what the last synthesis launch used
+   "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = matrices beyond 256 MiB (what fits the
+                       Infinity Cache reads faster through it); 0 / 1 = never / always.  The rows read FIRST -- the matrix' end, what an
+                       analysis wrote last and left dirty in that cache, where a non-temporal load is slow -- take ordinary loads all
+                       the same: "inverse_nt_skip_mb" -1 (default) = 1536 MB of matrices from 6 GiB on (between 2 and 16 GiB the form
+                       tuner tries every form with and without), 0 = none, S = the first S MB read.
+                       get_option "last_inverse_nt" / "last_inverse_skip" = what the last synthesis launch used (skip in rows)
    "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
                        per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof -- on the host's own
                        calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape

@@ -24,17 +24,17 @@ def run(combo, m, n, ch, label, **opts):
         p.set_option(k, v)
     p.sdft(x, d)
     ro = []
-    for r in range(22):                                     # (A) only read
+    for r in range(26):                                     # (A) only read
         t0 = time.perf_counter(); p.isdft(d, y); t1 = time.perf_counter()
-        if r >= 14:
+        if r >= 16:
             ro.append(t1 - t0)
-    a_state = (p.get_option("last_inverse_tuned"), p.get_option("last_inverse_nt"))
+    a_state = (p.get_option("last_inverse_tuned"), f"{p.get_option('last_inverse_nt')}/{p.get_option('last_inverse_skip')}")
     fw, iv = [], []
-    for r in range(22):                                     # (B) round trips
+    for r in range(26):                                     # (B) round trips
         t0 = time.perf_counter(); p.sdft(x, d); t1 = time.perf_counter(); p.isdft(d, y); t2 = time.perf_counter()
-        if r >= 14:
+        if r >= 16:
             fw.append(t1 - t0); iv.append(t2 - t1)
-    b_state = (p.get_option("last_inverse_tuned"), p.get_option("last_inverse_nt"))
+    b_state = (p.get_option("last_inverse_tuned"), f"{p.get_option('last_inverse_nt')}/{p.get_option('last_inverse_skip')}")
     esz = 16 if combo[3:] == "f64" else 8
     b = ch * n * m * esz
     print(f"{combo} {ch} x {n} x {m} {label:24s}: only read {np.median(ro) * 1e3:7.3f} ms ({b / np.median(ro) / 1e9:5.0f} GB/s, form {a_state[0]} nt {a_state[1]})"
@@ -44,11 +44,12 @@ def run(combo, m, n, ch, label, **opts):
 
 if __name__ == "__main__":
     print(f"device: {torch.cuda.get_device_name(0)}")
-    shapes = (("f32f64", 1024, 1000000, 1), ("f64f64", 1024, 1000000, 1), ("f64f64", 1024, 500000, 1), ("f32f64", 1024, 400000, 1), ("f32f64", 1024, 48000, 64), ("f32f64", 2048, 48000, 64))
+    shapes = (("f32f64", 1024, 1000000, 1), ("f64f64", 1024, 1000000, 1), ("f64f64", 1024, 500000, 1), ("f32f64", 1024, 400000, 1), ("f32f64", 1024, 48000, 64), ("f32f64", 2048, 48000, 64),
+              ("f64f64", 1000, 44100, 1), ("f32f64", 1024, 131072, 1), ("f64f64", 1024, 262144, 1), ("f32f64", 1024, 262144, 1))
     if len(sys.argv) > 1:
         shapes = tuple(shapes[int(i)] for i in sys.argv[1].split(","))
     for combo, m, n, ch in shapes:
         for rep in range(2):
             run(combo, m, n, ch, "ordinary loads", inverse_nt=0)
-            run(combo, m, n, ch, "non-temporal loads", inverse_nt=1)
+            run(combo, m, n, ch, "non-temporal loads", inverse_nt=1, inverse_nt_skip_mb=0)
             run(combo, m, n, ch, "default")

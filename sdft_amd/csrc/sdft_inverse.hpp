@@ -68,6 +68,9 @@ template <typename TD, typename FD> struct InverseArgs
   SpectralOp<FD> op;          // applied to every bin on the way in (identity for sdft_isdft_n)
   DoneSignal done;            // inverse_row_kernel only: total = rows
   int nt;                     // loads of the matrix are non-temporal (streamed past the caches: see Plan::opt_inverse_nt)
+  size_t nt_skip;             // ... but the first nt_skip rows READ (the matrix' end: what an analysis wrote last) take ordinary loads all the same:
+                              // non-temporal loads of lines that sit dirty in the Infinity Cache are slow, ordinary loads of them are not and
+                              // push the rest of what is dirty there out on the way (Plan::opt_inverse_nt_skip_mb)
 };
 
 // VERIFY (float samples from double bins): the reference's bits from the tree sum -- the rounding-interval test of
@@ -90,11 +93,12 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
     const size_t ch = r / a.n, t = r - ch * a.n;
     const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
     FD part = (FD)0, mag = (FD)0;
+    const int nt = (a.nt && ri >= a.nt_skip) ? 1 : 0;      // (wave-uniform)
     const FD* grow = OPS ? gain_row(a.op, t, a.nbins) : nullptr;
 #pragma unroll 4
     for (unsigned k = lane; k < a.nbins; k += kWave)
     {
-      const FD tv = synth_term<FD, LAT1, OPS>(load_bin(row + k, a.nt), k, a.op, a.syn, a.nbins, grow);
+      const FD tv = synth_term<FD, LAT1, OPS>(load_bin(row + k, nt), k, a.op, a.syn, a.nbins, grow);
       part += tv;
       if constexpr (VERIFY) mag += __builtin_fabs(tv);
     }
@@ -154,6 +158,7 @@ SDFT_D void inverse_rows_body(const InverseArgs<TD, FD>& a, unsigned chunk_len)
   // chunks are taken from the END of the matrix first (what the analysis wrote last still sits in the Infinity Cache)
   const size_t nchunks = (rows + chunk_len - 1) / chunk_len;
   const size_t cidx = nchunks - 1 - blockIdx.x;
+  const int nt = (a.nt && (size_t)blockIdx.x * chunk_len >= a.nt_skip) ? 1 : 0;
   const size_t r0 = cidx * (size_t)chunk_len;
   const size_t r1 = r0 + chunk_len < rows ? r0 + chunk_len : rows;
 
@@ -175,7 +180,7 @@ SDFT_D void inverse_rows_body(const InverseArgs<TD, FD>& a, unsigned chunk_len)
       const size_t rr = r + g < r1 ? r + g : r1 - 1;       // (past the chunk: the last row again, its sum is not used)
       const cx<FD>* row = row_of(rr);
 #pragma unroll
-      for (int j = 0; j < J; ++j) x[g][j] = live[j] ? load_bin(row + kb[j], a.nt) : cmake<FD>((FD)0, (FD)0);
+      for (int j = 0; j < J; ++j) x[g][j] = live[j] ? load_bin(row + kb[j], nt) : cmake<FD>((FD)0, (FD)0);
     }
   };
   auto term = [&](const cx<FD>& v, int j) -> FD { return v.re * sgn[j]; };             // sdft.h:643
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
     const size_t ch = g / ngroups_per_ch;
     const size_t r0 = (g - ch * ngroups_per_ch) * RW;
     const cx<FD>* base = a.in + ch * a.in_stride;
+    const int nt = (a.nt && gi * (size_t)RW >= a.nt_skip) ? 1 : 0;     // (wave-uniform)
     const FD* grow[NI];                                    // OPS: the gain vector of each row this lane stages
 #pragma unroll
     for (int i = 0; i < NI; ++i) grow[i] = OPS ? gain_row(a.op, r0 + (size_t)(RPI * i + sub), a.nbins) : nullptr;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
           const cx<FD>* rowp = a.in_rows ? a.in_rows[ch * a.n + r] : base + r * (size_t)a.nbins;
           if (BPL == 2 && vec_ok && k + 1 < a.nbins)
           {
-            const V q = load_vec(reinterpret_cast<const V*>(rowp + k), a.nt);
+            const V q = load_vec(reinterpret_cast<const V*>(rowp + k), nt);
             v[i][0] = cmake<FD>((FD)q[0], (FD)q[1]);
             if constexpr (BPL == 2) v[i][1] = cmake<FD>((FD)q[2], (FD)q[3]);
           }
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
           {
 #pragma unroll
             for (int b = 0; b < BPL; ++b)
-              if (k + b < a.nbins) v[i][b] = load_bin(rowp + k + b, a.nt);
+              if (k + b < a.nbins) v[i][b] = load_bin(rowp + k + b, nt);
           }
         }
       }

@@ -145,6 +145,7 @@ class Plan
   // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
   // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
   long opt_inverse_nt = -1;
+  long opt_inverse_nt_skip_mb = -1;                         // -1: 1536 MB of matrices from 4 GiB on (logic::inverse_ordinary_rows); 0: none
   // long synthesis calls: the fastest of the bit-identical streaming forms is found on the host's own calls (launch_inverse)
   long opt_inverse_tune = 1, last_inverse_tuned = 0;
   // (two tuners: a synthesis that follows an analysis call reads a matrix whose tail is still dirty in the Infinity Cache, one that
@@ -1366,6 +1367,7 @@ class Plan
     {
       const size_t matrix_bytes = channels * n * nbins * sizeof(fdx);
       ia.nt = (int)logic::inverse_streaming_loads(matrix_bytes, opt_inverse_nt);
+      ia.nt_skip = logic::inverse_ordinary_rows(matrix_bytes, nbins * sizeof(fdx), opt_inverse_nt_skip_mb);
     }
     const bool ops = op && op->kind != OP_IDENTITY;
     if (ops) ia.op = *op;

@@ -366,16 +366,26 @@ struct FormTuner
 };
 
 // ---- synthesis: are the matrix' loads non-temporal? ------------------------------------------------------------------------------
-// Between 256 MiB and 4 GiB (round 4: ordinary loads of a matrix the analysis has just written push its dirty tail out of the
-// Infinity Cache while they read) and from 32 GiB on (round 5: 50 GB stream 5 % faster past the caches whether they were just written
-// or not).  In between it depends on the host: a matrix that is only read streams 3-10 % faster with non-temporal loads, one the
-// analysis has just written up to 5 % slower (20 % at 6.5 GB) -- which the form tuner finds out on the host's own calls, with one
-// tuner for syntheses that follow an analysis and one for those that do not (profiles/r05_synthesis_streaming_loads_big.txt).
-// forced: the option (-1 = by size).
+// Beyond 256 MiB (what fits the Infinity Cache reads faster through it).  Round 4 had stopped at 4 GiB, where non-temporal loads of a just-written
+// matrix were 5 % slower; round 5 found why -- a non-temporal load of a line that sits DIRTY in the cache is slow -- and reads the rows that may be
+// dirty with ordinary loads (inverse_ordinary_rows below): with that, non-temporal loads win on every matrix measured, just written or only read, by
+// 3-10 % (profiles/r05_synthesis_streaming_loads_big.txt, r05_after_write_16gb.txt).  forced: the option (-1 = by size).
 inline bool inverse_streaming_loads(size_t matrix_bytes, long forced)
 {
   if (forced >= 0) return forced != 0;
-  return (matrix_bytes > ((size_t)256 << 20) && matrix_bytes <= ((size_t)4 << 30)) || matrix_bytes >= ((size_t)32 << 30);
+  return matrix_bytes > ((size_t)256 << 20);
+}
+
+// ... and how many of the rows a synthesis reads FIRST (the matrix' end) take ordinary loads whatever the kind of load: a non-temporal load of a line that
+// sits dirty in the 256 MiB Infinity Cache (what an analysis wrote last) is slow; ordinary loads of such lines are not, and 1.5 GB of them push everything
+// dirty out on the way.  n = 1e6 x 1024 (16.4 GB), rows in step: after the analysis 2.74 (all non-temporal) / 2.75 (all ordinary) -> 2.55 ms, only read 2.45
+// either way (profiles/r05_after_write_16gb.txt).  Matrices from 6 GiB on (below, none: 706 MB ... 2.1 GB read best without; around 4 GiB it depends on
+// the form, which the tuner finds out); forced_mb: the option (-1 = this rule, 0 = none).
+inline size_t inverse_ordinary_rows(size_t matrix_bytes, size_t row_bytes, long forced_mb)
+{
+  if (row_bytes == 0) return 0;
+  const size_t mb = forced_mb >= 0 ? (size_t)forced_mb : (matrix_bytes >= ((size_t)6 << 30) ? (size_t)1536 : 0);
+  return mb ? ((mb << 20) + row_bytes - 1) / row_bytes : 0;
 }
 
 // ---- fused call: waves of a workgroup and bins per lane (1, 2, 4) -----------------------------------------------------------

@@ -253,8 +253,11 @@ static void test_form_tuner()
   // the kind of load of the synthesis by the size of the matrix: the window of round 4, the very large matrices of round 5, the option
   const size_t MiB = (size_t)1 << 20, GiB = (size_t)1 << 30;
   CHECK(!inverse_streaming_loads(200 * MiB, -1) && inverse_streaming_loads(300 * MiB, -1) && inverse_streaming_loads(4 * GiB, -1), "the window");
-  CHECK(!inverse_streaming_loads(4 * GiB + 1, -1) && !inverse_streaming_loads(16 * GiB, -1) && inverse_streaming_loads(32 * GiB, -1) && inverse_streaming_loads(50 * GiB, -1), "beyond it");
+  CHECK(inverse_streaming_loads(4 * GiB + 1, -1) && inverse_streaming_loads(16 * GiB, -1) && inverse_streaming_loads(50 * GiB, -1), "beyond it");
   CHECK(inverse_streaming_loads(1, 1) && !inverse_streaming_loads(GiB, 0), "forced");
+  // ... but for the rows read first: 1.5 GB of matrices from 6 GiB on, whole rows, none below; the option
+  CHECK(inverse_ordinary_rows(16 * GiB, 16384, -1) == 98304 && inverse_ordinary_rows(5 * GiB, 16384, -1) == 0 && inverse_ordinary_rows(16 * GiB, 16000, -1) == 100664, "rows read first");
+  CHECK(inverse_ordinary_rows(GiB, 16384, 256) == 16384 && inverse_ordinary_rows(16 * GiB, 16384, 0) == 0 && inverse_ordinary_rows(GiB, 0, 100) == 0, "forced rows");
 }
 
 static void test_piece_ring()
