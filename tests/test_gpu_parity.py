@@ -752,6 +752,16 @@ def test_streaming_loads_change_no_bit(combo, m, n):
         with make(m, "hann", 0.5, combo, inverse_nt=nt) as p:
             outs.append(p.isdft(dd).cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], want)
+    # round 5: the rows read first take ordinary loads whatever the kind of load (option inverse_nt_skip_mb: here the first 3 MB read, so that a call has
+    # rows of both kinds in every form -- streaming forms of 4 / 16 rows per wave, the tree sum, whole rows in step)
+    for opts in ({"inverse_rows": 4}, {"inverse_rows": 16}, {"inverse_tune": 0}, {"inverse_step": 1}):
+        with make(m, "hann", 0.5 if "inverse_step" not in opts else 1.0, combo, inverse_nt=1, inverse_nt_skip_mb=3, **opts) as p:
+            if "inverse_step" in opts:
+                ref1 = O.best(m, "hann", 1.0, combo)
+                assert np.array_equal(p.isdft(dd).cpu().numpy(), ref1.isdft(d))
+            else:
+                assert np.array_equal(p.isdft(dd).cpu().numpy(), want)
+            assert p.get_option("last_inverse_nt") == 1 and p.get_option("last_inverse_skip") > 0
 
 
 @pytest.mark.gpu
