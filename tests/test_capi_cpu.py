@@ -173,14 +173,15 @@ def test_the_kernels_of_the_two_reference_calls_do_not_spill(hip_library, combo)
     prologue and the compiler starts spilling (round 4: the self-carried form for double samples spilled 48 registers after an
     unrelated change, sdft_sdft_n at the reference's bench.cpp shape went from 147 to 170 us and only the bench noticed).
     No scratch instruction in the kernels of sdft_sdft_n / sdft_isdft_n: the analysis kernels without fused synthesis (SYN = 0),
-    the bin-pair kernel, the state kernel, the exact-order synthesis kernels, the relay."""
+    the bin-pair kernel, the state kernel, the synthesis kernels (exact order, tree sum, whole rows in step: the one-bin form is held to 64 registers), the relay."""
     kernels = disassemble(combo, hip_library)
     checked = 0
     for name, body in kernels.items():
         args = re.search(r"<(.*)>", name)
         params = [a.strip() for a in args.group(1).split(",")] if args else []
         hot = (name.startswith("forward_rows_kernel") and len(params) > 5 and params[5] == "0") or \
-            name.startswith(("forward_rows_f32_kernel", "self_state_kernel", "inverse_exact_kernel", "carry_relay_kernel", "forward_hop2_kernel"))
+            name.startswith(("forward_rows_f32_kernel", "self_state_kernel", "inverse_exact_kernel", "inverse_rows1_kernel", "inverse_rows2_kernel", "inverse_kernel",
+                             "carry_relay_kernel", "forward_hop2_kernel"))
         if not hot:
             continue
         spills = [l for l in body if "scratch_" in l]
