@@ -473,7 +473,7 @@ def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False, reserve=90 
     nbytes = math.prod(shape) * esz
     probe_ok = candidates > 1 and nbytes >= (64 << 20)         # (the probe writes rows of 16 KiB whatever the matrix's own rows are)
     if arena and probe_ok and (4 << 30) <= nbytes < (96 << 30):
-        # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of device memory (profiles/r05_split_matrix.txt), and
+        # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of an allocation (profiles/r05_split_matrix.txt), and
         # where the stretches meet inside one large allocation a window of the matrix' size straddles them (profiles/r05_arena_probe.txt).  So: ONE large
         # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Larger
         # matrices are less at risk but not safe: 50 GB inside the first 64 GiB of an allocation take 5.9 TB/s, elsewhere 6.9-7.2 (profiles/r05_arena_probe.txt).  (What the library offers a C host as sdft_hip_malloc_matrix_in_arena; spelled out here so
