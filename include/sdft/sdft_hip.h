@@ -145,7 +145,20 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
 double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t* samples, sdft_fdx_t* dfts, sdft_td_t* out) SDFT_HIP_SYMBOL(time_hops);
 
 /* ---- options -----------------------------------------------------------------------------------
+   Eleven options are for hosts; the defaults are the safe and (but for the host-memory choices, which only the host can make) the fast ones:
    "async"         0|1   see above
+   "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a
+                       small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
+                       other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
+                       the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
+                       stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).
+                       Asynchronous synthesis calls that come back to back take the two streams in turn as well (n = 48 000:
+                       67 -> 80 %); a synthesis never runs beside an analysis.  Either kind of call is pipelined only once two
+                       of them have come in a row (a host that alternates analysis and synthesis stays on one stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
+                       profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
+                       falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
+                       "pipelined_calls", "pipelined_inverse_calls", "pipelined_ordered",
+                       "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
    "carry"         0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
                        serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
    "float_carry_parallel"  0 (default) | 1 = FD float plans take the chunk-parallel carries too: long calls run at
@@ -156,6 +169,33 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        float samples from double bins, option "inverse_verify" = 1 (default), up to 500 000
                        rows -- a tree sum whose rounding interval proves the reference's float, rows it cannot prove
                        added in order), 0 = wave-parallel tree sum, unverified
+   "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
+                       plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable
+                       memory pins the pages and remembers the pin by address; a host that frees the buffer, lets the heap
+                       shrink and gets the address back later makes the next copy fault the GPU (process gone).  1 = the
+                       runtime's path: faster (the reference driver's hop, 1.6 MB out and back: 128 against
+                       197 us; long copies 55 against 26 GB/s) and safe for a host that allocates its buffers once and
+                       keeps them, like the reference's driver (test/test.c:62-83) -- as is "host_register" = 1 (110 us);
+                       get_option "host_copies_staged" counts the copies that went through the pieces
+   "host_register" 0 (default) = host buffers are copied through staging buffers; 1 = host buffers of 1 MiB and more are
+                       registered in place once (hipHostRegister, the last 8 page ranges are remembered) and the kernels
+                       read and write them over PCIe: 139 -> 111 us per 100-sample hop of the reference's test driver.
+                       ONLY for hosts that keep their buffers allocated while the plan lives (like test/test.c:62-64 of the
+                       reference): a registration does not survive free() + malloc() handing the same address out again.
+   "copy_threads"  2 (default) = worker threads of the copies between the caller's host memory and the plan's pinned slots (the host's
+                       copy of one piece overlaps the DMA of the next; a hop-sized matrix is copied by the workers and the caller
+                       together); 0 = the calling thread alone
+   "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
+                       result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
+   "spin"          1 (default) = synchronous calls never sleep on the stream while they can still be running: calls of one
+                       time chunk poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
+                       before the stream reports the kernel finished); other calls spin on the host clock until the call's
+                       bytes could have moved at the chip's peak rate, then poll the stream (a sleeping wait wakes up 9 us
+                       late on one box and 45 us late on another); 0 = sleep on the stream, 2 = poll from the start
+   "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
+                       (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
+   The others force a path the library otherwise chooses by itself -- they exist for the measurements under scripts/ and for the tests, which run
+   every path against the reference; no host needs them:
    "chunk"         samples per time chunk (0 = heuristic)
    "segments"      time segments of the exact carry pass overlapped with the forward launches
    "rows_kernel"   1 (default) = row-group forward kernel when the row fits, 0 = independent tiles
@@ -168,11 +208,6 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "hop_parts"     0 (default) = a hop-sized call's samples are cut into up to 8 time parts, every (tile of bins, part) a
                        workgroup on a CU of its own; a part's recurrence wave first runs the stream state through the samples
                        before it with the reference's own operations, so every bit stays the reference's; 1 = never, n = n parts
-   "spin"          1 (default) = synchronous calls never sleep on the stream while they can still be running: calls of one
-                       time chunk poll a completion word their kernel sets in pinned host memory (it is visible ~6 us
-                       before the stream reports the kernel finished); other calls spin on the host clock until the call's
-                       bytes could have moved at the chip's peak rate, then poll the stream (a sleeping wait wakes up 9 us
-                       late on one box and 45 us late on another); 0 = sleep on the stream, 2 = poll from the start
    "rows_split"    0 (default) | 1 = FD float rows of 2049 ... 4096 bins (a multiple of 256) as two one-slot workgroups per
                        row, each computing the one bin pair it needs of the other half itself; same bits, measured 8-14 % slower
    "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn,
@@ -191,11 +226,6 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "pointers"      0 (default) = every call asks the runtime what each pointer is (hipPointerGetAttributes: 0.06-0.16 us,
                        nothing is cached -- a buffer that was freed and whose address came back as the other kind of memory
                        is classified as what it is now), 1 = all device, 2 = all host (no query)
-   "host_register" 0 (default) = host buffers are copied through staging buffers; 1 = host buffers of 1 MiB and more are
-                       registered in place once (hipHostRegister, the last 8 page ranges are remembered) and the kernels
-                       read and write them over PCIe: 139 -> 111 us per 100-sample hop of the reference's test driver.
-                       ONLY for hosts that keep their buffers allocated while the plan lives (like test/test.c:62-64 of the
-                       reference): a registration does not survive free() + malloc() handing the same address out again.
    "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
                        launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
                        0 = carries by a pre-pass (two more launches); calls of up to 2^19 samples per channel take it
@@ -219,39 +249,12 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        below; 1 = always where it applies, -1 = never.  Same bits either way.
    "xcd_map"       1 (default) = every XCD takes a contiguous eighth of an analysis launch's (channel, chunk) workgroups, so that the
                        workgroups that run at the same time are spread over the whole matrix (n = 1e6: 77.6 -> 83.9 % of the HBM peak)
-   "copy_threads"  2 (default) = worker threads of the copies between the caller's host memory and the plan's pinned slots (the host's
-                       copy of one piece overlaps the DMA of the next; a hop-sized matrix is copied by the workers and the caller
-                       together); 0 = the calling thread alone
    "copy_streams"  2 (default) = the DMAs of such copies of 16 MiB and more alternate between the plan's stream and a second stream
                        of the plan (every DMA costs ~15 us beside its bytes; two queues fill each other's gaps: 50 -> 54.5 GB/s);
                        to what the caller queues before and after, the copy stays one operation of the plan's stream; 1 = one stream
-   "pinned_io"     1 (default) = host sample buffers of up to 64 KiB (a hop of a host signal, the sample of sdft_sdft, the
-                       result of sdft_isdft) travel through a pinned scratch of the plan that the kernels access directly
-   "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a
-                       small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
-                       other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
-                       the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
-                       stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).
-                       Asynchronous synthesis calls that come back to back take the two streams in turn as well (n = 48 000:
-                       67 -> 80 %); a synthesis never runs beside an analysis.  Either kind of call is pipelined only once two
-                       of them have come in a row (a host that alternates analysis and synthesis stays on one stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
-                       profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
-                       falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
-                       "pipelined_calls", "pipelined_inverse_calls", "pipelined_ordered",
-                       "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
-   "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
-                       plan (beyond 64 KiB): the runtime is never handed caller memory to pin.  Its own path for pageable
-                       memory pins the pages and remembers the pin by address; a host that frees the buffer, lets the heap
-                       shrink and gets the address back later makes the next copy fault the GPU (process gone).  1 = the
-                       runtime's path: faster (the reference driver's hop, 1.6 MB out and back: 128 against
-                       197 us; long copies 55 against 26 GB/s) and safe for a host that allocates its buffers once and
-                       keeps them, like the reference's driver (test/test.c:62-83) -- as is "host_register" = 1 (110 us);
-                       get_option "host_copies_staged" counts the copies that went through the pieces
    "host_direct"   1 (default) = a host matrix of up to 4 MiB is written / read by the kernels in the pinned pieces themselves
                        (over PCIe, no DMA launch: 197 against 224 us per hop), 0 = always DMA between staging matrix and pieces
    "stage_bytes"   segment size of the host-pointer staging path
-   "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
-                       (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
    "last_chain", "last_fused_exact", "last_fused_fold", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
