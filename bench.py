@@ -64,10 +64,7 @@ def parse_args():
     ap.add_argument("--cpu-samples", type=int, default=200000)
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements outside the timed regions")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the many-core CPU baseline of the batch share")
-    ap.add_argument("--no-placement", action="store_true", help="take the output matrix as the first allocation comes (no store-only probe of candidates)")
-    ap.add_argument("--placement", choices=("arena", "candidates"), default="arena",
-                    help="how the output matrix of the headline workload is placed: the best window of one large allocation, or the best of several allocations")
-    ap.add_argument("--placement-candidates", type=int, default=12)     # (a third of the allocations are of the fast kind: profiles/r05_arena_probe.txt)
+    ap.add_argument("--no-placement", action="store_true", help="take the output matrix as the first allocation comes (the line's first_allocation figure becomes the headline)")
     return ap.parse_args()
 
 
@@ -142,24 +139,31 @@ def cpu_baseline(m, window, combo, n_cpu):
     return res
 
 
-def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz, td, device):
+def north_star_shape(torch, np, SDFT, sine_sweep, cdt, m, window, combo, esz, td, device, placed=True):
     """n = 48000 (the shape the north star quotes its >= 50 % target on) on the default drop-in path:
     device pointers, NO pointer hints, synchronous calls (what a C host that just calls sdft_sdft_n
-    gets) and asynchronous ones; wall clock per call."""
+    gets) and asynchronous ones; wall clock per call.  The matrices (786 MB) are placed like the headline's
+    (sdft_hip_malloc_matrix_in_arena: the kind of memory matters at this size too); `sync_first_allocation` is the
+    synchronous call into a plain allocation."""
     n48 = 48000
     x48 = torch.from_numpy(sine_sweep(n48, dtype=td)).cuda()
-    o48 = scratch.view(-1)[: n48 * m].view(n48, m)
+    o_plain = torch.empty((n48, m), dtype=cdt, device="cuda")
+    o48, pl_a, hold_a = place_matrix(torch, (n48, m), cdt, placed=placed)
+    o48b, pl_b, hold_b = place_matrix(torch, (n48, m), cdt, placed=placed)
     b48 = n48 * (m * esz + np.dtype(td).itemsize)
-    res = {}
+    res = {"buffer_placement": {"first": {k: pl_a.get(k) for k in ("placed", "window_gbs", "start_gbs", "boundary_offset", "pair_probes", "window_probes")},
+                                "second": {k: pl_b.get(k) for k in ("placed", "window_gbs", "start_gbs", "boundary_offset")}}}
     # (async_two_buffers: a host that alternates between two matrices -- consecutive calls then overlap, option "pipeline";
     # calls into ONE matrix are ordered behind each other as on one stream)
-    o48b = torch.empty_like(o48)
-    for mode in ("sync", "async", "async_two_buffers"):
+    for mode in ("sync", "async", "async_two_buffers", "async_two_buffers_pipelined", "sync_first_allocation"):
         p = SDFT(m, window, 1.0, combo, device=device)
-        if mode != "sync":
+        if not mode.startswith("sync"):
             p.set_option("async", 1)
+        if mode == "async_two_buffers_pipelined":
+            p.set_option("pipeline", 1)
         xs48 = C.c_void_p(x48.data_ptr())
-        os48 = [C.c_void_p(o48.data_ptr()), C.c_void_p((o48b if mode == "async_two_buffers" else o48).data_ptr())]
+        first = o_plain if mode == "sync_first_allocation" else o48
+        os48 = [C.c_void_p(first.data_ptr()), C.c_void_p((o48b if mode.startswith("async_two_buffers") else first).data_ptr())]
         for i in range(6):
             p.api.sdft_n(p._p, n48, xs48, os48[i & 1])       # the raw C-ABI call, as a C host makes it
         p.synchronize(); torch.cuda.synchronize()
@@ -170,7 +174,7 @@ def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz
         w = (time.perf_counter() - t0) / 50
         res[mode] = {"ms_per_call_wall": round(w * 1e3, 4), "msamples_s_wall": round(n48 / w / 1e6, 1),
                      "gbs_wall": round(b48 / w / 1e9, 1), "frac_of_peak_wall": round(b48 / w / 1e9 / HBM_PEAK_GBS, 4)}
-        if mode == "async_two_buffers":
+        if mode.startswith("async_two_buffers"):
             res[mode]["pipelined_calls"] = int(p.get_option("pipelined_calls"))
             res[mode]["chunks"] = [int(p.get_option("last_chunks")), int(p.get_option("last_chunk_len"))]
             res[mode]["row_streams"] = {0: "none (one stream)", 1: "ordinary", 2: "by priority"}.get(int(p.get_option("pipeline_streams")) // 10, "?")
@@ -181,10 +185,16 @@ def north_star_shape(torch, np, SDFT, sine_sweep, scratch, m, window, combo, esz
             pr = p.profile()
             k48 = pr["forward"][0] / max(pr["forward"][1], 1) * 1e-3
             res["forward_kernel_gbs"] = round(b48 / k48 / 1e9, 1)
+            res["forward_kernel_frac_of_peak"] = round(b48 / k48 / 1e9 / HBM_PEAK_GBS, 4)
             res["prepass_us"] = round((pr["delta"][0] + pr["carry"][0]) / max(pr["forward"][1], 1) * 1e3, 1)
             res["launches_per_call"] = 1 if p.get_option("last_self") == 1 else 3
             res["self_carried_chunks"] = bool(p.get_option("last_self") == 1)
+            res["chunks"] = [int(p.get_option("last_chunks")), int(p.get_option("last_chunk_len"))]
         p.close()
+    del o48, o48b, o_plain
+    for h in (hold_a, hold_b):
+        if h is not None:
+            h.free()
     res["path"] = "default: pointers classified by the library on every call, no options set"
     res["note"] = "786 MB matrix: part of the write is absorbed by the 256 MiB Infinity Cache"
     return res
@@ -369,7 +379,8 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         res["config3"] = {"skipped": f"needs {need / 1e9:.1f} GB of free HBM, {free / 1e9:.1f} GB free"}
     else:
         x = torch.from_numpy(np.stack([sine_sweep(n, channel=c, channels=chs, dtype=np.float32) for c in range(chs)])).cuda()
-        d, c3_placement = place_matrix(torch, (chs, n, m), torch.complex128, m, 16, 2 if placement else 1)      # (100.7 GB: two candidates fit)
+        d, c3_placement, _ = place_matrix(torch, (chs, n, m), torch.complex128, placed=False)      # (100.7 GB: more than two stretches of memory whatever its place)
+        c3_placement["policy"] = "first allocation (a matrix of 100.7 GB spans several stretches of memory wherever it lies)"
         p = SDFT(m, window, 1.0, combo, channels=chs, device=device)
         y = None
         for _ in range(2):
@@ -459,66 +470,36 @@ def launch_ranks(args) -> int:
 TUNER_CALLS = 14        # untimed calls of a shape before its synthesis is timed (FormTuner: up to 6 candidates x 2 samples)
 
 
-def place_matrix(torch, shape, cdt, m, esz, candidates, arena=False, reserve=90 << 30, chunk_len=1960):
-    """The output matrix, in memory that streams well.  Round 5 found that how fast a large buffer can be WRITTEN depends on which
-    physical memory backs it: of twelve 16.4 GB buffers allocated one after the other in one process, seven take the row-lockstep
-    store stream at 6.4-7.1 TB/s, four at 5.85 and one in between, the same ones on every pass; loads do not care
-    (profiles/r05_buffer_placement.txt) -- a property
-    of the allocation, not of the kernel (which reaches 96-98 % of either).  A host that cares allocates a few candidates, probes each
-    with a store-only kernel (2 x 2.5 ms) and keeps the best; this function does exactly that, UNTIMED and before anything is measured,
-    and the line says so (`buffer_placement`).  `--no-placement` (or one candidate) takes the first allocation as it comes."""
+def place_matrix(torch, shape, cdt, placed=True, arena_extra=64 << 30):
+    """The output matrix.  Which memory backs a large buffer decides how fast it can be WRITTEN (rounds 5 and 6: device memory comes in kinds
+    that alternate every 16-32 GiB of an allocation, and the analysis' store stream takes a matrix that lies half in one kind and half in
+    another at 6.8-7.1 TB/s, one that lies in a single kind at 5.6-5.85: profiles/r06_stretch_map.txt) -- a property of the allocation, not of
+    the kernel.  placed: the matrix comes from the LIBRARY's call for exactly this, `sdft_hip_malloc_matrix_in_arena(bytes, bytes + 64 GiB)` --
+    what include/sdft/sdft_hip.h gives a C host -- which finds where the kind of memory changes with a few 2 GiB probes and returns the window
+    centred there (untimed, before the warm-up; the line carries the call's own record: `buffer_placement`).  Not placed (--no-placement, shapes
+    the call does not cover, or a rank whose arena does not fit): the first allocation as it comes.  Returns (tensor, info, holder)."""
     import math
     from sdft_amd import capi
-    lib = capi.load()
-    nbytes = math.prod(shape) * esz
-    probe_ok = candidates > 1 and nbytes >= (64 << 20)         # (the probe writes rows of 16 KiB whatever the matrix's own rows are)
-    if arena and probe_ok and (4 << 30) <= nbytes < (96 << 30):
-        # Round 5, last finding: a matrix is fast exactly when its halves lie in different stretches of an allocation (profiles/r05_split_matrix.txt), and
-        # where the stretches meet inside one large allocation a window of the matrix' size straddles them (profiles/r05_arena_probe.txt).  So: ONE large
-        # allocation, the probe on a window every 4 GiB, the matrix is the best window (a view; the allocation lives as long as the matrix).  Larger
-        # matrices are less at risk but not safe: 50 GB inside the first 64 GiB of an allocation take 5.9 TB/s, elsewhere 6.9-7.2 (profiles/r05_arena_probe.txt).  (What the library offers a C host as sdft_hip_malloc_matrix_in_arena; spelled out here so
-        # that the line can list every window's rate.)
-        step = 4 << 30
+    nbytes = math.prod(shape) * torch.empty(0, dtype=cdt).element_size()
+    why = "--no-placement" if not placed else None
+    if placed and not ((64 << 20) <= nbytes < (96 << 30)):
+        why = "no placement for this size"
+    if why is None:
         free, _ = torch.cuda.mem_get_info()
-        abytes = (min(free - reserve, max(12 * nbytes, 200 << 30)) // step) * step
-        if abytes >= nbytes + 2 * step:
-            try:
-                block = torch.empty(abytes, dtype=torch.uint8, device="cuda")
-            except RuntimeError:
-                block = None
-            if block is not None:
-                offs = list(range(0, abytes - nbytes + 1, step))
-                rates = []
-                for o in offs:
-                    ms = lib.sdft_hip_store_ceiling(block.data_ptr() + o, (nbytes // 16384) * 16384, 4, 1024, 8, chunk_len, 2)
-                    rates.append(round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0)
-                torch.cuda.synchronize()
-                best = max(range(len(offs)), key=lambda i: rates[i])
-                out = block[offs[best]:offs[best] + nbytes].view(cdt).view(shape)
-                info = {"policy": "the best window of ONE allocation of %.0f GB (a window of the matrix' size every 4 GiB) by a store-only probe, untimed, before the warm-up "
-                                  "(--placement candidates: separate allocations; --no-placement: the first allocation)" % (abytes / 1e9),
-                        "probed_store_only_gbs": rates, "chosen": best}
-                return out, info
-    kept, rates = [], []
-    for i in range(max(1, candidates) if probe_ok else 1):
-        free, _ = torch.cuda.mem_get_info()
-        if i > 0 and free < nbytes * 1.1:
-            break
-        t = torch.empty(shape, dtype=cdt, device="cuda")
-        kept.append(t)
-        if not probe_ok:
-            break
-        torch.cuda.synchronize()
-        ms = lib.sdft_hip_store_ceiling(t.data_ptr(), (nbytes // 16384) * 16384, 4, 1024, 8, 1960, 2)
-        torch.cuda.synchronize()
-        rates.append(round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0)
-    best = max(range(len(kept)), key=lambda i: rates[i]) if rates else 0
-    out = kept[best]
-    del kept, t
-    torch.cuda.empty_cache()
-    info = {"policy": "best of up to %d allocations by a store-only probe, untimed, before the warm-up (--no-placement: the first allocation)" % candidates,
-            "probed_store_only_gbs": rates, "chosen": best} if probe_ok else {"policy": "first allocation (no probe for this shape)" if candidates > 1 else "first allocation (--no-placement)"}
-    return out, info
+        if free < nbytes + arena_extra + (8 << 30):
+            why = f"the arena does not fit ({free / 1e9:.0f} GB free)"
+    if why is None:
+        try:
+            pm = capi.PlacedMatrix(shape, cdt, arena_extra)
+            info = {"policy": "sdft_hip_malloc_matrix_in_arena(bytes, bytes + 64 GiB): the window centred on the first change of the kind of memory "
+                              "inside one allocation, found by two-part store probes; untimed, before the warm-up (--no-placement: the first allocation)",
+                    "placed": True, "matrix_bytes": nbytes}
+            info.update(pm.info)
+            return pm.tensor, info, pm
+        except Exception as e:                                   # (out of memory on this rank: say so, take the first allocation)
+            why = f"sdft_hip_malloc_matrix_in_arena failed: {str(e)[:120]}"
+    t = torch.empty(shape, dtype=cdt, device="cuda")
+    return t, {"policy": f"first allocation ({why})", "placed": False, "matrix_bytes": nbytes}, None
 
 
 def main():
@@ -581,9 +562,14 @@ def main():
         xh = np.stack([sine_sweep(n, channel=c, channels=channels_total, dtype=td) for c in range(first, first + count)])
     x = torch.from_numpy(xh).cuda()
     shape = (n, m) if count == 1 else (count, n, m)
-    # (beside the headline matrix the single workload later places a second one of its size, the batch workload nothing large)
-    out, placement = place_matrix(torch, shape, cdt, m, esz, 1 if args.no_placement else args.placement_candidates, arena=args.placement == "arena",
-                                  reserve=(90 << 30) if count == 1 else (24 << 30), chunk_len=1960 if count == 1 else 6000)
+    # The matrix a plain host has: the FIRST allocation of the process, as hipMalloc hands it out (the reference's contract is a caller-allocated
+    # matrix, sdft.h:605).  Timed below with the same --steps as the headline and reported beside it (`first_allocation`).
+    out_first = torch.empty(shape, dtype=cdt, device="cuda")
+    # ... and the matrix a host gets that asks the library for the memory (include/sdft/sdft_hip.h): the headline's
+    out, placement, out_holder = place_matrix(torch, shape, cdt, placed=not args.no_placement)
+    if not placement["placed"]:
+        del out
+        out = out_first                                       # (no second matrix: the headline IS the first allocation)
 
     stream = torch.cuda.Stream()
     plan = SDFT(m, window, 1.0, combo, channels=count, device=local_rank)
@@ -595,28 +581,49 @@ def main():
         plan.synchronize()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        plan.sdft(x, out)
-        if w == 0 and args.warmup > 1:
-            sync(); plan.profile()       # the first call allocates the workspace: not representative
-    sync()
-    warm = plan.profile()                # warm-up pass: per-stage events (delta, carries, forward)
+    def timed_region(matrix):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides (the contract's region)."""
+        plan.set_option("profile", 1)
+        for w in range(args.warmup):
+            plan.sdft(x, matrix)
+            if w == 0 and args.warmup > 1:
+                sync(); plan.profile()       # the first call allocates the workspace: not representative
+        sync()
+        warm = plan.profile()                # warm-up pass: per-stage events (delta, carries, forward)
+        plan.set_option("profile", 2)        # timed region: only the event pair around the dominant kernel
+        shard.barrier(local_rank)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.sdft(x, matrix)
+        sync()
+        shard.barrier(local_rank)
+        sync()
+        return time.perf_counter() - t0, plan.profile(), warm
+
+    elapsed, prof, warm = timed_region(out)
     prepass_ms = (warm["delta"][0] + warm["carry"][0]) / max(warm["forward"][1], 1)
-    plan.set_option("profile", 2)        # timed region: only the event pair around the dominant kernel
-    shard.barrier(local_rank)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.sdft(x, out)
-    sync()
-    shard.barrier(local_rank)
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = plan.profile()
 
     units = float(count * n * args.steps)
     rate, secs = shard.job_throughput(units, elapsed, local_rank)
     local_elapsed = elapsed
+    bytes_per_launch = count * n * (m * esz + np.dtype(td).itemsize)
+    # the same region into the process' first allocation (every rank; the same K and W)
+    # (every rank runs the region, placed or not: its barriers are collective)
+    first_elapsed, first_prof, _ = timed_region(out_first)
+    first_rate, first_secs = shard.job_throughput(units, first_elapsed, local_rank)
+    ff_ms, ff_calls = first_prof["forward"]
+    first_kernel_gbs = bytes_per_launch / (ff_ms / max(ff_calls, 1) * 1e-3) / 1e9 if ff_ms > 0 else 0.0
+    first_allocation = {
+        "value": round(first_rate / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(first_secs / args.steps * 1e3, 4),
+        "frac": round(first_kernel_gbs / HBM_PEAK_GBS, 4), "frac_is": "the kernel's algorithmic bytes / its HIP-event time / 8 TB/s, as roofline.frac",
+        "is": "the same K timed steps into the process' FIRST allocation of the matrix' size (a plain hipMalloc, what a host of the reference has: "
+              "sdft.h:605 'already allocated'); `value` is the matrix the library placed (buffer_placement)" if out is not out_first else
+              "this IS the headline: the matrix was not placed",
+    }
+    if out is not out_first:
+        del out_first                                         # (the side measurements need the room)
+        torch.cuda.empty_cache()
 
     # the same step one at a time (SURVEY.md 8d asks for a median): wall clock around one synchronised call each, and the
     # kernel's own HIP events launch by launch; outside the contract's timed region above
@@ -668,7 +675,6 @@ def main():
 
     # roofline of the dominant kernel (this rank's launches; every rank runs the same shape)
     f_ms, f_calls = prof["forward"]
-    bytes_per_launch = count * n * (m * esz + np.dtype(td).itemsize)
     f_avg_ms = f_ms / max(f_calls, 1)
     achieved = bytes_per_launch / (f_avg_ms * 1e-3) / 1e9 if f_avg_ms > 0 else 0.0
     traffic = None
@@ -683,7 +689,8 @@ def main():
 
     # N > 1: what makes the record checkable without logs -- how many ranks the collectives saw, on how many distinct GPUs,
     # and the spread of the per-rank step time and roofline fraction (every rank runs the same shape on its own channels)
-    census = shard.run_census(local_elapsed / args.steps * 1e3, achieved / HBM_PEAK_GBS, local_rank) if distributed else None
+    census = shard.run_census(local_elapsed / args.steps * 1e3, achieved / HBM_PEAK_GBS, local_rank, placement_gbs=float(placement.get("window_gbs", 0.0)),
+                              placed=bool(placement["placed"]), first_frac=first_kernel_gbs / HBM_PEAK_GBS) if distributed else None
     kernel_names = {1: "forward_kernel", 2: "forward_rows_kernel", 3: "forward_hop_kernel"}
     result = {
         "metric": "Msamples/s analysis+synthesis, m=1024 Hann fp64; achieved HBM GB/s vs peak",
@@ -706,6 +713,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64" if esz == 16 else "f32",
         "data": "synthetic",
+        "first_allocation": first_allocation,
         "buffer_placement": placement,
         "config": {
             "workload": name,
@@ -725,6 +733,11 @@ def main():
             "ms_per_step_min_over_ranks": round(census["seconds_min"], 4), "ms_per_step_max_over_ranks": round(census["seconds_max"], 4),
             "roofline_frac_min_over_ranks": round(census["roofline_frac_min"], 4), "roofline_frac_max_over_ranks": round(census["roofline_frac_max"], 4),
             "per_gpu_msamples_s": round(rate / 1e6 / max(n_gpus, 1), 3),
+            "ranks_with_a_placed_matrix": census["ranks_placed"],
+            "placement_gbs_min_over_ranks": round(census["placement_gbs_min"], 1), "placement_gbs_max_over_ranks": round(census["placement_gbs_max"], 1),
+            "first_allocation_frac_min_over_ranks": round(census["first_allocation_frac_min"], 4),
+            "first_allocation_frac_max_over_ranks": round(census["first_allocation_frac_max"], 4),
+            "placement_note": "buffer_placement is rank 0's; a rank whose arena did not fit took its first allocation (placement_gbs 0 in the minimum)",
         },
         "roofline": {
             "bound": "hbm",
@@ -841,50 +854,64 @@ def main():
                       "fp64_instruction_slots_frac prices every instruction as an FMA slot of the 78.6 TFLOP/s peak -- with a third fewer "
                       "instructions to issue the fraction says less than the time does")
         result["fused_process"] = fp
-        if workload == "single" and out.numel() >= 48000 * m:
-            result["north_star_n48000"] = north_star_shape(torch, np, SDFT, sine_sweep, out, m, window, combo, esz, td, local_rank)
+        if workload == "single":
+            result["north_star_n48000"] = north_star_shape(torch, np, SDFT, sine_sweep, cdt, m, window, combo, esz, td, local_rank, placed=not args.no_placement)
         if workload == "single" and count == 1:
             # the headline workload as a host that alternates between two matrices runs it: asynchronous calls on the plan's own
             # stream, pipelined; outside the contract's timed region, which stays one matrix on the caller's stream
+            out2_holder = None
             try:
-                out2, _ = place_matrix(torch, tuple(out.shape), cdt, m, esz, 1 if args.no_placement else 4)
-                pp = SDFT(m, window, 1.0, combo, device=local_rank)
-                pp.set_option("async", 1)
+                # (both matrices placed the same way: each the window of an arena of its own, bytes + 64 GiB -- round 5 compared a placed
+                # matrix with the best of four separate allocations)
+                out2, place2, out2_holder = place_matrix(torch, tuple(out.shape), cdt, placed=placement["placed"])
+                tm = {"workload": name, "placement": {"first": placement.get("window_gbs"), "second": place2.get("window_gbs"),
+                                                        "is": "store-only GB/s of the two matrices, each placed by sdft_hip_malloc_matrix_in_arena" if place2["placed"] else place2["policy"]}}
                 ptr = [C.c_void_p(out.data_ptr()), C.c_void_p(out2.data_ptr())]
                 xptr = C.c_void_p(x.data_ptr())
-                for i in range(4):
-                    pp.api.sdft_n(pp._p, n, xptr, ptr[i & 1])
-                pp.synchronize(); torch.cuda.synchronize()
-                tq = time.perf_counter()
-                for i in range(10):
-                    pp.api.sdft_n(pp._p, n, xptr, ptr[i & 1])
-                pp.synchronize(); torch.cuda.synchronize()
-                wq = (time.perf_counter() - tq) / 10
-                result["two_matrices_in_turn"] = {"workload": name, "ms_per_call_wall": round(wq * 1e3, 4), "msamples_s": round(n / wq / 1e6, 1),
-                                                  "frac_of_peak_wall": round(n * (m * esz + np.dtype(td).itemsize) / wq / 1e9 / HBM_PEAK_GBS, 4),
-                                                  "pipelined_calls": int(pp.get_option("pipelined_calls")),
-                                                  "chunks": [int(pp.get_option("last_chunks")), int(pp.get_option("last_chunk_len"))],
-                                                  "note": "asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn (option pipeline, default)"}
-                # ... and the synthesis of the two matrices in turn (stateless: the calls go to the two row streams in turn)
-                y2 = [torch.empty(n, dtype=x.dtype, device="cuda") for _ in range(2)]
-                yptr = [C.c_void_p(y2[0].data_ptr()), C.c_void_p(y2[1].data_ptr())]
-                for i in range(12):
-                    pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
-                    if i >= 2:
-                        pp.synchronize()
-                pp.synchronize(); torch.cuda.synchronize()
-                tq = time.perf_counter()
-                for i in range(10):
-                    pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
-                pp.synchronize(); torch.cuda.synchronize()
-                wq = (time.perf_counter() - tq) / 10
-                result["two_matrices_in_turn"].update({"synthesis_ms_per_call_wall": round(wq * 1e3, 4), "synthesis_msamples_s": round(n / wq / 1e6, 1),
-                                                       "synthesis_frac_of_peak_wall": round(n * (m * esz + np.dtype(td).itemsize) / wq / 1e9 / HBM_PEAK_GBS, 4),
-                                                       "pipelined_synthesis_calls": int(pp.get_option("pipelined_inverse_calls"))})
-                pp.close()
-                del out2, y2
+                bq = n * (m * esz + np.dtype(td).itemsize)
+                for label, pipe in (("pipelined", 1), ("one_stream", 0), ("library_default", None)):
+                    pp = SDFT(m, window, 1.0, combo, device=local_rank)
+                    pp.set_option("async", 1)
+                    if pipe is not None:
+                        pp.set_option("pipeline", pipe)
+                    for i in range(4):
+                        pp.api.sdft_n(pp._p, n, xptr, ptr[i & 1])
+                    pp.synchronize(); torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    for i in range(10):
+                        pp.api.sdft_n(pp._p, n, xptr, ptr[i & 1])
+                    pp.synchronize(); torch.cuda.synchronize()
+                    wq = (time.perf_counter() - tq) / 10
+                    tm[label] = {"ms_per_call_wall": round(wq * 1e3, 4), "msamples_s": round(n / wq / 1e6, 1), "frac_of_peak_wall": round(bq / wq / 1e9 / HBM_PEAK_GBS, 4),
+                                 "pipelined_calls": int(pp.get_option("pipelined_calls")),
+                                 "chunks": [int(pp.get_option("last_chunks")), int(pp.get_option("last_chunk_len"))]}
+                    if pipe is None:
+                        # ... and the synthesis of the two matrices in turn (stateless: the calls go to the two row streams in turn)
+                        y2 = [torch.empty(n, dtype=x.dtype, device="cuda") for _ in range(2)]
+                        yptr = [C.c_void_p(y2[0].data_ptr()), C.c_void_p(y2[1].data_ptr())]
+                        for i in range(2 * TUNER_CALLS):
+                            pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
+                            if i >= 2:
+                                pp.synchronize()
+                        pp.synchronize(); torch.cuda.synchronize()
+                        tq = time.perf_counter()
+                        for i in range(10):
+                            pp.api.isdft_n(pp._p, n, ptr[i & 1], yptr[i & 1])
+                        pp.synchronize(); torch.cuda.synchronize()
+                        wq = (time.perf_counter() - tq) / 10
+                        tm.update({"synthesis_ms_per_call_wall": round(wq * 1e3, 4), "synthesis_msamples_s": round(n / wq / 1e6, 1),
+                                   "synthesis_frac_of_peak_wall": round(bq / wq / 1e9 / HBM_PEAK_GBS, 4),
+                                   "pipelined_synthesis_calls": int(pp.get_option("pipelined_inverse_calls"))})
+                        del y2
+                    pp.close()
+                tm["note"] = ("asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn: option pipeline = 1 (the rows of consecutive calls on two "
+                              "streams), = 0 (one stream), and the library's default, which pipelines only calls of less than two rounds of the chip")
+                result["two_matrices_in_turn"] = tm
+                del out2
             except Exception as e:                              # (a second 16 GB matrix: not on every box)
                 result["two_matrices_in_turn"] = {"error": str(e)[:200]}
+            if out2_holder is not None:
+                out2_holder.free()
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)
         if not args.no_cpu_baseline:
             result["hop100_m1000"]["cpu_reference"] = cpu_hop_baseline(np, sine_sweep, combo, td)
@@ -910,13 +937,17 @@ def main():
             # one GPU's share of configs[4] (64 channels x 48000): the like-for-like N = 1 point of the
             # 1 -> 8 GPU curve the driver builds from the N > 1 runs of this script
             plan.close(); del out, y
+            if out_holder is not None:
+                out_holder.free(); out_holder = None
             torch.cuda.empty_cache()
             chs, nb_ = args.channels_per_gpu, 48000
             free, _ = torch.cuda.mem_get_info()
             if free > chs * nb_ * m * esz * 1.05:
                 xb = torch.from_numpy(np.stack([sine_sweep(nb_, channel=c, channels=chs, dtype=td) for c in range(chs)])).cuda()
-                ob, share_placement = place_matrix(torch, (chs, nb_, m), cdt, m, esz, 1 if args.no_placement else 4, arena=args.placement == "arena",
-                                                   reserve=24 << 30, chunk_len=6000)
+                ob_first = torch.empty((chs, nb_, m), dtype=cdt, device="cuda")        # (what N > 1 runs report as first_allocation)
+                ob, share_placement, ob_holder = place_matrix(torch, (chs, nb_, m), cdt, placed=not args.no_placement)
+                if not share_placement["placed"]:
+                    del ob; ob = ob_first
                 pb = SDFT(m, window, 1.0, combo, channels=chs, device=local_rank)
                 pb.set_option("async", 1)
                 yb = None
@@ -946,7 +977,16 @@ def main():
                     "ms_per_call_analysis": round(wa * 1e3, 3),
                     "buffer_placement": share_placement,
                 }
-                pb.close(); del ob, xb, yb
+                if ob is not ob_first:
+                    tb = time.perf_counter()
+                    for _ in range(reps):
+                        pb.sdft(xb, ob_first)
+                    pb.synchronize(); torch.cuda.synchronize()
+                    wf = (time.perf_counter() - tb) / reps
+                    share["first_allocation"] = {"analysis_msamples_s": round(chs * nb_ / wf / 1e6, 2), "analysis_frac_of_peak": round(bb / wf / 1e9 / HBM_PEAK_GBS, 4)}
+                pb.close(); del ob, ob_first, xb, yb
+                if ob_holder is not None:
+                    ob_holder.free()
                 torch.cuda.empty_cache()
                 if not args.no_cpu_all_cores:
                     import subprocess

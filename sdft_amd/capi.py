@@ -74,7 +74,58 @@ UNTYPED = {
     "sdft_hip_malloc_matrix": (C.c_void_p, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "sdft_hip_malloc_matrix_in_arena": (C.c_void_p, [C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]),
     "sdft_hip_free_matrix": (C.c_int, [C.c_void_p]),
+    "sdft_hip_matrix_placement": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
+
+
+class Placement(C.Structure):
+    """sdft_hip_placement_t (include/sdft/sdft_hip.h)."""
+    _fields_ = [("arena_bytes", C.c_size_t), ("window_offset", C.c_size_t), ("boundary_offset", C.c_size_t),
+                ("pair_probes", C.c_int), ("window_probes", C.c_int),
+                ("window_gbs", C.c_double), ("start_gbs", C.c_double), ("probe_ms", C.c_double)]
+
+    def as_dict(self) -> dict:
+        return {"arena_bytes": int(self.arena_bytes), "window_offset": int(self.window_offset), "boundary_offset": int(self.boundary_offset),
+                "pair_probes": int(self.pair_probes), "window_probes": int(self.window_probes),
+                "window_gbs": round(float(self.window_gbs), 1), "start_gbs": round(float(self.start_gbs), 1), "probe_ms": round(float(self.probe_ms), 2)}
+
+
+class PlacedMatrix:
+    """A DFT matrix in device memory placed by the library (sdft_hip_malloc_matrix_in_arena), seen as a torch tensor (a view: no copy;
+    the allocation lives until free()).  Test and bench plumbing: a C host uses the two calls directly."""
+
+    def __init__(self, shape, torch_dtype, arena_extra: int = 64 << 30):
+        import math
+        import torch
+        lib = load()
+        self.lib = lib
+        self.nbytes = math.prod(shape) * torch.empty(0, dtype=torch_dtype).element_size()
+        gbs = C.c_double(0.0)
+        self.ptr = lib.sdft_hip_malloc_matrix_in_arena(self.nbytes, self.nbytes + arena_extra, C.byref(gbs))
+        if not self.ptr:
+            err = lib.sdft_hip_last_error()
+            lib.sdft_hip_clear_error()
+            raise SdftHipError((err or b"sdft_hip_malloc_matrix_in_arena failed").decode())
+        info = Placement()
+        lib.sdft_hip_matrix_placement(C.c_void_p(self.ptr), C.byref(info))
+        self.info = info.as_dict()
+        typestr = {torch.complex128: "<c16", torch.complex64: "<c8", torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1"}[torch_dtype]
+        holder = type("DevicePointer", (), {"__cuda_array_interface__": {"shape": tuple(shape), "typestr": typestr, "data": (int(self.ptr), False),
+                                                                          "version": 2, "strides": None}})()
+        self.tensor = torch.as_tensor(holder, device=torch.device("cuda", torch.cuda.current_device()))
+        assert self.tensor.data_ptr() == self.ptr
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.tensor = None
+            self.lib.sdft_hip_free_matrix(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def symbol(name: str, combo: str) -> str:

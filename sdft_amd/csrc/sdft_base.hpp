@@ -197,6 +197,11 @@ template <typename FD> SDFT_D FD wave_sum_f(FD v)
   return v;
 }
 
+// the rounding-interval proof of the tree sums accepts a result only when both ends of the interval round to the SAME BITS:
+// -0.0f == +0.0f compares equal, and the reference's ordered sum may land on either zero (results below the smallest subnormal)
+SDFT_D bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+SDFT_D bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
 template <typename FD> struct BinState { cx<FD> acc, fid, tw; };
 
 // Completion word for synchronous short calls.  A kernel's end reaches the host ~6 us later than a store to pinned

@@ -257,6 +257,28 @@ __global__ __launch_bounds__(1024) void store_rowgroup_kernel(v2f64* dst, size_t
   }
 }
 
+// The same store stream (16 KiB rows in step, every XCD a contiguous eighth of the chunks) into a matrix whose two halves lie at two
+// places: what tells whether two places of an allocation are the same KIND of memory (round 6, profiles/r06_stretch_map.txt: device
+// memory comes in kinds that alternate every 16-32 GiB of a large allocation; the halves of a matrix written at the same time take
+// the stream at 6.8-7.1 TB/s when they are of different kinds and at 5.6-5.8 when of one).
+struct StoreParts { unsigned long long base[2]; };
+__global__ __launch_bounds__(1024) void store_parts_kernel(StoreParts parts, size_t rows, unsigned chunk_len)
+{
+  const unsigned R = 8, q = gridDim.x / R, r = gridDim.x % R, x = blockIdx.x % R;
+  const unsigned chunk = x * q + (x < r ? x : r) + blockIdx.x / R;
+  const size_t t0 = (size_t)chunk * chunk_len, t1 = t0 + chunk_len < rows ? t0 + chunk_len : rows;
+  const size_t per = (rows + 1) / 2;
+  v2f64 v; v.x = (double)threadIdx.x; v.y = 2.0;
+  unsigned since = 0;
+  for (size_t t = t0; t < t1; ++t)
+  {
+    const size_t p = t / per;
+    reinterpret_cast<v2f64*>(parts.base[p])[(t - p * per) * 1024 + threadIdx.x] = v;
+    v.x += 1.0;
+    if (++since == 8) { __syncthreads(); since = 0; }
+  }
+}
+
 // load-only counterpart of store_rowgroup_kernel (the synthesis' ceiling by access shape): one workgroup of row_slots/64 waves per
 // chunk of rows reads whole rows in step (16 bytes per lane), `depth` rows in flight per lane; regions as above (0: workgroup b
 // -> chunk b)
@@ -350,7 +372,7 @@ double sdft_hip_store_ceiling(void* dst, size_t bytes, int pattern, unsigned row
       const size_t rows = slots / row_slots;
       const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
       const dim3 b(((row_slots + 63) / 64) * 64), g(chunks);
-      const unsigned sync_every = lanes, regions = pattern >= 100 ? (unsigned)(pattern - 100) : 8u;
+      const unsigned sync_every = lanes, regions = pattern > 100 ? (unsigned)(pattern - 100) : 8u;     // (pattern 100 would be no region at all: eight)
       if (pattern == 2) hipLaunchKernelGGL((store_rowgroup_kernel<false, 0, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
       else if (pattern == 3) hipLaunchKernelGGL((store_rowgroup_kernel<true, 0, false>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
       else if (pattern == 5) hipLaunchKernelGGL((store_rowgroup_kernel<false, 0, true>), g, b, 0, 0, (v2f64*)dst, rows, row_slots, chunk_len, sync_every, regions);
@@ -460,11 +482,56 @@ void* sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs)
   return best;
 }
 
-// the same choice inside one allocation: window -> allocation base, for sdft_hip_free_matrix
-namespace sdfthip {
-static std::mutex g_arena_mutex;
-static std::vector<std::pair<void*, void*>> g_arenas;       // (window, base)
+// ------------------------------------------------------------------------------------------
+// The same choice made inside ONE allocation, by what round 6 learnt about device memory (profiles/r06_stretch_map.txt): a large
+// allocation is made of stretches of two or three KINDS of memory that alternate every 16-32 GiB (the first change of kind lies
+// 32 or 64 GiB into the allocation in every session kept; the same map whichever place it is taken from: an equivalence, most
+// likely the high physical address bits that select a rank of the HBM stacks, i.e. another set of DRAM banks), and the analysis'
+// store stream -- every XCD writing its own eighth of the matrix at the same time -- runs at 6.8-7.1 TB/s when the matrix lies
+// half in one kind and half in another, at 5.6-5.85 when all of it is of one kind.  So the place of a matrix is COMPUTED:
+// small two-part probes (2 GiB written, 0.35 ms each) find the first place where the kind changes -- steps of 16 GiB, then
+// bisection to 1 GiB -- and the matrix is the window centred on it.  Two full-size probes (the window, and a window at the
+// allocation's start: what a plain hipMalloc would have been) check the result and the better of the two is returned; only an
+// arena in which no change of kind is within reach is searched the old way (a window every 4 GiB, at most 8).
+// ------------------------------------------------------------------------------------------
+extern "C" {
+// (layout of include/sdft/sdft_hip.h; this file sees no public header)
+typedef struct
+{
+  size_t arena_bytes, window_offset, boundary_offset;
+  int    pair_probes, window_probes;
+  double window_gbs, start_gbs, probe_ms;
+} sdft_hip_placement_t;
 }
+namespace sdfthip {
+struct ArenaEntry { void* window; void* base; sdft_hip_placement_t info; };
+static std::mutex g_arena_mutex;
+static std::vector<ArenaEntry> g_arenas;
+
+// GB/s of the two-part store stream with parts of `part_bytes` at a and b (1 warm-up + 2 timed launches); 0 on failure
+static double pair_rate(char* a, char* b, size_t part_bytes, double* ms_total)
+{
+  const size_t rows = 2 * (part_bytes / 16384);
+  const unsigned chunk_len = (unsigned)std::max<size_t>(8, (rows + 510) / 511);
+  const unsigned chunks = (unsigned)((rows + chunk_len - 1) / chunk_len);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return 0.0; }
+  StoreParts parts{{(unsigned long long)a, (unsigned long long)b}};
+  hipLaunchKernelGGL(store_parts_kernel, dim3(chunks), dim3(1024), 0, 0, parts, rows, chunk_len);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(store_parts_kernel, dim3(chunks), dim3(1024), 0, 0, parts, rows, chunk_len);
+  (void)hipEventRecord(e1, 0);
+  float ms = 0.f;
+  const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+  if (!ok) (void)hipGetLastError();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (!ok) return 0.0;
+  if (ms_total) *ms_total += 1.5 * ms;
+  return (double)rows * 16384.0 / (ms / 2 * 1e-3) / 1e9;
+}
+}  // namespace sdfthip
+
 void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs)
 {
   using namespace sdfthip;
@@ -472,23 +539,88 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
   if (bytes == 0 || arena_bytes < bytes) { set_error("sdft_hip_malloc_matrix_in_arena", "the arena is smaller than the matrix"); return nullptr; }
   char* base = nullptr;
   if (hipMalloc((void**)&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_malloc_matrix_in_arena", "out of device memory"); return nullptr; }
-  const size_t step = (size_t)4 << 30;
-  size_t best_off = 0;
-  double best_ms = 0.0;
+  sdft_hip_placement_t info;
+  memset(&info, 0, sizeof info);
+  info.arena_bytes = arena_bytes;
+  const size_t GiB = (size_t)1 << 30, room = arena_bytes - bytes;         // the window may start anywhere in [0, room]
+  size_t off = 0;
   if (bytes >= ((size_t)64 << 20))
   {
     const size_t rows = bytes / 16384;
     const unsigned chunk_len = (unsigned)std::max<size_t>(8, (rows + 510) / 511);       // two rounds of the chip, as the analysis cuts time
-    for (size_t off = 0; off + bytes <= arena_bytes; off += step)
+    auto window_rate = [&](size_t o) {
+      const double ms = sdft_hip_store_ceiling(base + o, rows * 16384, 4, 1024, 8, chunk_len, 2);
+      ++info.window_probes;
+      if (ms > 0.0) info.probe_ms += 3.0 * ms;
+      return ms > 0.0 ? (double)(rows * 16384) / (ms * 1e-3) / 1e9 : 0.0;
+    };
+    // ---- where does the kind of memory change?  (parts of 1 GiB; a change shows as >= 1.1 x the rate of two parts of the start's kind) ----
+    const size_t part = GiB, step = 16 * GiB;
+    size_t found = 0;                                                    // offset of the change the window is centred on (0: none)
+    if (arena_bytes >= 3 * part && room >= GiB)
     {
-      const double ms = sdft_hip_store_ceiling(base + off, rows * 16384, 4, 1024, 8, chunk_len, 2);
-      if (ms > 0.0 && (best_ms == 0.0 || ms < best_ms)) { best_ms = ms; best_off = off; }
+      const double same = pair_rate(base, base + part, part, &info.probe_ms);
+      ++info.pair_probes;
+      auto differs = [&](size_t o) { ++info.pair_probes; return same > 0.0 && pair_rate(base, base + o, part, &info.probe_ms) > 1.1 * same; };
+      // the centred window [b - bytes / 2, b + bytes / 2) has to fit: b <= room + bytes / 2; a change before bytes / 2 leaves the window at the
+      // start (it straddles the change, off centre) -- kept in reserve, a later change that allows centring is preferred
+      size_t early = 0;
+      for (size_t o = step; o + part <= arena_bytes && o <= room + bytes / 2 + step && info.pair_probes < 12; o += step)
+      {
+        if (!differs(o)) continue;
+        size_t lo = o - step, hi = o;                                    // the kind changes in (lo, hi]: bisect to 1 GiB
+        while (hi - lo > GiB && info.pair_probes < 16)
+        {
+          const size_t mid = lo + ((hi - lo) / 2 / GiB) * GiB;
+          if (mid == lo || mid + part > arena_bytes) break;
+          if (differs(mid)) hi = mid; else lo = mid;
+        }
+        if (hi > room + bytes / 2) break;
+        if (2 * hi >= bytes) { found = hi; break; }
+        if (!early) early = hi;
+        break;                                                           // (beyond the first change the reference kind is no longer the start's: stop here)
+      }
+      if (!found && early) found = early;
+    }
+    info.boundary_offset = found;
+    info.start_gbs = window_rate(0);
+    info.window_gbs = info.start_gbs;
+    if (found)
+    {
+      const size_t centred = 2 * found >= bytes ? ((found - bytes / 2) >> 21) << 21 : 0;      // 2 MiB aligned
+      const size_t cand = std::min(centred, (room >> 21) << 21);
+      if (cand > 0)
+      {
+        const double r = window_rate(cand);
+        if (r > info.window_gbs) { info.window_gbs = r; off = cand; }
+      }
+    }
+    if (!found)
+    {
+      // no change of kind within reach (a small arena): the search of round 5, a window every 4 GiB, at most 8 of them
+      const size_t scan = (size_t)4 << 30;
+      for (size_t o = scan; o <= room && info.window_probes < 9; o += scan)
+      {
+        const double r = window_rate(o);
+        if (r > info.window_gbs) { info.window_gbs = r; off = o; }
+      }
     }
   }
-  if (gbs && best_ms > 0.0) *gbs = (double)((bytes / 16384) * 16384) / (best_ms * 1e-3) / 1e9;
+  info.window_offset = off;
+  if (gbs) *gbs = info.window_gbs;
   std::lock_guard<std::mutex> lock(g_arena_mutex);
-  g_arenas.emplace_back((void*)(base + best_off), (void*)base);
-  return base + best_off;
+  g_arenas.push_back(ArenaEntry{(void*)(base + off), (void*)base, info});
+  return base + off;
+}
+// how a window of sdft_hip_malloc_matrix_in_arena was placed: 0, or -1 for a pointer that call did not return
+int sdft_hip_matrix_placement(const void* window, sdft_hip_placement_t* out)
+{
+  using namespace sdfthip;
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  for (const ArenaEntry& e : g_arenas)
+    if (e.window == window) { if (out) *out = e.info; return 0; }
+  set_error("sdft_hip_matrix_placement", "not a window of sdft_hip_malloc_matrix_in_arena");
+  return -1;
 }
 int sdft_hip_free_matrix(void* window)
 {
@@ -497,7 +629,7 @@ int sdft_hip_free_matrix(void* window)
   {
     std::lock_guard<std::mutex> lock(g_arena_mutex);
     for (size_t i = 0; i < g_arenas.size(); ++i)
-      if (g_arenas[i].first == window) { base = g_arenas[i].second; g_arenas.erase(g_arenas.begin() + (long)i); break; }
+      if (g_arenas[i].window == window) { base = g_arenas[i].base; g_arenas.erase(g_arenas.begin() + (long)i); break; }
   }
   if (!base) { set_error("sdft_hip_free_matrix", "not a window of sdft_hip_malloc_matrix_in_arena"); return -1; }
   if (hipFree(base) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_free_matrix", "hipFree failed"); return -1; }

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
           const FD e = all * ((FD)2.5e-16 * (FD)term_bins);               // 2*g*sum|term| with 12 % to spare (g ~ n * 1.11e-16)
           const TD ylo = (TD)((sum - e) * fz.sweight), yhi = (TD)((sum + e) * fz.sweight);
           TD out = ylo;
-          if (!(ylo == yhi))                                                // wave-uniform: every lane holds the same sums
+          if (!same_bits(ylo, yhi))                                         // wave-uniform: every lane holds the same sums
           {
             typedef FD tvec __attribute__((ext_vector_type(2)));
             FD ordered = (FD)0;

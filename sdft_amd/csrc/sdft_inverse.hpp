@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(InverseArgs<TD, FD> a)
       const FD e = all * ((FD)2.5e-16 * (FD)(a.nbins + kWave));
       const TD ylo = (TD)((sum - e) * a.sweight), yhi = (TD)((sum + e) * a.sweight);
       out = ylo;
-      if (!(ylo == yhi))                                   // wave-uniform (every lane holds the wave's sums)
+      if (!same_bits(ylo, yhi))                            // wave-uniform (every lane holds the wave's sums)
       {
         FD ordered = (FD)0;
         for (unsigned k0 = 0; k0 < a.nbins; k0 += kWave)
@@ -240,7 +240,7 @@ SDFT_D void inverse_rows_body(const InverseArgs<TD, FD>& a, unsigned chunk_len)
       const FD e = all * ((FD)2.5e-16 * (FD)(a.nbins + 2 * kWave));
       const TD ylo = (TD)((sum - e) * a.sweight), yhi = (TD)((sum + e) * a.sweight);
       TD out = ylo;
-      if (!(ylo == yhi))                                   // wave-uniform
+      if (!same_bits(ylo, yhi))                            // wave-uniform
       {
         const cx<FD>* row = row_of(rr);
         FD ordered = (FD)0;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
         const FD tree = wave_sum_f(part), all = wave_sum_f(mag);
         const FD e = all * ((FD)2.5e-16 * (FD)TB);
         const TD ylo = (TD)((tree - e) * a.sweight), yhi = (TD)((tree + e) * a.sweight);
-        if (ylo == yhi) { decided = true; decided_y = ylo; break; }
+        if (same_bits(ylo, yhi)) { decided = true; decided_y = ylo; break; }
       }
     }
     __builtin_amdgcn_wave_barrier();

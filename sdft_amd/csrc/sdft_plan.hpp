@@ -145,31 +145,32 @@ class Plan
   // Measured after a write (profiles/r04_synthesis_streaming_loads.txt): 706 MB f64f64 217 -> 176 us, f32f64 193 -> 153 us,
   // 2.1 GB 461 -> 392 us; a matrix that fits the cache (192 MB) 51 -> 58 us and 8-16 GB +5 %: hence the size window.
   long opt_inverse_nt = -1;
-  long opt_inverse_nt_skip_mb = -1;                         // -1: 1536 MB of matrices from 4 GiB on (logic::inverse_ordinary_rows); 0: none
+  long opt_inverse_nt_skip_mb = -1;                         // -1: 1536 MB of matrices from 6 GiB on (logic::inverse_ordinary_rows); 0: none
   // long synthesis calls: the fastest of the bit-identical streaming forms is found on the host's own calls (launch_inverse)
   long opt_inverse_tune = 1, last_inverse_tuned = 0;
   // (two tuners: a synthesis that follows an analysis call reads a matrix whose tail is still dirty in the Infinity Cache, one that
   // follows another synthesis does not -- which form and which kind of load is fastest differs between the two, and a host may do both)
-  logic::FormTuner inv_tunes[2];
+  logic::TunerTable inv_tunes[2];                           // (each a few shapes: a host that alternates call lengths keeps what it has decided)
   bool inv_after_write = false;                              // the synthesis call being launched directly follows an analysis call
-  hipEvent_t tune_evs[2][logic::FormTuner::kMax][2] = {};     // a pair of events per candidate form and tuner
+  hipEvent_t tune_evs[2][logic::TunerTable::kSlots][logic::FormTuner::kMax][2] = {};     // a pair of events per candidate form and tuner
   bool ensure_tune_events()
   {
-    if (tune_evs[0][0][0]) return true;
-    for (auto& tuner : tune_evs)
-      for (auto& pair : tuner)
-        for (hipEvent_t& e : pair)
-          if (hipEventCreate(&e) != hipSuccess)
-          {
-            (void)hipGetLastError(); e = nullptr;
-            destroy_tune_events();
-            return false;
-          }
+    if (tune_evs[0][0][0][0]) return true;
+    for (auto& kind : tune_evs)
+      for (auto& tuner : kind)
+        for (auto& pair : tuner)
+          for (hipEvent_t& e : pair)
+            if (hipEventCreate(&e) != hipSuccess)
+            {
+              (void)hipGetLastError(); e = nullptr;
+              destroy_tune_events();
+              return false;
+            }
     return true;
   }
   void destroy_tune_events()
   {
-    for (auto& tuner : tune_evs) for (auto& q : tuner) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
+    for (auto& kind : tune_evs) for (auto& tuner : kind) for (auto& q : tuner) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
   }
   long opt_inverse_rpi = 4;      // development: rows per load instruction of the streaming synthesis (4: 256-byte row segments, 2, 1: a KiB)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
@@ -1421,7 +1422,7 @@ class Plan
 
   // Synchronous calls do not sleep on the stream (a sleeping hipStreamSynchronize wakes up tens of microseconds late):
   // they poll -- the completion word where the call's last kernel sets one, the stream otherwise -- for a bounded
-  // wall-clock time (about twice what the call can take at HBM speed, at most 5 ms; 50 ms for the word) and only then
+  // wall-clock time (logic::sync_wait: min(20 ms, 200 us + 4 x what the call's bytes take at HBM speed); 50 ms for the word) and only then
   // block.  flag_fallbacks counts completion words that never became visible (get_option "flag_fallbacks").
   long flag_fallbacks = 0;
   static inline void cpu_relax()

@@ -365,6 +365,31 @@ struct FormTuner
   }
 };
 
+// A host may alternate between a few call lengths (hops of two sizes; staged host-pointer calls that end in a shorter tail segment): one tuner per
+// kind of call would start over at candidate 0 on every change of shape and never settle.  A small table of tuners keyed by the shape, least recently
+// used replaced: a shape that has decided stays decided while up to kSlots shapes interleave.
+struct TunerTable
+{
+  static constexpr int kSlots = 3;
+  FormTuner slot[kSlots];
+  unsigned long stamp[kSlots] = {};                        // 0: never used
+  unsigned long clock = 0;
+  int find(size_t key, int candidates)
+  {
+    const int count = candidates < 1 ? 1 : (candidates > FormTuner::kMax ? FormTuner::kMax : candidates);
+    int lru = 0;
+    for (int i = 0; i < kSlots; ++i)
+    {
+      if (stamp[i] && slot[i].key == key && slot[i].count == count) { stamp[i] = ++clock; return i; }
+      if (stamp[i] < stamp[lru]) lru = i;
+    }
+    slot[lru].reset(key, candidates);
+    stamp[lru] = ++clock;
+    return lru;
+  }
+  void reset_all() { for (int i = 0; i < kSlots; ++i) { slot[i].reset(0, 1); stamp[i] = 0; } clock = 0; }
+};
+
 // ---- synthesis: are the matrix' loads non-temporal? ------------------------------------------------------------------------------
 // Beyond 256 MiB (what fits the Infinity Cache reads faster through it).  Round 4 had stopped at 4 GiB, where non-temporal loads of a just-written
 // matrix were 5 % slower; round 5 found why -- a non-temporal load of a line that sits DIRTY in the cache is slow -- and reads the rows that may be

@@ -74,9 +74,13 @@ def min_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
-def run_census(local_seconds: float, local_frac: float, device=None) -> dict:
+def run_census(local_seconds: float, local_frac: float, device=None, placement_gbs: float = 0.0, placed: bool = True,
+               first_frac: float = 0.0) -> dict:
     """What a multi-GPU record needs to be checked without reading logs: how many ranks took part in the collectives
-    of which backend on how many distinct devices, and the spread of the per-rank step time and roofline fraction."""
+    of which backend on how many distinct devices, the spread of the per-rank step time and roofline fraction, and -- so
+    that a slow rank is explained by its memory, not guessed -- the spread of the store-only rate of the ranks' matrices
+    (placement_gbs: 0 on a rank that took its first allocation), how many ranks had their matrix placed by the library,
+    and the spread of the roofline fraction into the ranks' FIRST allocations."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -98,6 +102,11 @@ def run_census(local_seconds: float, local_frac: float, device=None) -> dict:
         "seconds_max": max_over_ranks(local_seconds, device),
         "roofline_frac_min": min_over_ranks(local_frac, device),
         "roofline_frac_max": max_over_ranks(local_frac, device),
+        "placement_gbs_min": min_over_ranks(placement_gbs, device),
+        "placement_gbs_max": max_over_ranks(placement_gbs, device),
+        "ranks_placed": int(round(sum_over_ranks(1.0 if placed else 0.0, device))),
+        "first_allocation_frac_min": min_over_ranks(first_frac, device),
+        "first_allocation_frac_max": max_over_ranks(first_frac, device),
     }
 
 

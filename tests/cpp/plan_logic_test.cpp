@@ -250,6 +250,25 @@ static void test_form_tuner()
   t.reset(3000, 2);
   CHECK(t.next(false, timed) == 0 && !timed, "no timing possible: the static form");
   t.launched(1); t.report(7, 1.0f); t.report(1, -1.0f); CHECK(t.samples[1] == 0 && !t.inflight[1], "a failed sample frees the form and counts nothing");
+  // a host that alternates between call lengths: each shape keeps its tuner (and what it decided); a fourth shape replaces the least recently used
+  {
+    TunerTable tab;
+    const int a = tab.find(1000, 3), b = tab.find(2000, 3);
+    CHECK(a != b && tab.slot[a].key == 1000 && tab.slot[b].key == 2000, "two shapes, two tuners");
+    for (int i = 0; i < 6; ++i) { FormTuner& q = tab.slot[tab.find(1000, 3)]; const int g = q.next(true, timed); q.launched(g); q.report(g, 1.0f + g); (void)tab.find(2000, 3); }
+    FormTuner& qa = tab.slot[tab.find(1000, 3)];
+    CHECK(qa.next(true, timed) == 0 && qa.chosen == 0 && !timed, "the interleaved shape did not make the first one start over");
+    CHECK(tab.slot[tab.find(2000, 3)].chosen < 0, "the second shape is still open");
+    const int c = tab.find(3000, 3);
+    CHECK(c != a && c != b, "a third shape takes the free slot");
+    (void)tab.find(1000, 3); (void)tab.find(3000, 3);
+    const int d = tab.find(4000, 2);
+    CHECK(d == b && tab.slot[d].key == 4000 && tab.slot[d].count == 2 && tab.slot[d].chosen < 0, "a fourth shape replaces the least recently used (2000)");
+    CHECK(tab.slot[tab.find(1000, 3)].chosen == 0, "... and the decided one is still there");
+    CHECK(tab.find(1000, 4) >= 0 && tab.slot[tab.find(1000, 4)].count == 4, "another candidate count is another tuner");
+    tab.reset_all();
+    CHECK(tab.slot[tab.find(1000, 3)].chosen < 0, "reset_all forgets");
+  }
   // the kind of load of the synthesis by the size of the matrix: the window of round 4, the very large matrices of round 5, the option
   const size_t MiB = (size_t)1 << 20, GiB = (size_t)1 << 30;
   CHECK(!inverse_streaming_loads(200 * MiB, -1) && inverse_streaming_loads(300 * MiB, -1) && inverse_streaming_loads(4 * GiB, -1), "the window");
