@@ -286,12 +286,12 @@ def cpu_hop_baseline(np, sine_sweep, combo, td, m=1000, hop=100, total=2000):
     return {"us_per_hop": round(best * 1e6, 1), "kind": plan.kind, "cores": 1, "sample": f"{total // hop} hops of {hop} samples, dftsize {m}, hann, {combo}"}
 
 
-def reference_bench_shape(torch, np, SDFT, device, with_cpu=True):
+def reference_bench_shape(torch, np, SDFT, device, with_cpu=True, placed=True):
     """/root/reference/cpp/examples/bench.cpp:15-48 (rust/examples/bench.rs): dftsize 1000, 44100 zero samples, TD = FD =
     double, Hann, 10 runs, microseconds per sdft / isdft call -- on device pointers, and the reference on one host core."""
     m, n, runs = 1000, 44100, 10
     x = torch.zeros(n, dtype=torch.float64, device="cuda")
-    d = torch.empty((n, m), dtype=torch.complex128, device="cuda")
+    d, rb_placement, rb_holder = place_matrix(torch, (n, m), torch.complex128, placed=placed)
     y = torch.empty(n, dtype=torch.float64, device="cuda")
     p = SDFT(m, "hann", 1.0, "f64f64", device=device)
     fw, iv = [], []
@@ -300,8 +300,13 @@ def reference_bench_shape(torch, np, SDFT, device, with_cpu=True):
         if r >= TUNER_CALLS:
             fw.append(t1 - t0); iv.append(t2 - t1)
     p.close()
+    del d
+    if rb_holder is not None:
+        rb_holder.free()
     res = {"shape": "dftsize 1000, 44100 samples of zeros, TD = FD = double, hann, 10 runs (cpp/examples/bench.cpp:15-48)",
-           "gpu_sdft_us": round(float(np.median(fw)) * 1e6, 1), "gpu_isdft_us": round(float(np.median(iv)) * 1e6, 1)}
+           "gpu_sdft_us": round(float(np.median(fw)) * 1e6, 1), "gpu_isdft_us": round(float(np.median(iv)) * 1e6, 1),
+           "matrix": "placed by sdft_hip_malloc_matrix_in_arena (%.0f GB/s store-only against %.0f at the allocation's start)" % (rb_placement.get("window_gbs", 0), rb_placement.get("start_gbs", 0))
+                     if rb_placement["placed"] else rb_placement["policy"]}
     if with_cpu:
         from oracle import oracle as O
         if not O.have_port("f64f64"):
@@ -337,7 +342,10 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         res["config2"] = {"skipped": f"needs {n * m * 8 / 1e9:.1f} GB of free HBM, {free / 1e9:.1f} GB free"}
     else:
         x = torch.from_numpy(sine_sweep(n, dtype=np.float32)).cuda()
-        d = torch.empty((n, m), dtype=torch.complex64, device="cuda")
+        d_first = torch.empty((n, m), dtype=torch.complex64, device="cuda")        # a plain allocation, timed beside the placed matrix
+        d, c2_placement, c2_holder = place_matrix(torch, (n, m), torch.complex64, placed=placement)
+        if not c2_placement["placed"]:
+            del d; d = d_first
         y = torch.empty(n, dtype=torch.float32, device="cuda")
         p = SDFT(m, window, 1.0, combo, device=device)
         # (the synthesis finds its form and its kind of load on the first calls of a shape -- up to six candidates, two timed calls each, one
@@ -348,6 +356,8 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
             p.isdft(d, y)
         fwd = timed(lambda: p.sdft(x, d), p.synchronize, 5)
         inv = timed(lambda: p.isdft(d, y), p.synchronize, 5)
+        p.sdft(x, d_first)
+        fwd_first = timed(lambda: p.sdft(x, d_first), p.synchronize, 5)
         p.set_option("async", 1)
         pair = timed(lambda: (p.sdft(x, d), p.isdft(d, y)), p.synchronize, 5)
         p.set_option("profile", 1)
@@ -359,6 +369,8 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         res["config2"] = {
             "workload": f"BASELINE configs[2]: round trip, n={n}, m={m}, {window}, TD float / FD float, latency 1 (exact carries: bit-identical to the reference)",
             "forward_ms_wall": round(fwd * 1e3, 4), "inverse_ms_wall": round(inv * 1e3, 4), "round_trip_ms_wall_async_pair": round(pair * 1e3, 4),
+            "forward_ms_wall_first_allocation": round(fwd_first * 1e3, 4), "forward_frac_of_peak_first_allocation": round(n * (m * 8 + 4) / fwd_first / 1e9 / HBM_PEAK_GBS, 4),
+            "buffer_placement": {k: c2_placement.get(k) for k in ("placed", "policy", "arena_bytes", "window_offset", "boundary_offset", "window_gbs", "start_gbs", "pair_probes", "window_probes", "probe_ms")},
             "forward_gbs": round(b / fwd / 1e9, 1), "forward_frac_of_peak": round(b / fwd / 1e9 / HBM_PEAK_GBS, 4),
             "inverse_gbs": round(b / inv / 1e9, 1), "inverse_frac_of_peak": round(b / inv / 1e9 / HBM_PEAK_GBS, 4),
             "round_trip_gbs": round(2 * b / pair / 1e9, 1), "round_trip_frac_of_peak": round(2 * b / pair / 1e9 / HBM_PEAK_GBS, 4),
@@ -368,7 +380,9 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
             "algorithmic_bytes_per_direction": b, "msamples_s_round_trip": round(n / pair / 1e6, 2),
             "note": "carry and forward stages overlap (the relay runs beside the forward launch): their kernel times do not add up to the wall time",
         }
-        p.close(); del x, d, y
+        p.close(); del x, d, d_first, y
+        if c2_holder is not None:
+            c2_holder.free()
         torch.cuda.empty_cache()
 
     # ---- configs[3] ----
@@ -915,7 +929,7 @@ def main():
         result["hop100_m1000"] = hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, local_rank)
         if not args.no_cpu_baseline:
             result["hop100_m1000"]["cpu_reference"] = cpu_hop_baseline(np, sine_sweep, combo, td)
-        result["reference_bench_shape"] = reference_bench_shape(torch, np, SDFT, local_rank, with_cpu=not args.no_cpu_baseline)
+        result["reference_bench_shape"] = reference_bench_shape(torch, np, SDFT, local_rank, with_cpu=not args.no_cpu_baseline, placed=not args.no_placement)
 
         # PCIe-inclusive host-pointer path (never `value`)
         npci = min(n, 65536)

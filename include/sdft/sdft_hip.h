@@ -161,20 +161,20 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
 double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t* samples, sdft_fdx_t* dfts, sdft_td_t* out) SDFT_HIP_SYMBOL(time_hops);
 
 /* ---- options -----------------------------------------------------------------------------------
-   Eleven options are for hosts; the defaults are the safe and (but for the host-memory choices, which only the host can make) the fast ones:
+   Twenty-two keys.  The first eleven are for hosts; the defaults are the safe and (but for the host-memory choices, which only the host can
+   make) the fast ones:
    "async"         0|1   see above
-   "pipeline"      1 (default) = asynchronous analysis calls on the plan's own stream overlap: the state after a call comes from a
-                       small kernel ahead of the call's rows, the rows of consecutive calls run on two internal streams; every
-                       other call of the plan and sdft_hip_synchronize wait for them.  Only calls whose matrix does not overlap
-                       the previous call's (a host that alternates between two matrices; calls into one matrix stay on one
-                       stream), from 6 Mi bins per call on, at any length (n = 1e6, m = 1024: 77 -> 80-82 % of the HBM peak).
-                       Asynchronous synthesis calls that come back to back take the two streams in turn as well (n = 48 000:
-                       67 -> 80 %); a synthesis never runs beside an analysis.  Either kind of call is pipelined only once two
-                       of them have come in a row (a host that alternates analysis and synthesis stays on one stream).  Off by itself on a caller's stream, once sdft_hip_get_stream has been called, and with
-                       profiling.  0 = one stream, 2 = the same with the row streams picked by priority at once (what the plan
-                       falls back to when no ordinary pair of streams runs concurrently).  get_option "last_pipelined",
-                       "pipelined_calls", "pipelined_inverse_calls", "pipelined_ordered",
-                       "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary streams, 2 = by priority, 0 = none found)
+   "pipeline"      asynchronous analysis calls on the plan's own stream into matrices that do not overlap (a host that alternates between two
+                       matrices) overlap: the state after a call comes from a small kernel ahead of the call's rows, the rows of consecutive
+                       calls run on two internal streams; every other call of the plan and sdft_hip_synchronize wait for them.
+                       1 (default) = calls of up to one round of the chip's workgroups, where the next call fills what a launch leaves idle
+                       (n = 48 000, m = 1024: 73.6 against 68.5 % of the HBM peak); calls of two rounds and more fill the chip by themselves and
+                       stay on one stream (n = 1e6 into two equally placed matrices: 84.5 % on one stream, 81.7 % pipelined).  2 = calls of any
+                       length, 0 = never.  Asynchronous synthesis calls that come back to back take the two streams in turn as well; a synthesis
+                       never runs beside an analysis; either kind only once two of them have come in a row.  Off by itself on a caller's stream,
+                       once sdft_hip_get_stream has been called, and with profiling.  get_option "last_pipelined", "pipelined_calls",
+                       "pipelined_inverse_calls", "pipelined_ordered", "pipeline_streams" (10 x kind + pairs tried; kind 1 = ordinary
+                       streams, 2 = by priority: what the plan falls back to when no ordinary pair runs concurrently, 0 = none found)
    "carry"         0 = chunk-parallel carries (FD double default; <= 1e-11 relative deviation from the
                        serial reference), 1 = exact serial carry pass (bit-identical; FD float always)
    "float_carry_parallel"  0 (default) | 1 = FD float plans take the chunk-parallel carries too: long calls run at
@@ -210,27 +210,17 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        late on one box and 45 us late on another); 0 = sleep on the stream, 2 = poll from the start
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
-   The others force a path the library otherwise chooses by itself -- they exist for the measurements under scripts/ and for the tests, which run
-   every path against the reference; no host needs them:
+   Eleven more pick a route the library otherwise picks by itself (a host that knows its shapes may, the tests do):
    "chunk"         samples per time chunk (0 = heuristic)
-   "segments"      time segments of the exact carry pass overlapped with the forward launches
-   "rows_kernel"   1 (default) = row-group forward kernel when the row fits, 0 = independent tiles
-   "row_slots_max" 1|2   bins-per-lane slots the row-group kernel may use
-   "fused"         1 (default) = FMA arithmetic in the chunk-parallel FD double path
-   "fft_carry"     1 (default) = chunk partial sums by FFT when 2*dftsize is a power of two
-   "interior"      bin-owning lanes per wave of the independent-tile kernel
-   "inverse_rows"  rows per wave of the exact inverse (0 = heuristic, 16, 32)
-   "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis)
-   "hop_parts"     0 (default) = a hop-sized call's samples are cut into up to 8 time parts, every (tile of bins, part) a
-                       workgroup on a CU of its own; a part's recurrence wave first runs the stream state through the samples
-                       before it with the reference's own operations, so every bit stays the reference's; 1 = never, n = n parts
-   "rows_split"    0 (default) | 1 = FD float rows of 2049 ... 4096 bins (a multiple of 256) as two one-slot workgroups per
-                       row, each computing the one bin pair it needs of the other half itself; same bits, measured 8-14 % slower
-   "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn,
-                       one dependent addition per step on the chain) while bins x channels leave SIMDs idle, 0 = always the
-                       serial pass, 2 = relay form whenever the geometry allows ("chain_block" 8|16|32|64|128 steps,
-                       "relay_waves" 1..8 waves per relay; "relay_flow" 1 (default) = one relay launch beside one forward
-                       launch whose workgroups wait for their chunk's carries)
+   "segments"      time segments of the exact carry pass overlapped with the forward launches (0 = heuristic)
+   "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn, one dependent addition
+                       per step on the chain; one relay launch beside one forward launch whose workgroups wait for their chunk's carries)
+                       while bins x channels leave SIMDs idle, 0 = always the serial pass, 2 = relay form whenever the geometry allows
+   "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
+                       launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
+                       0 = carries by a pre-pass (two more launches); calls of up to 2^19 samples per channel take it
+   "hop_kernel"    1 (default) = calls of one time chunk run one fused launch (differences + analysis; a hop's samples in up to 8 time
+                       parts, every (tile of bins, part) a workgroup: bit-identical), 0 = the general launches
    "fused_exact"   sdft_hip_process_n: 0 = folded form (window, operation and synthesis folded into per-bin
                        coefficients, sum over bins by a tree), 1 = bins summed in the reference's order by the
                        fastest route that gives those bits, 2 = in that order by the fused kernel,
@@ -238,43 +228,31 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        (float samples from double bins: the reference's bits are proven from the tree sum and a bound on
                        what any summation order can differ by; only samples whose bound straddles a rounding boundary of the
                        float are summed in order -- get_option "ordered_walks" counts them)
-   "fold"          1 (default) = the tree-sum flavour uses the folded form, 0 = the windowed rows in LDS
+   "inverse_rows"  rows per wave of the exact inverse (0 = heuristic and tuner; 4, 8, 16, 32)
+   "inverse_verify" 1 (default) = float samples from double bins by the tree sum with the rounding-interval proof (see "exact_inverse"), 0 = always
+                       the ordered sum
+   "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
+                       per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof, whole rows read in step -- on the
+                       host's own calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape
+                       (a few shapes are remembered: a host that alternates call lengths keeps what it has decided); 0 = the static choice.
+                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B, 4 8 rows,
+                       5 4 rows, 6 whole rows in step)
    "pointers"      0 (default) = every call asks the runtime what each pointer is (hipPointerGetAttributes: 0.06-0.16 us,
                        nothing is cached -- a buffer that was freed and whose address came back as the other kind of memory
                        is classified as what it is now), 1 = all device, 2 = all host (no query)
-   "self_carry"    1 (default) = chunk-parallel FD double calls with 2*dftsize <= 4096 a power of two or 2/3/5-smooth run as ONE
-                       launch: every workgroup derives its carry-in from the raw samples (fold + FFT in LDS);
-                       0 = carries by a pre-pass (two more launches); calls of up to 2^19 samples per channel take it
-   "rows_f32"      1 (default) = FD float rows of a multiple of 128 bins are analysed by the bin-pair kernel (a lane's two
-                       adjacent bins are the halves of every packed operand; same bits), 0 = the generic row-group kernel
-   "inverse_nt"    synthesis reads the matrix with streaming (non-temporal) loads: -1 (default) = matrices beyond 256 MiB (what fits the
-                       Infinity Cache reads faster through it); 0 / 1 = never / always.  The rows read FIRST -- the matrix' end, what an
-                       analysis wrote last and left dirty in that cache, where a non-temporal load is slow -- take ordinary loads all
-                       the same: "inverse_nt_skip_mb" -1 (default) = 1536 MB of matrices from 6 GiB on (between 2 and 16 GiB the form
-                       tuner tries every form with and without), 0 = none, S = the first S MB read.
-                       get_option "last_inverse_nt" / "last_inverse_skip" = what the last synthesis launch used (skip in rows)
-   "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
-                       per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof -- on the host's own
-                       calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape
-                       (which form wins differs from lease to lease by a few per cent either way); 0 = the static choice.
-                       get_option "last_inverse_tuned" = 10 x decided + form (0 tree sum, 1 32 rows, 2 16 rows, 3 16 rows x 512 B, 4 8 rows, 5 4 rows,
-                       6 whole rows in step)
-   "inverse_step"  0 (default) = float samples from double bins at latency 1: the form that reads whole rows of a chunk of the matrix in
-                       step (one workgroup per chunk, tree sums with the rounding-interval proof; 6.55-6.66 TB/s against 6.2 for the
-                       streaming forms on matrices of 8 GB and more) is the static choice from 6 GB on and a candidate of the tuner
-                       below; 1 = always where it applies, -1 = never.  Same bits either way.
-   "xcd_map"       1 (default) = every XCD takes a contiguous eighth of an analysis launch's (channel, chunk) workgroups, so that the
-                       workgroups that run at the same time are spread over the whole matrix (n = 1e6: 77.6 -> 83.9 % of the HBM peak)
-   "copy_streams"  2 (default) = the DMAs of such copies of 16 MiB and more alternate between the plan's stream and a second stream
-                       of the plan (every DMA costs ~15 us beside its bytes; two queues fill each other's gaps: 50 -> 54.5 GB/s);
-                       to what the caller queues before and after, the copy stays one operation of the plan's stream; 1 = one stream
-   "host_direct"   1 (default) = a host matrix of up to 4 MiB is written / read by the kernels in the pinned pieces themselves
-                       (over PCIe, no DMA launch: 197 against 224 us per hop), 0 = always DMA between staging matrix and pieces
    "stage_bytes"   segment size of the host-pointer staging path
+   A key the library does not know returns -1.
+   TEST HOOKS.  Every other fork of the host logic is decided by the library alone in libsdft_hip.so.  The same sources built with
+   -DSDFT_HIP_TEST_HOOKS (libsdft_hip_hooks.so, built beside the product by `python -m sdft_amd.build`; no host links it) accept the keys that force
+   those forks, so that the tests can run every route against the reference and the probes under scripts/ can measure them:
+   "rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves",
+   "relay_flow", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams" (sdft_capi.inc names what each selects);
+   get_option "test_hooks" = 1 in that build.
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",
    "last_chain", "last_fused_exact", "last_fused_fold", "last_process_path" (1 fused kernel, 2 hop pair, 3 two-pass),
-   "last_self", "cursor", "device", "ring_recoveries" (calls re-run with the serial carry pass after a poll loop of
+   "last_self", "last_inverse_nt" / "last_inverse_skip" (what the last synthesis launch used: non-temporal loads, rows read with ordinary loads),
+   "cursor", "device", "ring_recoveries" (calls re-run with the serial carry pass after a poll loop of
    the exact-carry kernels timed out: results stay valid, sdft_hip_last_warning() reports it), "flag_fallbacks". */
 int  sdft_hip_set_option(sdft_t* sdft, const char* key, long value) SDFT_HIP_SYMBOL(set_option);
 long sdft_hip_get_option(const sdft_t* sdft, const char* key) SDFT_HIP_SYMBOL(get_option);

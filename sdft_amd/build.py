@@ -1,4 +1,4 @@
-"""Builds libsdft_hip.so (the C-ABI + HIP kernels) in-tree with hipcc for gfx950.
+"""Builds libsdft_hip.so (the C-ABI + HIP kernels) and its test-hooks flavour libsdft_hip_hooks.so in-tree with hipcc for gfx950.
 
     python -m sdft_amd.build [--force] [--save-temps]
 
@@ -20,6 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libsdft_hip.so")
+# the same sources with -DSDFT_HIP_TEST_HOOKS: sdft_hip_set_option then also knows the keys that force every remaining fork of the host
+# logic (sdft_capi.inc) -- what the tests run against the reference route by route and the probes under scripts/ measure; no host links it
+LIB_HOOKS = os.path.join(OUT_DIR, "libsdft_hip_hooks.so")
 ARCH = "gfx950"
 COMBOS = ("f32f64", "f32f32", "f64f64", "f64f32")
 SOURCES = ["sdft_common.hip"] + [f"sdft_capi_{c}.hip" for c in COMBOS]
@@ -70,18 +73,19 @@ STAMP = os.path.join(OUT_DIR, "libsdft_hip.sources.sha256")
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_HOOKS) or not os.path.exists(STAMP):
         return True
     with open(STAMP) as fh:
         return fh.read().strip() != _source_hash()
 
 
 def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
-          extra_flags=tuple(os.environ.get("SDFT_HIP_EXTRA_FLAGS", "").split())) -> str:
-    """Compile (if stale) and return the path of libsdft_hip.so."""
+          extra_flags=tuple(os.environ.get("SDFT_HIP_EXTRA_FLAGS", "").split()), hooks: bool = False) -> str:
+    """Compile (if stale) both flavours and return the path of libsdft_hip.so (hooks: of libsdft_hip_hooks.so)."""
     force = force or bool(extra_flags)                    # development flags: never hand back a library built without them
+    want = LIB_HOOKS if hooks else LIB
     if not force and not _stale():
-        return LIB
+        return want
     os.makedirs(OUT_DIR, exist_ok=True)
     # one builder at a time (every rank of a torchrun job may arrive here at once): the others wait
     # on the lock and then find a fresh library; the link goes to a temporary name and is renamed
@@ -90,8 +94,9 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False,
     with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not _stale():
-            return LIB
-        return _build_locked(save_temps, verbose, extra_flags)
+            return want
+        _build_locked(save_temps, verbose, extra_flags)
+        return want
 
 
 def _build_locked(save_temps, verbose, extra_flags) -> str:
@@ -107,9 +112,10 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
     with open(os.path.join(obj_dir, "sdft_kernels_src.inc"), "w") as fh:
         fh.write("\n".join(f'R"SDFTSRC({piece})SDFTSRC"' for piece in pieces) + "\n")
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, *extra_flags, f"-I{obj_dir}", "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job) -> str:
+        src, hooks = job
+        obj = os.path.join(obj_dir, src.replace(".hip", ".hooks.o" if hooks else ".o"))
+        cmd = [cc, *FLAGS, *extra_flags, *(["-DSDFT_HIP_TEST_HOOKS"] if hooks else []), f"-I{obj_dir}", "-c", os.path.join(CSRC, src), "-o", obj]
         if save_temps:
             cmd.insert(1, "-save-temps=obj")
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=obj_dir)
@@ -119,18 +125,22 @@ def _build_locked(save_temps, verbose, extra_flags) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    # (sdft_common.hip holds nothing a hook changes: one object serves both libraries)
+    jobs = [(src, False) for src in SOURCES] + [(src, True) for src in SOURCES[1:]]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    plain, hooked = objs[:len(SOURCES)], [objs[0]] + objs[len(SOURCES):]
     # -no-hip-rt: no DT_NEEDED on a particular libamdhip64.  A process must hold exactly one HIP
     # runtime (two cannot both open the GPU); PyTorch wheels bundle their own under a different
     # soname than /opt/rocm's.  The host decides: a C program links -lamdhip64 itself
     # (INTEGRATION.md), capi.load() binds to the runtime already loaded in the interpreter.
-    tmp = LIB + f".tmp{os.getpid()}"
-    r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lm", "-ldl"],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    os.replace(tmp, LIB)
+    for lib, members in ((LIB, plain), (LIB_HOOKS, hooked)):
+        tmp = lib + f".tmp{os.getpid()}"
+        r = subprocess.run([cc, "-shared", "-fPIC", "-no-hip-rt", f"--offload-arch={ARCH}", *members, "-o", tmp, "-lm", "-ldl"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        os.replace(tmp, lib)
     if not extra_flags:                                   # (a development build is never mistaken for the product)
         with open(STAMP, "w") as fh:
             fh.write(_source_hash() + "\n")

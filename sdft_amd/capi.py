@@ -176,16 +176,22 @@ def _bind_hip_runtime() -> str:
 hip_runtime = None
 
 
-def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load libsdft_hip.so and declare every prototype; raises if it cannot be had."""
-    global _lib, hip_runtime
-    if _lib is not None:
+_lib_hooks = None
+
+
+def load(build_if_missing: bool = True, hooks: bool = False) -> C.CDLL:
+    """Load libsdft_hip.so (hooks: libsdft_hip_hooks.so, the same sources built with the path-forcing test options) and declare every
+    prototype; raises if it cannot be had.  Both may live in one process: each has its own plans, error channel and kernels."""
+    global _lib, _lib_hooks, hip_runtime
+    if hooks and _lib_hooks is not None:
+        return _lib_hooks
+    if not hooks and _lib is not None:
         return _lib
-    path = library_path()
+    path = (_build.LIB_HOOKS if "SDFT_HIP_LIBRARY" not in os.environ else os.environ.get("SDFT_HIP_HOOKS_LIBRARY", _build.LIB_HOOKS)) if hooks else library_path()
     if not os.path.exists(path):
         if not build_if_missing:
             raise SdftHipError(f"{path} not found; run `python -m sdft_amd.build`")
-        path = _build.build()
+        path = _build.build(hooks=hooks)
     hip_runtime = _bind_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in UNTYPED.items():
@@ -195,18 +201,22 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         for name, (res, args) in typed_signatures(combo).items():
             fn = getattr(lib, symbol(name, combo))
             fn.restype, fn.argtypes = res, args
-    _lib = lib
+    if hooks:
+        _lib_hooks = lib
+    else:
+        _lib = lib
     return lib
 
 
 class Api:
     """The typed entry points of one (td, fd) combination as attributes: ``api.sdft_n(...)``."""
 
-    def __init__(self, combo: str = "f32f64"):
+    def __init__(self, combo: str = "f32f64", hooks: bool = False):
         if combo not in COMBOS:
             raise ValueError(f"unknown type combination {combo!r}; expected one of {COMBOS}")
         self.combo = combo
-        self.lib = load()
+        self.hooks = hooks
+        self.lib = load(hooks=hooks)
         for name in typed_signatures(combo):
             setattr(self, name, getattr(self.lib, symbol(name, combo)))
 

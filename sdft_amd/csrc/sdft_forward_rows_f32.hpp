@@ -21,16 +21,6 @@
 // (re, re, im, im) quads in exactly that layout: the lane that owns an edge pair publishes it with ONE 16-byte write).
 // Same row-lockstep geometry, edge-slot protocol, flow-mode waits and chunk grid as forward_rows_kernel.
 // Rows of N = 128 * waves * S bins (N a multiple of 128: no mirror lanes inside a wave), dense 16-byte aligned output.
-//
-// SPLIT (round 5): rows beyond 2048 bins used to take two slots per lane -- 16 waves x 96-128 registers, ONE workgroup per CU,
-// 4 waves per SIMD, each a chain of dependent packed operations: 33 GB/s of rows per CU where the one-slot kernel with 8
-// waves per SIMD reaches 46.  Here such a row is the work of TWO one-slot workgroups (the lower and
-// the upper half of the bins, 64 registers: two workgroups to a CU, 8 waves per SIMD).  What a half needs of the other --
-// the window's two neighbour bins across the cut, ONE bin pair -- it computes itself: the recurrence of a bin depends on
-// nothing but its own carry-in (sdft.h:583-585), so one wave runs that pair through the chunk's samples before the time loop
-// (a hundred-odd samples, a few microseconds, all lanes the same arithmetic) and leaves the demodulated pairs in LDS, where
-// the wave at the cut reads them as its neighbouring wave's edge pair.  No exchange between workgroups, no flags, nothing
-// that depends on co-residency; the same operations on the same operands as the reference: bit-identical.
 
 #pragma once
 
@@ -92,14 +82,12 @@ template <int WIN> SDFT_D sdft_v4f32 window_quad(PairF c, PairF m2, PairF p2, fl
   return y;
 }
 
-// G: samples per lockstep group (one barrier each); SPLIT: the workgroup is one half of a row (see above; S == 1)
-template <int WIN, int S, int G, bool SPLIT = false>
+// G: samples per lockstep group (one barrier each)
+template <int WIN, int S, int G>
 __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(ForwardArgs<float> a)
 {
-  static_assert(!SPLIT || S == 1, "half rows are one-slot workgroups");
   constexpr int H = win_halo<WIN>::value;
   constexpr int VW = kRowWavesMax * S;                    // virtual waves
-  extern __shared__ sdft_v4f32 halo[];                    // SPLIT: the pair across the cut, one quad (re, re, im, im) per sample of the chunk
   // edge[side][buf][u][v] = (re(e0), re(e1), im(e0), im(e1)):
   //   side 0 (left):  e0 = first bin of virtual wave v - 2, e1 = first - 1     (what lane 0 receives as `below`)
   //   side 1 (right): e0 = last bin + 1, e1 = last + 2                          (what lane 63 receives as `above`)
@@ -110,10 +98,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
   const int nwaves = blockDim.x >> 6;
   const int nv = nwaves * S;
   unsigned chunk; size_t ch;
-  const unsigned half = SPLIT ? (blockIdx.x & 1u) : 0u;    // lower / upper half of the bins
-  flow_position(a, chunk, ch, SPLIT ? (blockIdx.x >> 1) : blockIdx.x);
+  flow_position(a, chunk, ch, blockIdx.x);
   if (!flow_wait(a, chunk, ch)) return;                    // flow mode: the chunk's carries (a time-out ends the workgroup)
-  const unsigned kbase = SPLIT ? half * (a.nbins / 2) : 0u;      // first bin of this workgroup
+  const unsigned kbase = 0u;                               // first bin of this workgroup
 
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
   const size_t t0 = chunk ? (size_t)chunk * a.chunk_len - a.chunk_shift : 0;
@@ -179,36 +166,6 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
     return X;
   };
 
-  // SPLIT: the pair across the cut -- bins (N/2, N/2 + 1) for the lower half, (N/2 - 2, N/2 - 1) for the upper -- run through
-  // the chunk's samples by the wave at the cut, every lane the same arithmetic; the demodulated pairs wait in LDS for phase B
-  // (the loop's first barrier orders these writes before the first read)
-  const int cut_wave = half ? 0 : nwaves - 1;
-  if constexpr (SPLIT && H >= 1)
-  {
-    if (wave == cut_wave)
-    {
-      PairF ha, hf, ht;
-      load_pair(half ? kbase - 2u : kbase + a.nbins / 2, ha, hf, ht);
-      unsigned hc = c;
-      for (size_t tt = t0; tt < t1; tt += 8)
-      {
-        float dd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dd[u] = d[tt + u];           // (past the call's end: the workspace has slack)
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tt + u < t1)
-          {
-            const bool wrap = (hc == maxc);
-            const PairF X = step(ha, hf, ht, dd[u], wrap);
-            hc = wrap ? 0 : hc + 1;
-            sdft_v4f32 quad; quad.x = X.re.x; quad.y = X.re.y; quad.z = X.im.x; quad.w = X.im.y;
-            if (lane == 0) halo[tt - t0 + u] = quad;
-          }
-      }
-    }
-  }
-
   // edge slots: lane 63 owns the next virtual wave's left edge pair, lane 0 the previous one's right edge pair (one 16-byte
   // write of the lane's own pair); at the two ends of the spectrum the conjugate mirror images (sdft.h:589-595):
   // X[-1] = conj X[1], X[-2] = conj X[2] come from lane 0's b1 and lane 1's b0 of virtual wave 0; X[N] = conj X[N-2],
@@ -230,11 +187,10 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
       if (lane == 0 && v > 0) quad_dst[q] = &edge[1][0][0][v - 1];
       float* el = reinterpret_cast<float*>(&edge[0][0][0][0]);
       float* er = reinterpret_cast<float*>(&edge[1][0][0][nv - 1]);
-      const bool low_end = !SPLIT || half == 0, high_end = !SPLIT || half == 1;             // (a half row has one end of the spectrum)
-      if (low_end && v == 0 && lane == 0) { mir_dst[q] = el + 1; mir_hi[q] = true; }                  // X[-1] = conj X[1]
-      if (low_end && v == 0 && lane == 1) { mir_dst[q] = el + 0; mir_hi[q] = false; }                 // X[-2] = conj X[2]
-      if (high_end && v == nv - 1 && lane == kWave - 1) { mir_dst[q] = er + 0; mir_hi[q] = false; }    // X[N]   = conj X[N-2]
-      if (high_end && v == nv - 1 && lane == kWave - 2) { mir_dst[q] = er + 1; mir_hi[q] = true; }     // X[N+1] = conj X[N-3]
+      if (v == 0 && lane == 0) { mir_dst[q] = el + 1; mir_hi[q] = true; }                  // X[-1] = conj X[1]
+      if (v == 0 && lane == 1) { mir_dst[q] = el + 0; mir_hi[q] = false; }                 // X[-2] = conj X[2]
+      if (v == nv - 1 && lane == kWave - 1) { mir_dst[q] = er + 0; mir_hi[q] = false; }    // X[N]   = conj X[N-2]
+      if (v == nv - 1 && lane == kWave - 2) { mir_dst[q] = er + 1; mir_hi[q] = true; }     // X[N+1] = conj X[N-3]
     }
   }
   auto publish = [&](const PairF (&x)[S], int buf, int u)
@@ -262,10 +218,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_f32_kernel(
 
   // phase B of one group: window and store, pair by pair; the edge quads of the NEXT pair are requested before the current
   // one is worked on (after the barrier every wave of the SIMD would otherwise sit through the same LDS latency together)
-  // (SPLIT: the wave at the cut takes its outer neighbour from the halo image -- a wave-uniform choice of the address)
-  const bool halo_left = SPLIT && half == 1 && wave == 0, halo_right = SPLIT && half == 0 && wave == nwaves - 1;
-  auto left_quad = [&](int buf, int u, int v, size_t tl) -> sdft_v4f32 { return *(halo_left ? &halo[tl + u] : &edge[0][buf][u][v]); };
-  auto right_quad = [&](int buf, int u, int v, size_t tl) -> sdft_v4f32 { return *(halo_right ? &halo[tl + u] : &edge[1][buf][u][v]); };
+  auto left_quad = [&](int buf, int u, int v, size_t) -> sdft_v4f32 { return edge[0][buf][u][v]; };
+  auto right_quad = [&](int buf, int u, int v, size_t) -> sdft_v4f32 { return edge[1][buf][u][v]; };
   auto finish_group = [&](const PairF (&x)[G][S], int buf, int m, size_t tl)
   {
     sdft_v4f32 l = {}, r = {};

@@ -115,7 +115,7 @@ class Plan
 
   // options
   int carry_mode = sizeof(FD) == 8 ? CARRY_FAST : CARRY_EXACT;
-  long opt_flag_max = (long)1 << 24;                       // bin-samples up to which a row-group analysis call signals its own completion
+  static constexpr size_t kFlagMax = (size_t)1 << 24;       // bin-samples up to which a row-group analysis call signals its own completion
 #ifdef SDFT_SELF_STAMPS
   long opt_self_stamps = 0;                                // development builds: device address of 8 stamp words
 #endif
@@ -172,7 +172,6 @@ class Plan
   {
     for (auto& kind : tune_evs) for (auto& tuner : kind) for (auto& q : tuner) for (hipEvent_t& f : q) if (f) { (void)hipEventDestroy(f); f = nullptr; }
   }
-  long opt_inverse_rpi = 4;      // development: rows per load instruction of the streaming synthesis (4: 256-byte row segments, 2, 1: a KiB)
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
@@ -219,7 +218,6 @@ class Plan
   bool fid_canonical = true;
   long opt_chain = 1;            // 0 = always the serial pass (carry_exact_kernel), 1 = heuristic, 2 = chain form whenever possible
   long opt_chain_L = 0, opt_chain_debug = 0;
-  long opt_hop_pipe = 1;         // calls of one time chunk, small launches: two waves per tile (forward_hop2_kernel)
   long last_hop_pipe = 0;
   long opt_hop_parts = 0, last_hop_parts = 1;   // ... in time parts (0 = by the launch's size, 1 = never, n = that many)
   long opt_fold = 1;             // fused call, tree-sum flavour: window, operation and synthesis folded into per-bin coefficients
@@ -397,12 +395,16 @@ class Plan
   bool rows_kernel_ok(bool row_pointers) const { return logic::rows_kernel_ok(nbins, sizeof(fdx), row_pointers, opt_rows_kernel != 0, opt_row_slots_max); }
   long row_slots() const { return logic::row_slots(nbins, sizeof(fdx)); }       // slots per lane (1 or 2) ...
   long row_waves() const { return logic::row_waves(nbins, sizeof(fdx)); }       // ... and physical waves of the row group
-  void choose_chunks(size_t n, long& chunks, long& len, bool rows_kernel = false) const
+  logic::ChunkQuery chunk_query(size_t n, bool rows_kernel) const
   {
     logic::ChunkQuery q;
     q.n = n; q.channels = channels; q.nbins = nbins; q.rows_kernel = rows_kernel; q.exact = carry_mode == CARRY_EXACT; q.pipelined = pipe_this;
     q.forced_chunk = opt_chunk; q.row_waves = row_waves(); q.tiles = tiles(); q.compute_units = compute_units;
-    const logic::Chunking c = logic::choose_chunks(q);
+    return q;
+  }
+  void choose_chunks(size_t n, long& chunks, long& len, bool rows_kernel = false) const
+  {
+    const logic::Chunking c = logic::choose_chunks(chunk_query(n, rows_kernel));
     chunks = c.chunks; len = c.len;
   }
 
@@ -563,7 +565,7 @@ class Plan
       // (calls of a few thousand rows gain a microsecond from it and cost the host seven runtime calls instead of one,
       // 19 against 3 us: n = 4096, m = 1024: 25.6 against 26.4 us per call; from n = 8192 on 30.4 against 32.9)
       pipe_this = calls.analysis_batch && pipe_wanted(nullptr) && self_eligible(n, false, true) && n < ((size_t)1 << 31) && channels * n * nb >= ((size_t)6 << 20) &&
-                  !logic::overlap(out_lo, out_hi, prev_out);
+                  !logic::overlap(out_lo, out_hi, prev_out) && logic::pipeline_pays(chunk_query(n, true), opt_pipeline);
     }
     bool self_form = self_eligible(n, fuse != nullptr, pipe_this) && (fuse ? folded_fuse : use_rows);
     if (self_form && fuse)
@@ -826,7 +828,7 @@ class Plan
     // short synchronous calls: the row-group kernels report their own completion (a word in pinned host memory
     // reaches the host before the stream does).  Worth it while the kernel has little to write back: n = 4096,
     // N = 1024: 49.7 -> 46.7 us per sdft_sdft_n, 40.4 -> 35.8 us per fused call; nothing at n = 48000.
-    if ((use_rows || fuse) && segments == 1 && channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)opt_flag_max))
+    if ((use_rows || fuse) && segments == 1 && channels * n * nb <= (fuse ? (size_t)1 << 26 : kFlagMax))
       fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
     last_segments = segments;
     for (long sg = 0; sg < segments; ++sg)
@@ -955,7 +957,7 @@ class Plan
       bool found = false;
       int lo = 0, hi = 0;                                     // (numerically: greatest = lowest priority)
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-      for (int attempt = (opt_pipeline == 2 ? 3 : 0); attempt < 4 && !found; ++attempt)      // (option pipeline = 2: the pair by priority at once)
+      for (int attempt = 0; attempt < 4 && !found; ++attempt)
       {
         hipStream_t cand[2] = {nullptr, nullptr};
         const bool by_priority = attempt == 3;
@@ -1075,7 +1077,7 @@ class Plan
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
     if (!grid_fits(channels * (size_t)chunks)) return false;
-    if (channels * n * nb <= (fuse ? (size_t)1 << 26 : (size_t)opt_flag_max)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
+    if (channels * n * nb <= (fuse ? (size_t)1 << 26 : kFlagMax)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
     const unsigned blocks = (unsigned)(channels * (size_t)chunks);
     const bool fused = opt_fused != 0;
     last_fused = fused; last_segments = 1; last_chain = 0;
@@ -1172,7 +1174,7 @@ class Plan
     const unsigned long long blocks = wide ? (ha.total_waves + 3) / 4 : ha.total_waves;
     if (!grid_fits(blocks)) return false;
     // small launches of hop-sized calls: two waves per tile (recurrence | window + stores)
-    const bool pipe = !wide && opt_hop_pipe && n <= (size_t)kHopMax;
+    const bool pipe = !wide && n <= (size_t)kHopMax;       // small launches: two waves per tile (forward_hop2_kernel)
     last_hop_pipe = pipe;
     // ... and the call's samples in time parts, every (tile, part) a workgroup on a CU of its own (forward_hop2_kernel): as many
     // parts as leave every workgroup a CU, at most 8, at least 12 samples each (the recurrence wave of a part runs the state

@@ -390,6 +390,21 @@ struct TunerTable
   void reset_all() { for (int i = 0; i < kSlots; ++i) { slot[i].reset(0, 1); stamp[i] = 0; } clock = 0; }
 };
 
+// ---- pipelined analyses: where they pay ------------------------------------------------------------------------------------------
+// The next call's workgroups fill what a launch leaves idle -- the launch gap, the prologue of the self-carried chunks, the ragged end: that pays for calls
+// of up to ONE round of the chip (n = 48 000 into two matrices in turn: 73.6 against 68.5 % of the HBM peak on one stream).  A call of two rounds or more
+// fills the chip by itself and its own cut (two rounds of shorter chunks) beats the pipelined one: n = 1e6 into two equally placed matrices 84.5 % on one
+// stream against 81.7 % pipelined (bench.py two_matrices_in_turn, round 6; round 5 had compared unequally placed matrices).
+// option: 0 never, 1 (default) calls of up to one round, 2 calls of any length.
+inline bool pipeline_pays(ChunkQuery q, long option)
+{
+  if (option <= 0) return false;
+  if (option >= 2) return true;
+  q.pipelined = false;
+  const Chunking c = choose_chunks(q);
+  return c.chunks * (long)std::max<size_t>(q.channels, 1) <= (long)q.compute_units;
+}
+
 // ---- synthesis: are the matrix' loads non-temporal? ------------------------------------------------------------------------------
 // Beyond 256 MiB (what fits the Infinity Cache reads faster through it).  Round 4 had stopped at 4 GiB, where non-temporal loads of a just-written
 // matrix were 5 % slower; round 5 found why -- a non-temporal load of a line that sits DIRTY in the cache is slow -- and reads the rows that may be

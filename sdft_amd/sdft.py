@@ -39,8 +39,12 @@ class SDFT:
     """
 
     def __init__(self, dftsize: int, window="hann", latency: float = 1.0, combo: str = "f32f64",
-                 channels: int = 1, device=None):
-        self.api = Api(combo)
+                 channels: int = 1, device=None, hooks: bool = False):
+        # hooks: the plan lives in libsdft_hip_hooks.so (the same sources built with -DSDFT_HIP_TEST_HOOKS), whose set_option also knows
+        # the keys that force every remaining fork of the host logic -- for the tests and the probes; see set_option below
+        self.api = Api(combo, hooks=hooks)
+        self._options = []                                   # (key, value) set so far, and the caller's stream: replayed when the plan moves
+        self._stream = None
         self.combo = combo
         self.td = _NP_REAL[combo[:3]]
         self.fd = _NP_REAL[combo[3:]]
@@ -87,8 +91,32 @@ class SDFT:
 
     # ---- options ------------------------------------------------------------------------
     def set_option(self, key: str, value: int):
-        if self.api.set_option(self._p, key.encode(), int(value)) != 0:
-            raise SdftHipError(f"unknown option {key!r}")
+        """sdft_hip_set_option.  A key the product library does not know may be a test hook (include/sdft/sdft_hip.h lists them): the plan
+        then moves to libsdft_hip_hooks.so -- a new plan with the same parameters on the same device, the options set so far replayed
+        and the stream state copied over (sdft_hip_get_state / set_state) -- so that the tests can force a route on any plan they make; a key
+        neither build knows raises."""
+        if self.api.set_option(self._p, key.encode(), int(value)) == 0:
+            self._options.append((key, int(value)))
+            return
+        if not self.api.hooks:
+            other = Api(self.combo, hooks=True)
+            if self.device >= 0:
+                other.lib.sdft_hip_set_device(self.device)
+            q = other.alloc_batch(self.dftsize, self.window, self.latency, self.channels)
+            if q and other.set_option(q, key.encode(), int(value)) == 0:
+                for k, v in self._options:
+                    other.set_option(q, k.encode(), v)
+                acc, fid, hist, cursor = self.state()            # (synchronises; the plan may have been called already)
+                self.api.free(self._p)
+                self.api, self._p = other, q
+                self.set_state(acc, fid, hist, cursor)
+                if self._stream is not None:
+                    self.set_stream(self._stream)
+                self._options.append((key, int(value)))
+                return
+            if q:
+                other.free(q)
+        raise SdftHipError(f"unknown option {key!r}")
 
     def get_option(self, key: str) -> int:
         return int(self.api.get_option(self._p, key.encode()))
@@ -97,6 +125,7 @@ class SDFT:
         """Launch on a caller-owned HIP stream (e.g. ``torch.cuda.Stream().cuda_stream``)."""
         if self.api.set_stream(self._p, C.c_void_p(stream_handle)) != 0:
             self.api.check()
+        self._stream = stream_handle
 
     def synchronize(self):
         if self.api.synchronize(self._p) != 0:

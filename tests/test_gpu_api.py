@@ -2,6 +2,7 @@
 corner-case arguments.  Everything goes through libsdft_hip.so on a real GPU."""
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -243,19 +244,15 @@ def test_hop_kernel_matches_reference_and_legacy_single_chunk_path(combo, window
         ch = 2
         xb = np.stack([noise(total, seed=11 + c, dtype=td) for c in range(ch)])
         refs = [O.best(m, window, 0.5, combo) for _ in range(ch)]
-        with make(m, window, 0.5, combo, ch, chunk=1 << 30) as p, make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_kernel=0) as q, \
-                make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_pipe=0) as r:
+        with make(m, window, 0.5, combo, ch, chunk=1 << 30) as p, make(m, window, 0.5, combo, ch, chunk=1 << 30, hop_kernel=0) as q:
             i = 0
             for h in hops:
                 seg = np.ascontiguousarray(xb[:, i:i + h])
                 got = p.sdft(seg)
                 old = q.sdft(seg)
                 assert p.get_option("last_kernel") == 3 and q.get_option("last_kernel") != 3
-                # hop-sized calls: two waves per tile (recurrence | window + stores); the one-wave form must agree
+                # hop-sized calls: two waves per tile (recurrence | window + stores); longer ones the one-wave form
                 assert p.get_option("last_hop_pipe") == (1 if h <= 512 else 0)
-                one_wave = r.sdft(seg)
-                assert r.get_option("last_kernel") == 3 and r.get_option("last_hop_pipe") == 0
-                assert np.array_equal(got, one_wave), (combo, window, m, h)
                 for c in range(ch):
                     want = refs[c].sdft(seg[c])
                     assert np.array_equal(got[c], want), (combo, window, m, h, c)
@@ -772,18 +769,25 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         assert p.get_option("pipelined_calls") == 2
         assert np.array_equal(host, got[1][0][2])
         p.synchronize()
-    # the row streams picked by priority (the fallback when no ordinary pair runs concurrently): same results
-    with SDFT(m, "hann", 1.0, "f32f64") as p:
-        p.set_option("async", 1)
-        p.set_option("pipeline", 2)
-        xd = [torch.from_numpy(x).cuda() for x in xs]
-        outs = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(calls)]
-        for i in range(calls):
-            p.sdft(xd[i], outs[i])
-        p.synchronize()
-        assert p.get_option("pipelined_calls") == calls - 1 and p.get_option("pipeline_streams") // 10 == 2
-        for o, b in zip(outs, got[1][0]):
-            assert np.array_equal(o.cpu().numpy(), b)
+    # calls of two rounds of the chip and more fill it by themselves: by default (1) they stay on one stream (round 6: n = 1e6 into two equally
+    # placed matrices 84.5 % of the HBM peak against 81.7 % pipelined), on request (2) calls of any length are pipelined; same results
+    ml, nl = 256, 120000
+    xl3 = [noise(nl, seed=90 + i) for i in range(3)]
+    long_res = {}
+    for pipe in (1, 2):
+        with SDFT(ml, "hann", 1.0, "f32f64") as p:
+            p.set_option("async", 1)
+            p.set_option("pipeline", pipe)
+            xd = [torch.from_numpy(x).cuda() for x in xl3]
+            outs = [torch.empty((nl, ml), dtype=torch.complex128, device="cuda") for _ in range(3)]
+            for i in range(3):
+                p.sdft(xd[i], outs[i])
+            p.synchronize()
+            assert p.get_option("last_chunks") > 256 or pipe == 2
+            assert p.get_option("pipelined_calls") == (2 if pipe == 2 else 0), (pipe, p.get_option("last_chunks"))
+            long_res[pipe] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(long_res[1], long_res[2]):
+        assert rel(a, b) <= 1e-12
     # a batched plan (one state workgroup per channel), a size that is not a power of two (the mixed-radix fold)
     for mm, ch in ((512, 3), (500, 2)):
         xb = [noise(ch * 9000, seed=80 + i).reshape(ch, 9000) for i in range(4)]
@@ -985,6 +989,51 @@ def test_matrix_as_the_best_window_of_one_allocation():
     lib.sdft_hip_clear_error()
     small = lib.sdft_hip_malloc_matrix_in_arena(4096, 8192, None)      # small matrices: no probe, the start of the allocation
     assert small and lib.sdft_hip_free_matrix(C.c_void_p(small)) == 0
+
+
+def test_product_library_knows_22_options_and_the_hooks_library_the_rest():
+    """Round 6: libsdft_hip.so accepts the twenty-two documented keys; the keys that force the remaining forks of the host logic exist only
+    in libsdft_hip_hooks.so (the same sources built with -DSDFT_HIP_TEST_HOOKS).  The Python mirror moves a plan there when a test asks for
+    such a key -- options replayed, stream state copied -- so the route tests keep working on any plan."""
+    import torch
+    from sdft_amd import capi
+    from sdft_amd.sdft import SDFT
+    product = ("async", "pipeline", "carry", "float_carry_parallel", "exact_inverse", "host_copy", "host_register", "copy_threads", "pinned_io", "spin",
+               "profile", "chunk", "segments", "chain", "self_carry", "hop_kernel", "fused_exact", "inverse_rows", "inverse_verify", "inverse_tune",
+               "pointers", "stage_bytes")
+    hooks = ("rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves",
+             "relay_flow", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams")
+    gone = ("rows_split", "inverse_rpi", "hop_pipe", "flag_max", "no_such_option")
+    assert len(product) == 22
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdft", "sdft_hip.h")).read()
+    for k in product + hooks:
+        assert '"%s"' % k in header, k
+    for hk, api in ((False, capi.Api("f32f64")), (True, capi.Api("f32f64", hooks=True))):
+        q = api.alloc_batch(64, 1, 1.0, 1)
+        assert q and api.get_option(q, b"test_hooks") == (1 if hk else 0)
+        for k in product:
+            cur = api.get_option(q, k.encode()) if k not in ("stage_bytes", "profile") else 0
+            assert api.set_option(q, k.encode(), max(cur, 0)) == 0, (hk, k)
+        for k in hooks:
+            assert api.set_option(q, k.encode(), 1) == (0 if hk else -1), (hk, k)
+        for k in gone:
+            assert api.set_option(q, k.encode(), 1) == -1, (hk, k)
+        api.free(q)
+    # a plan that has already run moves with its state
+    m = 64
+    x = noise(900, seed=5)
+    ref = O.best(m, "hann", 1.0, "f32f64")
+    with SDFT(m, "hann", 1.0, "f32f64") as p:
+        p.set_option("chunk", 128)
+        assert rel(p.sdft(x[:500]), ref.sdft(x[:500])) <= 1e-11
+        assert not p.api.hooks
+        p.set_option("rows_kernel", 0)                        # a hook: the plan moves
+        assert p.api.hooks and p.get_option("test_hooks") == 1 and p.get_option("chunk") == 128 and p.get_option("rows_kernel") == 0
+        got = p.sdft(x[500:])
+        assert p.get_option("last_kernel") == 1                # the independent-tile kernel, as forced
+        assert rel(got, ref.sdft(x[500:])) <= 1e-11
+        with pytest.raises(Exception):
+            p.set_option("no_such_option", 1)
 
 
 def test_driver_entry_point_smoke():

@@ -90,15 +90,22 @@ def test_single_rank_bench_line_contract():
     assert cfg["single_sample"]["sdft_us_per_call_device_row"] > 0 and cfg["single_sample"]["cpu_sdft_us_per_sample"] > 0
     assert res["roofline"]["traffic"] is None or "replayed" in res["roofline"]["traffic_source"]
     assert res["ranks"] is None                                                    # the census belongs to N > 1 lines
-    # round 5: the output matrix is the best of a few allocations by a store-only probe, untimed, and the line says so
+    # round 6: the output matrix comes from the library's own placement call inside matrix + 64 GiB, untimed, and the line says how it was
+    # found; the same K steps into the process' first allocation ride beside the headline
     bp = res["buffer_placement"]
-    assert "untimed" in bp["policy"] and 1 <= len(bp["probed_store_only_gbs"]) <= 64 and bp["probed_store_only_gbs"][bp["chosen"]] == max(bp["probed_store_only_gbs"])
-    # the headline workload as asynchronous calls into two matrices in turn (pipelined calls), and the north star's shape likewise
+    assert "untimed" in bp["policy"] and "sdft_hip_malloc_matrix_in_arena" in bp["policy"] and bp["placed"] is True, bp
+    assert bp["arena_bytes"] <= bp["matrix_bytes"] + (64 << 30) and bp["window_offset"] + bp["matrix_bytes"] <= bp["arena_bytes"], bp
+    assert bp["window_probes"] <= 9 and bp["pair_probes"] <= 16 and bp["window_gbs"] >= bp["start_gbs"] > 0, bp
+    fa = res["first_allocation"]
+    assert fa["value"] > 0 and 0 < fa["frac"] < 1 and fa["ms_per_step"] > 0 and "FIRST allocation" in fa["is"], fa
+    # the headline workload as asynchronous calls into two matrices in turn, pipelined against one stream on equally placed matrices
     two = res["two_matrices_in_turn"]
-    assert "error" in two or (two["pipelined_calls"] >= 10 and 0 < two["frac_of_peak_wall"] < 1 and
-                              two["pipelined_synthesis_calls"] >= 10 and 0 < two["synthesis_frac_of_peak_wall"] < 1), two
-    ns = res["north_star_n48000"]["async_two_buffers"]
-    assert ns["pipelined_calls"] >= 50 and ns["row_streams"] in ("ordinary", "by priority"), ns
+    assert "error" in two or (two["pipelined"]["pipelined_calls"] >= 10 and two["one_stream"]["pipelined_calls"] == 0 and
+                              0 < two["pipelined"]["frac_of_peak_wall"] < 1 and 0 < two["one_stream"]["frac_of_peak_wall"] < 1 and
+                              0 < two["library_default"]["frac_of_peak_wall"] < 1 and 0 < two["synthesis_frac_of_peak_wall"] < 1), two
+    ns = res["north_star_n48000"]
+    assert ns["async_two_buffers_pipelined"]["pipelined_calls"] >= 50 and ns["async_two_buffers_pipelined"]["row_streams"] in ("ordinary", "by priority"), ns
+    assert 0 < ns["sync"]["frac_of_peak_wall"] < 1 and 0 < ns["sync_first_allocation"]["frac_of_peak_wall"] < 1 and ns["buffer_placement"]["first"]["placed"] is True, ns
 
 
 def test_eight_rank_bench_plumbing():
@@ -113,6 +120,14 @@ def test_eight_rank_bench_plumbing():
     assert abs(res["value"] - 16 * 4096 / (res["ms_per_step"] * 1e-3) / 1e6) <= 0.02 * res["value"]
     assert "configs[4]" in res["config"]["workload"] and "2/GPU" in res["config"]["workload"]
     assert res["ranks"]["ranks_in_collectives"] == 8 and res["ranks"]["world_size"] == 8
+    # round 6: a rank whose arena (matrix + 64 GiB) does not fit -- eight ranks on one GPU here, a GPU somebody else is using on a real node --
+    # takes its first allocation and the census says how many did, with the spread of the ranks' store-only rates and first-allocation fractions
+    rk = res["ranks"]
+    assert 0 <= rk["ranks_with_a_placed_matrix"] <= 8
+    assert rk["placement_gbs_min_over_ranks"] <= rk["placement_gbs_max_over_ranks"]
+    assert (rk["placement_gbs_min_over_ranks"] == 0) == (rk["ranks_with_a_placed_matrix"] < 8), rk
+    assert 0 < rk["first_allocation_frac_min_over_ranks"] <= rk["first_allocation_frac_max_over_ranks"] < 1, rk
+    assert res["first_allocation"]["value"] > 0 and res["buffer_placement"]["placed"] in (True, False)
 
 
 def _hip_rank(rank, world, port, q):

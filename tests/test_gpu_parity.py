@@ -352,11 +352,6 @@ def test_inverse_is_bit_identical(combo, latency):
             for rows in (4, 8, 16) + ((32,) if combo[3:] == "f64" else ()):
                 p.set_option("inverse_rows", rows)
                 assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want), (combo, latency, m, n, rows)
-            # (round 5: row segments of 512 bytes and of a KiB per load instruction)
-            for rows, rpi in ((16, 2), (16, 1)) + (((32, 2),) if combo[3:] == "f64" else ()):
-                p.set_option("inverse_rows", rows); p.set_option("inverse_rpi", rpi)
-                assert np.array_equal(p.isdft(torch.from_numpy(d).cuda()).cpu().numpy(), want), (combo, latency, m, n, rows, rpi)
-            p.set_option("inverse_rpi", 4)
             p.set_option("inverse_rows", 0)
             p.set_option("exact_inverse", 0)                       # wave-parallel sum: inside the bar, not identical
             assert rel_err(p.isdft(d), want) <= TOL[combo[3:]]
@@ -697,44 +692,6 @@ def test_bin_pair_kernel_is_the_generic_kernel_bit_for_bit(combo, m, window):
     x = xb[0, :min(5 * m + 3000, xb.shape[1])]
     with make(m, window, 1.0, combo, float_carry_parallel=1) as p, make(m, window, 1.0, combo, float_carry_parallel=1, rows_f32=0) as q:
         assert np.array_equal(p.sdft(x), q.sdft(x)) and p.get_option("last_rows_f32") == 1 and p.get_option("last_chain") == 0
-
-
-@pytest.mark.parametrize("combo,m,window", [("f32f32", 4096, "blackman"), ("f32f32", 4096, "hann"), ("f32f32", 2304, "hamming"), ("f64f32", 2560, "blackman"),
-                                            ("f32f32", 3840, "boxcar"), ("f32f32", 3072, "hann")])
-def test_half_row_workgroups_are_the_two_slot_kernel_bit_for_bit(combo, m, window):
-    """Round 5: FD float rows of 2049 ... 4096 bins (a multiple of 256) as the work of TWO one-slot workgroups per row, each
-    computing the one bin pair it needs of the other half itself (forward_rows_f32_kernel<..., SPLIT>, option rows_split = 1;
-    measured 8-14 % slower than the two-slot kernel, so off by default -- DESIGN.md 9.1) -- against the two-slot
-    kernel and the oracle: calls that cross the roll-over and start mid-block (shifted chunk grid:
-    a short first chunk), batched channels, the state they leave, forced chunk lengths, chunk-parallel carries."""
-    td, fd, fdx = O.combo_types(combo)
-    C = 2
-    lens = (2 * m + 2101, 2 * m + 1000 + 7, 2048)
-    xb = np.stack([noise(sum(lens), seed=190 + c, dtype=td) for c in range(C)])
-    refs = [O.best(m, window, 1.0, combo) for _ in range(C)]
-    with make(m, window, 1.0, combo, C, rows_split=1) as p, make(m, window, 1.0, combo, C, rows_split=0) as q:
-        i = 0
-        for n in lens:
-            seg = np.ascontiguousarray(xb[:, i:i + n])
-            got, old = p.sdft(seg), q.sdft(seg)
-            assert p.get_option("last_rows_split") == 1 and q.get_option("last_rows_split") == 0 and q.get_option("last_rows_f32") == 1
-            assert p.get_option("last_chunks") > 1
-            for c in range(C):
-                assert np.array_equal(got[c], refs[c].sdft(seg[c])), (combo, m, window, n, c)
-            assert np.array_equal(got, old)
-            i += n
-        acc, fid, hist, cur = p.state()
-        for c in range(C):
-            racc, rfid, rhist, rcur = refs[c].state()
-            assert cur == rcur and np.array_equal(acc[c], racc) and np.array_equal(fid[c], rfid) and np.array_equal(hist[c], rhist)
-    x = xb[0, :3 * m + 1500]
-    ref = O.best(m, window, 1.0, combo)
-    want = ref.sdft(x)
-    for chunk in (64, 200, 1024):                               # forced chunk lengths (serial carry pass; whole and ragged groups of the halo loop)
-        with make(m, window, 1.0, combo, chunk=chunk, rows_split=1) as p:
-            assert np.array_equal(p.sdft(x), want) and p.get_option("last_rows_split") == 1, chunk
-    with make(m, window, 1.0, combo, float_carry_parallel=1, rows_split=1) as p, make(m, window, 1.0, combo, float_carry_parallel=1, rows_split=0) as q:
-        assert np.array_equal(p.sdft(x), q.sdft(x)) and p.get_option("last_rows_split") == 1 and p.get_option("last_chain") == 0
 
 
 @pytest.mark.parametrize("combo,m,n", [("f64f64", 1000, 30000), ("f32f64", 1024, 20000), ("f32f32", 4096, 9000), ("f32f64", 512, 700)])
