@@ -221,6 +221,22 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
             p.synchronize()
             w = (time.perf_counter() - t0) / (total // hop)
         res[f"us_per_hop_{mode}"] = round(w * 1e6, 1)
+    # option "resident" = 1 (off by default): the same two synchronous calls per hop served by one kernel that stays on the chip -- a doorbell
+    # and a completion word per call instead of a launch (sdft_resident.hpp)
+    p.set_option("async", 0)
+    p.set_option("resident", 1)
+    w = 0.0
+    for rep in range(2):
+        p.synchronize()
+        t0 = time.perf_counter()
+        for i in range(0, total, hop):
+            p.api.sdft_n(p._p, hop, C.c_void_p(xs + i * isz), C.c_void_p(ds))
+            p.api.isdft_n(p._p, hop, C.c_void_p(ds), C.c_void_p(ys + i * isz))
+        w = (time.perf_counter() - t0) / (total // hop)
+        p.synchronize()
+    res["us_per_hop_resident_sync"] = round(w * 1e6, 1)
+    res["resident"] = {"calls": int(p.get_option("resident_calls")), "launches": int(p.get_option("resident_launches")), "missed": int(p.get_option("resident_missed"))}
+    p.set_option("resident", 0)
     # the fused entry point: one call and one launch per hop (process_hop_kernel: folded form, tiles combined in the kernel)
     for mode in ("sync", "async"):
         p.set_option("async", 1 if mode == "async" else 0)

@@ -161,7 +161,7 @@ int   sdft_hip_synchronize(sdft_t* sdft) SDFT_HIP_SYMBOL(synchronize);
 double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t* samples, sdft_fdx_t* dfts, sdft_td_t* out) SDFT_HIP_SYMBOL(time_hops);
 
 /* ---- options -----------------------------------------------------------------------------------
-   Twenty-two keys.  The first eleven are for hosts; the defaults are the safe and (but for the host-memory choices, which only the host can
+   Twenty-two keys.  The first twelve are for hosts; the defaults are the safe and (but for the host-memory choices, which only the host can
    make) the fast ones:
    "async"         0|1   see above
    "pipeline"      asynchronous analysis calls on the plan's own stream into matrices that do not overlap (a host that alternates between two
@@ -182,7 +182,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        arithmetic does, but NOT within 1e-4 of the float reference (which itself drifts about 2e-4
                        of the largest bin per 262144 samples); the state then differs from the reference's by the same
    "exact_inverse" 1 (default) = synthesis gives the reference's bits (bins of a row added in the reference's order, or --
-                       float samples from double bins, option "inverse_verify" = 1 (default), up to 500 000
+                       float samples from double bins, up to 500 000
                        rows -- a tree sum whose rounding interval proves the reference's float, rows it cannot prove
                        added in order), 0 = wave-parallel tree sum, unverified
    "host_copy"     0 (default) = copies between the caller's host memory and the device go through pinned 2 MiB pieces of the
@@ -210,7 +210,17 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        late on one box and 45 us late on another); 0 = sleep on the stream, 2 = poll from the start
    "profile"       0 off, 1 = HIP events around every stage, 2 = around the forward / inverse kernel only
                        (read with sdft_hip_get_profile; every event pair costs ~5 us of stream time)
-   Eleven more pick a route the library otherwise picks by itself (a host that knows its shapes may, the tests do):
+   "resident"      0 (default) | 1 = the reference driver's loop -- sdft_sdft_n + sdft_isdft_n per hop, synchronous calls of one time chunk
+                       (< 512 samples; synthesis of up to 1024 rows) on device pointers, single-channel plan on its own stream
+                       (test/test.c:69-83 of the reference) -- is served by ONE kernel that stays on the chip: the host writes a call into a
+                       cache line of pinned memory and rings a doorbell word, the kernel's workgroups run the same device functions the launches
+                       run (bit-identical) and set the completion word: no launch and no stream query per call.  The kernel leaves by itself when
+                       no call has come for 200 us (the first call after that starts it again), so a blocking hipMemcpy of the host -- which
+                       waits for the plan's stream -- waits that long at most; every other entry point of the plan and sdft_hip_synchronize
+                       retire it first.  Off by default: while it lives it holds 256 small workgroups and the plan's stream.
+                       get_option "resident_calls", "resident_launches", "resident_missed" (calls that raced with the time-out and were
+                       rung again), "resident_alive"
+   Ten more pick a route the library otherwise picks by itself (a host that knows its shapes may, the tests do):
    "chunk"         samples per time chunk (0 = heuristic)
    "segments"      time segments of the exact carry pass overlapped with the forward launches (0 = heuristic)
    "chain"         exact carries: 1 (default) = relay form (seed table; identical waves take blocks of steps in turn, one dependent addition
@@ -229,8 +239,6 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
                        what any summation order can differ by; only samples whose bound straddles a rounding boundary of the
                        float are summed in order -- get_option "ordered_walks" counts them)
    "inverse_rows"  rows per wave of the exact inverse (0 = heuristic and tuner; 4, 8, 16, 32)
-   "inverse_verify" 1 (default) = float samples from double bins by the tree sum with the rounding-interval proof (see "exact_inverse"), 0 = always
-                       the ordered sum
    "inverse_tune"  1 (default) = synthesis calls from 8 Ki rows on find the fastest of their bit-identical forms -- 4, 8, 16 or 32 rows
                        per wave, 256- or 512-byte row segments, the tree sum with the rounding-interval proof, whole rows read in step -- on the
                        host's own calls: the first calls of a shape take the forms in turn, timed by events, then the fastest serves the shape
@@ -245,7 +253,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    TEST HOOKS.  Every other fork of the host logic is decided by the library alone in libsdft_hip.so.  The same sources built with
    -DSDFT_HIP_TEST_HOOKS (libsdft_hip_hooks.so, built beside the product by `python -m sdft_amd.build`; no host links it) accept the keys that force
    those forks, so that the tests can run every route against the reference and the probes under scripts/ can measure them:
-   "rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves",
+   "rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves", "inverse_verify",
    "relay_flow", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams" (sdft_capi.inc names what each selects);
    get_option "test_hooks" = 1 in that build.
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",

@@ -255,8 +255,10 @@ __global__ __launch_bounds__(kWave * WPB) void forward_hop_kernel(HopArgs<TD, FD
 // serial pass would have there.  Nothing is approximated and nothing is exchanged: every row is still the reference's, bit
 // for bit, and the last part's workgroups write the state.  Critical path per tile: n x 22 -> about n x (10 + 12 / parts).
 // ------------------------------------------------------------------------------------------
+// (the body is a device function of (arguments, workgroup number, workgroups of the call): forward_hop2_kernel runs it once per launch, the resident
+// kernel of sdft_resident.hpp once per doorbell)
 template <typename TD, typename FD, int BPL, int WIN, bool ROWS>
-__global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD> a)
+SDFT_D void forward_hop2_body(const HopArgs<TD, FD>& a, const unsigned block, const unsigned blocks)
 {
   constexpr int H = win_halo<WIN>::value;
   constexpr int HL = (H + BPL - 1) / BPL;
@@ -272,9 +274,9 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
 #endif
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 recurrence, 1 window + stores
-  const unsigned tile = blockIdx.x % a.tiles;
-  const unsigned part = (blockIdx.x / a.tiles) % a.parts;
-  const size_t ch = blockIdx.x / (a.tiles * a.parts);
+  const unsigned tile = block % a.tiles;
+  const unsigned part = (block / a.tiles) % a.parts;
+  const size_t ch = block / (a.tiles * a.parts);
   const size_t p0 = (size_t)part * a.part_len;                                   // this workgroup's samples: [p0, p1)
   const size_t p1 = (p0 + a.part_len < a.n) ? p0 + a.part_len : a.n;
 
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
         }
     }
 #ifdef SDFT_HOP_STAMPS
-    if (a.stamps && blockIdx.x == gridDim.x - 1 && lane == 0) for (int i = 0; i < 4; ++i) a.stamps[i] = stamp[i];       // (the last part: the longest way)
+    if (a.stamps && block == blocks - 1 && lane == 0) for (int i = 0; i < 4; ++i) a.stamps[i] = stamp[i];       // (the last part: the longest way)
 #endif
   }
   else
@@ -516,11 +518,17 @@ __global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD>
     }
 #ifdef SDFT_HOP_STAMPS
     SDFT_HOP2_STAMP(2);
-    if (a.stamps && blockIdx.x == gridDim.x - 1 && lane == 0) for (int i = 0; i < 3; ++i) a.stamps[4 + i] = stamp[i];
+    if (a.stamps && block == blocks - 1 && lane == 0) for (int i = 0; i < 3; ++i) a.stamps[4 + i] = stamp[i];
 #endif
   }
   // completion word: both waves' stores are out before one lane reports
   signal_done_workgroup(a.done);
+  (void)blocks;
+}
+template <typename TD, typename FD, int BPL, int WIN, bool ROWS>
+__global__ __launch_bounds__(2 * kWave) void forward_hop2_kernel(HopArgs<TD, FD> a)
+{
+  forward_hop2_body<TD, FD, BPL, WIN, ROWS>(a, blockIdx.x, gridDim.x);
 }
 
 }  // namespace sdfthip

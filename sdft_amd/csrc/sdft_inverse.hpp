@@ -420,17 +420,21 @@ __global__ __launch_bounds__(kBlock) void inverse_exact_kernel(InverseArgs<TD, F
 // order (every lane holds the same sum: no exec masking, same cost as one lane).  What remains is
 // the chain of N dependent additions the reference's summation order dictates.
 // ------------------------------------------------------------------------------------------
-template <typename TD, typename FD, bool LAT1, bool OPS = false>
-__global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> a)
+// (the body is a device function of (arguments, the wave's row, its block of LDS): inverse_row_kernel runs it once per launch, the resident kernel of
+// sdft_resident.hpp once per row a wave takes)
+template <typename FD> struct inverse_row_geometry
 {
-  constexpr int BPL = 16 / (int)sizeof(cx<FD>);          // bins per 16-byte load
-  constexpr int NL = 16;                                 // loads in flight per lane
-  constexpr int TB = kWave * NL * BPL;                   // bins per LDS block (1024 f64 / 2048 f32: 8 KiB)
+  static constexpr int BPL = 16 / (int)sizeof(cx<FD>);   // bins per 16-byte load
+  static constexpr int NL = 16;                          // loads in flight per lane
+  static constexpr int TB = kWave * NL * BPL;            // bins per LDS block (1024 f64 / 2048 f32: 8 KiB)
+};
+template <typename TD, typename FD, bool LAT1, bool OPS = false>
+SDFT_D void inverse_row_body(const InverseArgs<TD, FD>& a, const size_t r, FD* terms)
+{
+  constexpr int BPL = inverse_row_geometry<FD>::BPL, NL = inverse_row_geometry<FD>::NL, TB = inverse_row_geometry<FD>::TB;
   using V = typename StoreVec<FD, (sizeof(cx<FD>) == 16 ? 1 : 2)>::type;
-  __shared__ __align__(16) FD terms[TB];
 
-  const int lane = threadIdx.x;
-  const size_t r = (size_t)gridDim.x - 1 - blockIdx.x;       // last rows first (what the analysis wrote last is still in cache)
+  const int lane = threadIdx.x & (kWave - 1);
   const size_t ch = r / a.n, t = r - ch * a.n;
   const cx<FD>* row = a.in_rows ? a.in_rows[r] : a.in + ch * a.in_stride + t * (size_t)a.nbins;
   const FD* grow = OPS ? gain_row(a.op, t, a.nbins) : nullptr;
@@ -524,6 +528,13 @@ __global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> 
     a.y[ch * a.y_stride + t] = decided ? decided_y : (TD)(sum * a.sweight);           // sdft.h:654-656
     signal_done(a.done);
   }
+}
+template <typename TD, typename FD, bool LAT1, bool OPS = false>
+__global__ __launch_bounds__(kWave) void inverse_row_kernel(InverseArgs<TD, FD> a)
+{
+  __shared__ __align__(16) FD terms[inverse_row_geometry<FD>::TB];
+  // last rows first (what the analysis wrote last is still in cache)
+  inverse_row_body<TD, FD, LAT1, OPS>(a, (size_t)gridDim.x - 1 - blockIdx.x, terms);
 }
 
 }  // namespace sdfthip

@@ -6,6 +6,7 @@
 
 #include "sdft_kernels.hpp"
 #include "sdft_forward_rows_f32.hpp"      // not part of the run-time-compiled text: plain analysis only
+#include "sdft_resident.hpp"              // likewise: the opt-in resident kernel of the hop loop
 #include "sdft_plan_logic.hpp"            // every decision that needs no HIP call (unit-tested on the CPU under sanitizers)
 #include "sdft_host_io.hpp"               // the caller's host memory: classification, registration, copies through pinned slots
 
@@ -271,6 +272,8 @@ class Plan
   void destroy()
   {
     (void)hipSetDevice(device);
+    (void)resident_retire();
+    resident_release();
     (void)pipe_join();
     if (stream) (void)hipStreamSynchronize(stream);
     d_tw.release(); d_syn.release(); d_wtab.release();
@@ -305,7 +308,12 @@ class Plan
 
   // a host driving several GPUs from one process may have switched the current device
   std::chrono::steady_clock::time_point call_start;         // when the entry point in progress began (finish() counts from here)
-  bool bind() { flag_pending = false; flag_wanted = false; pipe_allowed = false; call_start = std::chrono::steady_clock::now(); SDFT_TRY(hipSetDevice(device)); return true; }
+  bool bind()
+  {
+    flag_pending = false; flag_wanted = false; pipe_allowed = false; call_start = std::chrono::steady_clock::now();
+    SDFT_TRY(hipSetDevice(device));
+    return res.alive ? resident_retire() : true;             // (option "resident": whatever is not one of its calls ends the kernel first)
+  }
 
   // sdft.h:517-529
   bool reset()
@@ -334,6 +342,7 @@ class Plan
 
   bool synchronize()
   {
+    if (res.alive && !resident_retire()) return false;
     if (!pipe_join()) return false;
     SDFT_TRY(hipStreamSynchronize(stream));
     if (status_armed)
@@ -1328,6 +1337,7 @@ class Plan
   }
   // ---- the kernel launches: run-time values -> template instantiations -------------------------------------------------
 #include "sdft_plan_launch.inc"
+#include "sdft_plan_resident.inc"
 
   // ---- inverse on device-resident buffers --------------------------------------------------
   bool inverse_device(size_t n, const fdx* in, size_t in_stride, const fdx* const* rows, TD* y, size_t y_stride,

@@ -1,0 +1,158 @@
+// sdft_resident.hpp -- an opt-in RESIDENT kernel for the reference driver's hop loop (/root/reference/test/test.c:69-83:
+// sdft_sdft_n + sdft_isdft_n per hop of 100 samples, synchronous calls on device pointers).
+// Not part of the run-time-compiled text (sdft_kernels.hpp): plain analysis and synthesis only.
+//
+// A synchronous call costs a launch and a completion whatever its kernel does: 13.5 us per call where the two kernels of a hop need 11 us
+// together (profiles/r05_hop_time_parts.txt).  With option "resident" = 1 the first such call starts ONE kernel of kResidentBlocks small
+// workgroups that stays on the chip and serves the calls that follow: the host writes a call into one cache line of pinned memory (pointers,
+// length, cursor, state slots; the doorbell -- a sequence number -- last), workgroup 0 polls that line over PCIe (one 64-byte read per poll),
+// copies it to device memory and publishes its number there; the other workgroups poll the device word.  The work of a call is the body of
+// forward_hop2_kernel (analysis: every (tile of bins, time part) one workgroup) or of inverse_row_kernel (synthesis: a wave per row) -- the
+// same device functions, bit for bit the same results -- and completion is the kernels' own completion word in pinned memory.
+// What orders a call after the one before it: every workgroup ends a call with an agent-scope release (the ticket of the completion word)
+// and begins the next with an agent-scope acquire (the poll of the device word), and the host rings the doorbell only after it has seen the
+// completion word -- a synthesis reads the rows the analysis before it wrote, on whichever XCD.
+// The kernel LEAVES by itself when no call has come for `idle_ticks` of the 100 MHz clock (200 us): a blocking-stream hipMemcpy of the
+// host, which waits for the plan's stream, waits that long at most.  Every other entry point of the plan retires it first (a QUIT call).
+// On leaving it writes the number of the last call it served to pinned memory: a host whose call raced with the time-out sees that its
+// call was not served and launches the ordinary kernel.  All polls are bounded.
+
+#pragma once
+
+#include "sdft_forward_hop.hpp"
+#include "sdft_inverse.hpp"
+
+#pragma clang fp contract(off)
+
+namespace sdfthip {
+
+constexpr unsigned kResidentBlocks = 256;                  // workgroups of the resident kernel (two waves each): one per CU
+enum { RES_ANALYSIS = 1, RES_SYNTHESIS = 2, RES_QUIT = 3 };
+
+// one call = one cache line of pinned host memory; the host writes `seq` LAST (the line is read with one 64-byte request: a snapshot)
+struct __attribute__((aligned(64))) ResidentCall
+{
+  unsigned long long x, out, y;                            // device pointers: analysis x -> out, synthesis out -> y
+  unsigned n, cursor0, parts, part_len;
+  unsigned slots;                                          // bits 0-1: the state slot the call reads, bits 2-3: the delay-line slot (it writes slot ^ 1)
+  unsigned op, flag_seq, blocks;                           // blocks: workgroups (analysis) / rows (synthesis) that report to the completion word
+  unsigned check;                                          // ~seq: a line whose words do not belong together is polled again
+  unsigned seq;                                            // the doorbell
+};
+static_assert(sizeof(ResidentCall) == 64, "one cache line");
+
+template <typename TD, typename FD> struct ResidentArgs
+{
+  HopArgs<TD, FD> ha;                                      // what does not change from call to call (tables, geometry, window scale)
+  InverseArgs<TD, FD> ia;
+  cx<FD>* acc[4];                                          // the plan's state slots
+  cx<FD>* fid[4];
+  TD* hist[4];
+  const unsigned* host_call;                               // the line the host writes (pinned, mapped), as 16 words
+  unsigned* dev_call;                                      // two device copies of it (by call number & 1), published by workgroup 0
+  unsigned* dev_seq;                                       // device word: the number of the latest call in dev_call
+  unsigned* done_flag;                                     // completion word (pinned) and its ticket counter (device): DoneSignal
+  unsigned* done_count;
+  unsigned* exit_word;                                     // pinned: the last call served, written when the kernel leaves
+  unsigned first_seq;                                      // the first call this launch serves
+  unsigned idle_ticks;                                     // leave when no call has come for that long (100 MHz clock)
+};
+
+template <typename TD, typename FD, int BPL, int WIN, bool LAT1>
+__global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD, FD> ra)
+{
+  __shared__ unsigned cur[16];                             // the call being served (ResidentCall as words)
+  __shared__ __align__(16) FD terms[2][inverse_row_geometry<FD>::TB];
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned next = ra.first_seq;                            // the call this workgroup waits for
+  unsigned served = ra.first_seq - 1u;                     // (workgroup 0: the last call taken from the host)
+  for (;;)
+  {
+    if (wave == 0)
+    {
+      if (blockIdx.x == 0)
+      {
+        // ---- workgroup 0: the host's line, over PCIe ----
+        const unsigned long long t0 = wall_clock64();
+        unsigned word = 0;
+        bool quit = false;
+        for (;;)
+        {
+          word = lane < 16 ? __hip_atomic_load(const_cast<unsigned*>(ra.host_call) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+          const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
+          if (seq == next && chk == ~seq) break;
+          if (wall_clock64() - t0 > (unsigned long long)ra.idle_ticks) { quit = true; break; }
+        }
+        if (quit) word = lane == 11 ? (unsigned)RES_QUIT : (lane == 15 ? next : (lane == 14 ? ~next : 0u));
+        else served = next;
+        unsigned* slot = ra.dev_call + 16u * (next & 1u);
+        if (lane < 16) { __hip_atomic_store(slot + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cur[lane] = word; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(ra.dev_seq, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the call before this one wrote, on any XCD
+      }
+      else
+      {
+        // ---- the others: the device word; always the LATEST call (a workgroup that fell behind had no work in the ones it skips:
+        // the host rings only after every workgroup with work has reported) ----
+        const unsigned long long t0 = wall_clock64();
+        unsigned word = 0;
+        for (;;)
+        {
+          const unsigned s = __hip_atomic_load(ra.dev_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(s - next) >= 0)
+          {
+            word = lane < 16 ? __hip_atomic_load(ra.dev_call + 16u * (s & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const unsigned s2 = __hip_atomic_load(ra.dev_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
+            if ((s2 == s || s2 == s + 1u) && seq == s && chk == ~s) break;       // (two publishes since: the copy may be the newer call's: again)
+          }
+          else __builtin_amdgcn_s_sleep(2);
+          // (four idle periods: workgroup 0 has long said QUIT if it lives)
+          if (wall_clock64() - t0 > 4ull * (unsigned long long)ra.idle_ticks) { word = lane == 11 ? (unsigned)RES_QUIT : 0u; break; }
+        }
+        if (lane < 16) cur[lane] = word;
+      }
+    }
+    __syncthreads();
+    const unsigned op = cur[11];
+    if (op != (unsigned)RES_ANALYSIS && op != (unsigned)RES_SYNTHESIS) break;      // QUIT (or a line nobody should have written)
+    const unsigned long long px = ((unsigned long long)cur[1] << 32) | cur[0], pout = ((unsigned long long)cur[3] << 32) | cur[2],
+                             py = ((unsigned long long)cur[5] << 32) | cur[4];
+    const unsigned n = cur[6], blocks = cur[13];
+    DoneSignal done; done.flag = ra.done_flag; done.count = ra.done_count; done.seq = cur[12]; done.total = blocks;
+    if (op == (unsigned)RES_ANALYSIS)
+    {
+      if (blockIdx.x < blocks)
+      {
+        HopArgs<TD, FD> a = ra.ha;
+        const unsigned ss = cur[10] & 3u, hs = (cur[10] >> 2) & 3u;
+        a.x = reinterpret_cast<const TD*>(px); a.x_stride = n;
+        a.out = reinterpret_cast<cx<FD>*>(pout); a.out_stride = (size_t)n * a.nbins; a.out_rows = nullptr;
+        a.n = n; a.cursor0 = cur[7]; a.parts = cur[8]; a.part_len = cur[9];
+        a.acc_in = ra.acc[ss]; a.fid_in = ra.fid[ss]; a.acc_out = ra.acc[ss ^ 1u]; a.fid_out = ra.fid[ss ^ 1u];
+        a.hist_in = ra.hist[hs]; a.hist_out = ra.hist[hs ^ 1u];
+        a.vec_store = (BPL == 2 && (a.nbins % 2u) == 0u && (pout % 16ull) == 0ull) ? 1 : 0;
+        a.done = done;
+        forward_hop2_body<TD, FD, BPL, WIN, false>(a, blockIdx.x, blocks);
+      }
+    }
+    else
+    {
+      InverseArgs<TD, FD> ia = ra.ia;
+      ia.in = reinterpret_cast<const cx<FD>*>(pout); ia.in_stride = (size_t)n * ia.nbins; ia.in_rows = nullptr;
+      ia.y = reinterpret_cast<TD*>(py); ia.y_stride = n; ia.n = n;
+      ia.done = done;
+      // a wave per row, last rows first (what the analysis wrote last is nearest)
+      for (size_t r = (size_t)blockIdx.x * 2u + wave; r < (size_t)n; r += 2u * (size_t)gridDim.x)
+        inverse_row_body<TD, FD, LAT1, false>(ia, (size_t)n - 1u - r, terms[wave]);
+    }
+    __syncthreads();                                         // everybody is through with `cur`
+    next = cur[15] + 1u;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ra.exit_word, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace sdfthip

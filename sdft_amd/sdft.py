@@ -109,7 +109,10 @@ class SDFT:
                 acc, fid, hist, cursor = self.state()            # (synchronises; the plan may have been called already)
                 self.api.free(self._p)
                 self.api, self._p = other, q
-                self.set_state(acc, fid, hist, cursor)
+                # (a plan nobody has called yet is not handed a state: an installed fid counts as the host's own, and the relay
+                # form of the exact carries, which needs the canonical rotation, would never be taken)
+                if cursor != 0 or np.any(acc) or np.any(hist):
+                    self.set_state(acc, fid, hist, cursor)
                 if self._stream is not None:
                     self.set_stream(self._stream)
                 self._options.append((key, int(value)))

@@ -8,7 +8,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("scripts", "README.md")]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("scripts", "README.md"), os.path.join("profiles", "HISTORY.md")]
 # a claim cites a file under profiles/ (the builder's sessions) or one of the DRIVER's records at the repository root
 # (BENCH_r0N.json: the line the driver's own run of bench.py produced at the end of round N -- round-4 review, item 10)
 CLAIM = re.compile(r"⟨([^⟩·]+)·\s*((?:profiles/[A-Za-z0-9_./-]+)|(?:BENCH_r\d+\.json))\s*⟩")

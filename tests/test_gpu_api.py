@@ -999,10 +999,10 @@ def test_product_library_knows_22_options_and_the_hooks_library_the_rest():
     from sdft_amd import capi
     from sdft_amd.sdft import SDFT
     product = ("async", "pipeline", "carry", "float_carry_parallel", "exact_inverse", "host_copy", "host_register", "copy_threads", "pinned_io", "spin",
-               "profile", "chunk", "segments", "chain", "self_carry", "hop_kernel", "fused_exact", "inverse_rows", "inverse_verify", "inverse_tune",
+               "profile", "resident", "chunk", "segments", "chain", "self_carry", "hop_kernel", "fused_exact", "inverse_rows", "inverse_tune",
                "pointers", "stage_bytes")
     hooks = ("rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves",
-             "relay_flow", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams")
+             "relay_flow", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams", "inverse_verify")
     gone = ("rows_split", "inverse_rpi", "hop_pipe", "flag_max", "no_such_option")
     assert len(product) == 22
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdft", "sdft_hip.h")).read()
@@ -1012,7 +1012,7 @@ def test_product_library_knows_22_options_and_the_hooks_library_the_rest():
         q = api.alloc_batch(64, 1, 1.0, 1)
         assert q and api.get_option(q, b"test_hooks") == (1 if hk else 0)
         for k in product:
-            cur = api.get_option(q, k.encode()) if k not in ("stage_bytes", "profile") else 0
+            cur = api.get_option(q, k.encode()) if k not in ("stage_bytes", "profile", "resident") else 0
             assert api.set_option(q, k.encode(), max(cur, 0)) == 0, (hk, k)
         for k in hooks:
             assert api.set_option(q, k.encode(), 1) == (0 if hk else -1), (hk, k)

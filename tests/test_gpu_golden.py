@@ -103,3 +103,68 @@ def test_reference_test_wav_pattern():
     assert rel_err(np.concatenate(ys), g["y"]) <= 1e-6
     # the reference's own acceptance rule (test/main.py:70,78): np.allclose defaults
     assert np.allclose(np.concatenate(ys), g["y"]) and np.allclose(np.stack(firsts), g["hop_first_rows"])
+
+
+def test_reference_test_wav_pattern_with_the_resident_kernel():
+    """Round 6, option "resident" = 1: the reference driver's loop -- sdft_sdft_n + sdft_isdft_n per hop, synchronous, device
+    pointers (test/test.c:69-83) -- served by ONE kernel that stays on the chip: a doorbell per call instead of a launch.  Same device
+    functions as the launches: every row of every hop and every sample bit-identical to the plan without it and to the reference's golden
+    vectors.  The kernel leaves by itself after 200 us without a call (a pause in the loop: it is started again, nothing changes); a plain
+    blocking hipMemcpy right after the loop returns within that time-out; every other entry point retires it first."""
+    import ctypes as C
+    import time
+    import torch
+    from sdft_amd import capi
+    from sdft_amd.sdft import SDFT
+    g = load("testwav_m1000_hop100_hann_f32f64.npz")
+    hop, x = int(g["hop"]), g["x"]
+    hops = x.size // hop
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for resident in (0, 1):
+        with SDFT(1000, "hann", 1.0, "f32f64") as p:
+            p.set_option("resident", resident)
+            d = torch.empty((hop, 1000), dtype=torch.complex128, device="cuda")
+            y = torch.empty(x.size, dtype=torch.float32, device="cuda")
+            rows = []
+            for i in range(hops):
+                p.sdft(xd[i * hop:(i + 1) * hop], d)
+                if i % 7 == 0:
+                    rows.append(d.cpu().numpy().copy())          # (a blocking copy on the null stream in the middle of the loop: waits for the kernel to leave)
+                else:
+                    rows.append(None)
+                p.isdft(d, y[i * hop:(i + 1) * hop])
+                if i == hops // 2:
+                    time.sleep(0.01)                              # a pause longer than the idle time-out: the kernel has left and is started again
+            if resident:
+                assert p.get_option("resident_calls") >= 2 * hops - 2 * (hops // 7 + 2), (p.get_option("resident_calls"), hops)
+                assert 2 <= p.get_option("resident_launches") <= hops // 7 + 4, p.get_option("resident_launches")
+                # a plain hipMemcpy right after the loop: the plan's stream is a blocking stream, the copy waits for the kernel to leave
+                hip = C.CDLL(capi.hip_runtime)
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                p.sdft(xd[:hop], d); p.isdft(d, y[:hop])          # (the kernel is alive: two resident calls)
+                assert p.get_option("resident_alive") == 1
+                host = np.empty(hop, dtype=np.float32)
+                t0 = time.perf_counter()
+                assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(y.data_ptr()), C.c_size_t(host.nbytes), 2) == 0
+                waited = time.perf_counter() - t0
+                assert waited < 5e-3, waited                       # (200 us of idle time-out and the copy itself; 5 ms leaves room for a busy box)
+                # undo those two calls' effect on the comparison below: run the other plan's loop the same way
+            else:
+                assert p.get_option("resident_calls") == 0
+                p.sdft(xd[:hop], d); p.isdft(d, y[:hop])
+            # every other entry point retires the kernel first: the state, a long call, a host-pointer call
+            st = p.state()
+            assert p.get_option("resident_alive") == 0
+            tail = p.sdft(x[:37])                                  # host pointers: the ordinary route
+            res[resident] = (rows, y.cpu().numpy(), st, tail)
+    rows0, y0, st0, tail0 = res[0]
+    rows1, y1, st1, tail1 = res[1]
+    for a, b in zip(rows0, rows1):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    assert np.array_equal(y0, y1) and np.array_equal(tail0, tail1)
+    for a, b in zip(st0[:3], st1[:3]):
+        assert np.array_equal(a, b)
+    assert st0[3] == st1[3]
+    assert np.array_equal(np.stack([r[0] for r in rows1 if r is not None]), g["hop_first_rows"][::7][:len([r for r in rows1 if r is not None])])
+    assert rel_err(y1[hop:], g["y"][hop:y1.size]) <= 1e-6
