@@ -155,12 +155,12 @@ def north_star_shape(torch, np, SDFT, sine_sweep, cdt, m, window, combo, esz, td
                                 "second": {k: pl_b.get(k) for k in ("placed", "window_gbs", "start_gbs", "boundary_offset")}}}
     # (async_two_buffers: a host that alternates between two matrices -- consecutive calls then overlap, option "pipeline";
     # calls into ONE matrix are ordered behind each other as on one stream)
-    for mode in ("sync", "async", "async_two_buffers", "async_two_buffers_pipelined", "sync_first_allocation"):
+    for mode in ("sync", "async", "async_two_buffers", "async_two_buffers_one_stream", "sync_first_allocation"):
         p = SDFT(m, window, 1.0, combo, device=device)
         if not mode.startswith("sync"):
             p.set_option("async", 1)
-        if mode == "async_two_buffers_pipelined":
-            p.set_option("pipeline", 1)
+        if mode == "async_two_buffers_one_stream":
+            p.set_option("pipeline", 0)
         xs48 = C.c_void_p(x48.data_ptr())
         first = o_plain if mode == "sync_first_allocation" else o48
         os48 = [C.c_void_p(first.data_ptr()), C.c_void_p((o48b if mode.startswith("async_two_buffers") else first).data_ptr())]
@@ -899,7 +899,7 @@ def main():
                 ptr = [C.c_void_p(out.data_ptr()), C.c_void_p(out2.data_ptr())]
                 xptr = C.c_void_p(x.data_ptr())
                 bq = n * (m * esz + np.dtype(td).itemsize)
-                for label, pipe in (("pipelined", 1), ("one_stream", 0), ("library_default", None)):
+                for label, pipe in (("pipelined", 2), ("one_stream", 0), ("library_default", None)):
                     pp = SDFT(m, window, 1.0, combo, device=local_rank)
                     pp.set_option("async", 1)
                     if pipe is not None:
@@ -934,8 +934,8 @@ def main():
                                    "pipelined_synthesis_calls": int(pp.get_option("pipelined_inverse_calls"))})
                         del y2
                     pp.close()
-                tm["note"] = ("asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn: option pipeline = 1 (the rows of consecutive calls on two "
-                              "streams), = 0 (one stream), and the library's default, which pipelines only calls of less than two rounds of the chip")
+                tm["note"] = ("asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn: option pipeline = 2 (the rows of consecutive calls on two "
+                              "streams whatever the length), = 0 (one stream), and the library's default (1), which pipelines only calls of up to one round of the chip")
                 result["two_matrices_in_turn"] = tm
                 del out2
             except Exception as e:                              # (a second 16 GB matrix: not on every box)

@@ -90,7 +90,6 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
         if (lane < 16) { __hip_atomic_store(slot + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cur[lane] = word; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_store(ra.dev_seq, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the call before this one wrote, on any XCD
       }
       else
       {
@@ -98,17 +97,19 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
         // the host rings only after every workgroup with work has reported) ----
         const unsigned long long t0 = wall_clock64();
         unsigned word = 0;
+        // (relaxed polls: an acquire per poll would invalidate the XCD's L2 under the workgroups that are working; the one acquire a call
+        // needs is made below, by the workgroups that have work in it)
         for (;;)
         {
-          const unsigned s = __hip_atomic_load(ra.dev_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned s = __hip_atomic_load(ra.dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((int)(s - next) >= 0)
           {
             word = lane < 16 ? __hip_atomic_load(ra.dev_call + 16u * (s & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            const unsigned s2 = __hip_atomic_load(ra.dev_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
+            const unsigned s2 = __hip_atomic_load(ra.dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((s2 == s || s2 == s + 1u) && seq == s && chk == ~s) break;       // (two publishes since: the copy may be the newer call's: again)
           }
-          else __builtin_amdgcn_s_sleep(2);
+          else __builtin_amdgcn_s_sleep(1);
           // (four idle periods: workgroup 0 has long said QUIT if it lives)
           if (wall_clock64() - t0 > 4ull * (unsigned long long)ra.idle_ticks) { word = lane == 11 ? (unsigned)RES_QUIT : 0u; break; }
         }
@@ -122,6 +123,9 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
                              py = ((unsigned long long)cur[5] << 32) | cur[4];
     const unsigned n = cur[6], blocks = cur[13];
     DoneSignal done; done.flag = ra.done_flag; done.count = ra.done_count; done.seq = cur[12]; done.total = blocks;
+    // a workgroup with work in this call sees what the call before it wrote, on any XCD (its own release was the completion ticket)
+    const bool has_work = op == (unsigned)RES_ANALYSIS ? blockIdx.x < blocks : blockIdx.x < n;
+    if (has_work) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (op == (unsigned)RES_ANALYSIS)
     {
       if (blockIdx.x < blocks)
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
       ia.in = reinterpret_cast<const cx<FD>*>(pout); ia.in_stride = (size_t)n * ia.nbins; ia.in_rows = nullptr;
       ia.y = reinterpret_cast<TD*>(py); ia.y_stride = n; ia.n = n;
       ia.done = done;
-      // a wave per row, last rows first (what the analysis wrote last is nearest)
-      for (size_t r = (size_t)blockIdx.x * 2u + wave; r < (size_t)n; r += 2u * (size_t)gridDim.x)
+      // a wave per row, the rows spread over the workgroups (a hop of 100 rows: one wave on each of 100 CUs), last rows first
+      for (size_t r = (size_t)blockIdx.x + (size_t)wave * gridDim.x; r < (size_t)n; r += 2u * (size_t)gridDim.x)
         inverse_row_body<TD, FD, LAT1, false>(ia, (size_t)n - 1u - r, terms[wave]);
     }
     __syncthreads();                                         // everybody is through with `cur`

@@ -104,7 +104,8 @@ def test_single_rank_bench_line_contract():
                               0 < two["pipelined"]["frac_of_peak_wall"] < 1 and 0 < two["one_stream"]["frac_of_peak_wall"] < 1 and
                               0 < two["library_default"]["frac_of_peak_wall"] < 1 and 0 < two["synthesis_frac_of_peak_wall"] < 1), two
     ns = res["north_star_n48000"]
-    assert ns["async_two_buffers_pipelined"]["pipelined_calls"] >= 50 and ns["async_two_buffers_pipelined"]["row_streams"] in ("ordinary", "by priority"), ns
+    assert ns["async_two_buffers"]["pipelined_calls"] >= 50 and ns["async_two_buffers"]["row_streams"] in ("ordinary", "by priority"), ns
+    assert ns["async_two_buffers_one_stream"]["pipelined_calls"] == 0, ns
     assert 0 < ns["sync"]["frac_of_peak_wall"] < 1 and 0 < ns["sync_first_allocation"]["frac_of_peak_wall"] < 1 and ns["buffer_placement"]["first"]["placed"] is True, ns
 
 
