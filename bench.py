@@ -164,14 +164,14 @@ def north_star_shape(torch, np, SDFT, sine_sweep, cdt, m, window, combo, esz, td
         xs48 = C.c_void_p(x48.data_ptr())
         first = o_plain if mode == "sync_first_allocation" else o48
         os48 = [C.c_void_p(first.data_ptr()), C.c_void_p((o48b if mode.startswith("async_two_buffers") else first).data_ptr())]
-        for i in range(6):
+        for i in range(20):                                  # (the plan's first pipelined calls look for two concurrent streams: a millisecond, once)
             p.api.sdft_n(p._p, n48, xs48, os48[i & 1])       # the raw C-ABI call, as a C host makes it
         p.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(50):
+        for i in range(200):
             p.api.sdft_n(p._p, n48, xs48, os48[i & 1])
         p.synchronize(); torch.cuda.synchronize()
-        w = (time.perf_counter() - t0) / 50
+        w = (time.perf_counter() - t0) / 200
         res[mode] = {"ms_per_call_wall": round(w * 1e3, 4), "msamples_s_wall": round(n48 / w / 1e6, 1),
                      "gbs_wall": round(b48 / w / 1e9, 1), "frac_of_peak_wall": round(b48 / w / 1e9 / HBM_PEAK_GBS, 4)}
         if mode.startswith("async_two_buffers"):
@@ -935,7 +935,7 @@ def main():
                         del y2
                     pp.close()
                 tm["note"] = ("asynchronous sdft_sdft_n calls on the plan's own stream into two matrices in turn: option pipeline = 2 (the rows of consecutive calls on two "
-                              "streams whatever the length), = 0 (one stream), and the library's default (1), which pipelines only calls of up to one round of the chip")
+                              "streams whatever the length), = 0 (one stream), and the library's default (1), which pipelines only calls of less than 2^29 bins (a tie at this length: profiles/r06_pipelined_calls.txt)")
                 result["two_matrices_in_turn"] = tm
                 del out2
             except Exception as e:                              # (a second 16 GB matrix: not on every box)

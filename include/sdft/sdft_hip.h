@@ -167,9 +167,9 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    "pipeline"      asynchronous analysis calls on the plan's own stream into matrices that do not overlap (a host that alternates between two
                        matrices) overlap: the state after a call comes from a small kernel ahead of the call's rows, the rows of consecutive
                        calls run on two internal streams; every other call of the plan and sdft_hip_synchronize wait for them.
-                       1 (default) = calls of up to one round of the chip's workgroups, where the next call fills what a launch leaves idle
-                       (n = 48 000, m = 1024: 73.6 against 68.5 % of the HBM peak); calls of two rounds and more fill the chip by themselves and
-                       stay on one stream (n = 1e6 into two equally placed matrices: 84.5 % on one stream, 81.7 % pipelined).  2 = calls of any
+                       1 (default) = calls of less than 2^29 bins, where the next call fills what a launch leaves idle -- a fixed 20-30 us per call:
+                       n = 48 000, m = 1024: 82 against 75 % of the HBM peak, n = 131 072: 85 against 76 % (profiles/r06_pipelined_calls.txt); longer calls
+                       amortise that by themselves and stay on one stream (n = 1e6: a tie at 85 %).  2 = calls of any
                        length, 0 = never.  Asynchronous synthesis calls that come back to back take the two streams in turn as well; a synthesis
                        never runs beside an analysis; either kind only once two of them have come in a row.  Off by itself on a caller's stream,
                        once sdft_hip_get_stream has been called, and with profiling.  get_option "last_pipelined", "pipelined_calls",

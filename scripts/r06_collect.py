@@ -9,7 +9,7 @@ for src, dst in (("bench_n1e6_m1024.json", "r06_bench_n1e6_m1024.json"), ("bench
                  ("trace_full/full_kernel_stats.csv", "r06_bench_all_side_measurements_kernel_stats.csv"),
                  ("trace_cfg/cfg_kernel_stats.csv", "r06_all_configs_kernel_stats.csv"),
                  ("configs.md", "r06_configs.md"), ("configs_under_rocprof.md", "r06_configs_under_rocprof.md"),
-                 ("north_star_ab.txt", "r06_north_star_n48000_ab.txt"), ("hop_host.txt", "r06_hop_loop.txt")):
+                 ("north_star_ab.txt", "r06_north_star_n48000_ab.txt"), ("hop_host.txt", "r06_hop_loop.txt"), ("pipelined_calls.txt", "r06_pipelined_calls.txt")):
     hits = glob.glob(os.path.join(O, src)) or glob.glob(os.path.join(O, os.path.dirname(src), "**", os.path.basename(src)), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(P, dst))
@@ -34,6 +34,28 @@ if tr:
         for r in rows:
             fh.write("%-72s %10.1f %10.1f %9.1f\n" % (r["Kernel_Name"][:72], (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+# the forward kernel's launches of `bench.py --no-extras` under rocprof, one by one: bench_kernel_stats.csv averages the launches into the placed matrix
+# with those into the first allocation (and the warm-ups); this file keeps them apart, in the order bench.py makes them
+tr = glob.glob(os.path.join(O, "trace", "**", "*kernel_trace.csv"), recursive=True)
+und = os.path.join(P, "r06_bench_n1e6_m1024_under_rocprof.json")
+if tr and os.path.exists(und):
+    line = json.loads(open(und).read().strip().splitlines()[-1])
+    W, K = line["warmup"], line["steps"]
+    rows = sorted((r for r in csv.DictReader(open(tr[0])) if "forward_rows_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    regions = [("warm-up, placed matrix", W), ("TIMED REGION, placed matrix (the headline: roofline.avg_launch_ms)", K), ("warm-up, first allocation", W),
+               ("timed region, first allocation (first_allocation)", K), ("one at a time, placed matrix", min(K, 20)), ("the rest (analysis + synthesis pairs, placed matrix)", len(d))]
+    with open(os.path.join(P, "r06_bench_forward_launches.txt"), "w") as fh:
+        fh.write("# rocprofv3 --kernel-trace of `bench.py --steps %d --no-extras --no-cpu-baseline` (the command of r06_bench_n1e6_m1024_kernel_stats.csv): every launch of\n"
+                 "# forward_rows_kernel<double, 1, 1, true, 1, 0, true, float, false>, milliseconds, in launch order, by the region of bench.py it belongs to.\n"
+                 "# The line this run printed: roofline.avg_launch_ms %.4f (HIP events), first_allocation.frac %.4f.\n" % (K, line["roofline"]["avg_launch_ms"], line["first_allocation"]["frac"]))
+        i = 0
+        for name, count in regions:
+            part = d[i:i + count]; i += len(part)
+            if part:
+                fh.write("%-75s launches %3d  mean %.4f ms  min %.4f  max %.4f  = %.4f of 8 TB/s\n" % (name, len(part), sum(part) / len(part), min(part), max(part),
+                                                                                                   line["roofline"]["algorithmic_bytes_per_launch"] / (sum(part) / len(part) * 1e-3) / 8e12))
+                fh.write("    " + " ".join("%.3f" % v for v in part) + "\n")
 cols = ("Counter_Name", "Counter_Value", "Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Start_Timestamp", "End_Timestamp")
 
 

@@ -19,4 +19,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fb -o fb
 python3 $R/scripts/config_report.py > $O/configs.md 2>/dev/null
 python3 $R/scripts/ns_ab.py 2>/dev/null > $O/north_star_ab.txt
 python3 $R/scripts/hop_host.py 2>/dev/null > $O/hop_host.txt
+python3 $R/scripts/pipeline_ab.py 2>/dev/null > $O/pipelined_calls.txt
 ls -la $O

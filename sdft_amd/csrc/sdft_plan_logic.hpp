@@ -391,18 +391,18 @@ struct TunerTable
 };
 
 // ---- pipelined analyses: where they pay ------------------------------------------------------------------------------------------
-// The next call's workgroups fill what a launch leaves idle -- the launch gap, the prologue of the self-carried chunks, the ragged end: that pays for calls
-// of up to ONE round of the chip (n = 48 000 into two matrices in turn: 73.6 against 68.5 % of the HBM peak on one stream).  A call of two rounds or more
-// fills the chip by itself and its own cut (two rounds of shorter chunks) beats the pipelined one: n = 1e6 into two equally placed matrices 84.5 % on one
-// stream against 81.7 % pipelined (bench.py two_matrices_in_turn, round 6; round 5 had compared unequally placed matrices).
-// option: 0 never, 1 (default) calls of up to one round, 2 calls of any length.
-inline bool pipeline_pays(ChunkQuery q, long option)
+// The next call's workgroups fill what a launch leaves idle -- the launch gap, the prologue of the self-carried chunks, the ragged end: a fixed 20-30 us
+// per call.  Interleaved in one process on two equally placed matrices (profiles/r06_pipelined_calls.txt): n = 24 000 +12 %, n = 48 000 +9 % (82 against
+// 75 % of the HBM peak), n = 90 000 +6 %, n = 131 072 +11 % (85 against 76 %), n = 1e6 a tie (85 %: 2.4 ms per call amortise what pipelining hides, and the
+// call's own cut -- two rounds of shorter chunks -- is as good as the pipelined one).  So: calls of less than 2^29 bins (half a million rows of 1024 bins,
+// about a millisecond of store stream) by default.
+// option: 0 never, 1 (default) calls below that size, 2 calls of any length.
+constexpr size_t kPipelineBinsMax = (size_t)1 << 29;
+inline bool pipeline_pays(const ChunkQuery& q, long option)
 {
   if (option <= 0) return false;
   if (option >= 2) return true;
-  q.pipelined = false;
-  const Chunking c = choose_chunks(q);
-  return c.chunks * (long)std::max<size_t>(q.channels, 1) <= (long)q.compute_units;
+  return std::max<size_t>(q.channels, 1) * q.n * q.nbins < kPipelineBinsMax;
 }
 
 // ---- synthesis: are the matrix' loads non-temporal? ------------------------------------------------------------------------------

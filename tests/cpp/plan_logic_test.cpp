@@ -81,12 +81,12 @@ static void test_chunks()
   CHECK(c.chunks > 256 && c.chunks <= 512, "two rounds at n = 1e6: %ld", c.chunks);
   q.pipelined = true; q.n = 48000; c = choose_chunks(q);
   CHECK(c.chunks == 300 && c.len == 160, "pipelined calls: about 300 chunks of >= 160 rows: %ld x %ld", c.chunks, c.len);
-  // where pipelined calls pay: calls of up to one round of the chip by default, any length on request, never when off
+  // where pipelined calls pay: calls below 2^29 bins by default, any length on request, never when off
   q.pipelined = true;
-  q.n = 48000; CHECK(pipeline_pays(q, 1) && pipeline_pays(q, 2) && !pipeline_pays(q, 0), "north star: one round, pipelined by default");
-  q.n = 90000; CHECK(pipeline_pays(q, 1), "between one and two rounds a call takes one round: pipelined");
-  q.n = 1000000; CHECK(!pipeline_pays(q, 1) && pipeline_pays(q, 2), "two rounds fill the chip: one stream by default");
-  q.n = 48000; q.channels = 64; CHECK(!pipeline_pays(q, 1), "one GPU's share of configs[4]: 512 workgroups");
+  q.n = 48000; CHECK(pipeline_pays(q, 1) && pipeline_pays(q, 2) && !pipeline_pays(q, 0), "north star: pipelined by default");
+  q.n = 131072; CHECK(pipeline_pays(q, 1), "n = 131072 gains 11 %%: pipelined");
+  q.n = 1000000; CHECK(!pipeline_pays(q, 1) && pipeline_pays(q, 2), "n = 1e6 is a tie: one stream by default");
+  q.n = 48000; q.channels = 64; CHECK(!pipeline_pays(q, 1), "one GPU's share of configs[4]: 3e9 bins");
   q.channels = 1;
   q.pipelined = false; q.exact = true; q.n = 262144; q.nbins = 4096; c = choose_chunks(q);
   CHECK(c.chunks == 2048 && c.len == 128, "configs[2]: %ld x %ld", c.chunks, c.len);

@@ -769,25 +769,30 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         assert p.get_option("pipelined_calls") == 2
         assert np.array_equal(host, got[1][0][2])
         p.synchronize()
-    # calls of two rounds of the chip and more fill it by themselves: by default (1) they stay on one stream (round 6: n = 1e6 into two equally
-    # placed matrices 84.5 % of the HBM peak against 81.7 % pipelined), on request (2) calls of any length are pipelined; same results
-    ml, nl = 256, 120000
-    xl3 = [noise(nl, seed=90 + i) for i in range(3)]
-    long_res = {}
-    for pipe in (1, 2):
-        with SDFT(ml, "hann", 1.0, "f32f64") as p:
-            p.set_option("async", 1)
-            p.set_option("pipeline", pipe)
-            xd = [torch.from_numpy(x).cuda() for x in xl3]
-            outs = [torch.empty((nl, ml), dtype=torch.complex128, device="cuda") for _ in range(3)]
-            for i in range(3):
-                p.sdft(xd[i], outs[i])
-            p.synchronize()
-            assert p.get_option("last_chunks") > 256 or pipe == 2
-            assert p.get_option("pipelined_calls") == (2 if pipe == 2 else 0), (pipe, p.get_option("last_chunks"))
-            long_res[pipe] = [o.cpu().numpy() for o in outs]
-    for a, b in zip(long_res[1], long_res[2]):
-        assert rel(a, b) <= 1e-12
+    # long calls amortise what pipelining hides: from 2^29 bins per call on they stay on one stream by default (1) (round 6: n = 1e6 is a tie, shorter
+    # calls gain 6-12 %), on request (2) calls of any length are pipelined; same results
+    ml, nl = 1024, 540000
+    free, _ = torch.cuda.mem_get_info()
+    if free > 3 * nl * ml * 16:
+        xl3 = [noise(nl, seed=90 + i) for i in range(3)]
+        long_res = {}
+        for pipe in (1, 2):
+            with SDFT(ml, "hann", 1.0, "f32f64") as p:
+                p.set_option("async", 1)
+                p.set_option("pipeline", pipe)
+                xd = [torch.from_numpy(x).cuda() for x in xl3]
+                outs = [torch.empty((nl, ml), dtype=torch.complex128, device="cuda") for _ in range(2)]
+                sums = []
+                for i in range(3):
+                    p.sdft(xd[i], outs[i & 1])
+                    if i >= 1:
+                        p.synchronize()
+                        sums.append(outs[i & 1][::997].cpu().numpy().copy())
+                p.synchronize()
+                assert p.get_option("pipelined_calls") == (1 if pipe == 2 else 0), (pipe, p.get_option("pipelined_calls"))
+                long_res[pipe] = sums
+        for a, b in zip(long_res[1], long_res[2]):
+            assert rel(a, b) <= 1e-12
     # a batched plan (one state workgroup per channel), a size that is not a power of two (the mixed-radix fold)
     for mm, ch in ((512, 3), (500, 2)):
         xb = [noise(ch * 9000, seed=80 + i).reshape(ch, 9000) for i in range(4)]
