@@ -15,6 +15,16 @@ for src, dst in (("bench_n1e6_m1024.json", "r06_bench_n1e6_m1024.json"), ("bench
         shutil.copy(hits[0], os.path.join(P, dst))
     else:
         print("missing:", src)
+# a header for the pipelined calls' A/B
+pc = os.path.join(P, "r06_pipelined_calls.txt")
+if os.path.exists(pc):
+    text = open(pc).read()
+    if not text.startswith("Asynchronous"):
+        open(pc, "w").write("Asynchronous sdft_sdft_n calls through the raw C-ABI into TWO matrices in turn, both placed by sdft_hip_malloc_matrix_in_arena (equal footing), option pipeline\n"
+                            "= 0 (one stream) / 1 (default: calls below 2^29 bins) / 2 (any length), interleaved in one process, four rounds, 200 calls each (20 at n = 1e6) after 6\n"
+                            "warm-up calls (scripts/pipeline_ab.py, the round's session); microseconds per call = fraction of the 8 TB/s HBM peak by the algorithmic bytes.\n"
+                            "Pipelining hides a fixed 10-40 us per call (launch gap, prologue of the self-carried chunks, ragged end): +12 % at n = 24 000, +9 % at 48 000, +7 % at 90 000,\n"
+                            "+12 % at 131 072, a tie at 1e6 -- where the default (1) therefore stays on one stream.\n" + text)
 # the share of the placement probes in the GPU time of a whole bench run (all side measurements)
 full = os.path.join(P, "r06_bench_all_side_measurements_kernel_stats.csv")
 if os.path.exists(full):

@@ -789,7 +789,7 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
                         p.synchronize()
                         sums.append(outs[i & 1][::997].cpu().numpy().copy())
                 p.synchronize()
-                assert p.get_option("pipelined_calls") == (1 if pipe == 2 else 0), (pipe, p.get_option("pipelined_calls"))
+                assert p.get_option("pipelined_calls") == (2 if pipe == 2 else 0), (pipe, p.get_option("pipelined_calls"))
                 long_res[pipe] = sums
         for a, b in zip(long_res[1], long_res[2]):
             assert rel(a, b) <= 1e-12
