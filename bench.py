@@ -235,6 +235,20 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
         w = (time.perf_counter() - t0) / (total // hop)
         p.synchronize()
     res["us_per_hop_resident_sync"] = round(w * 1e6, 1)
+    # ... and both from a C loop (sdft_hip_time_hops: the calls as a C host makes them, without the interpreter's microsecond per call)
+    try:
+        hops = total // hop
+        p.synchronize()
+        tc = p.api.time_hops(p._p, hops, hop, C.c_void_p(xs), C.c_void_p(ds), C.c_void_p(ys))
+        tc = p.api.time_hops(p._p, hops, hop, C.c_void_p(xs), C.c_void_p(ds), C.c_void_p(ys))
+        res["us_per_hop_resident_sync_c_loop"] = round(tc / hops * 1e6, 1)
+        p.set_option("resident", 0)
+        tc = p.api.time_hops(p._p, hops, hop, C.c_void_p(xs), C.c_void_p(ds), C.c_void_p(ys))
+        tc = p.api.time_hops(p._p, hops, hop, C.c_void_p(xs), C.c_void_p(ds), C.c_void_p(ys))
+        res["us_per_hop_sync_c_loop"] = round(tc / hops * 1e6, 1)
+        p.set_option("resident", 1)
+    except Exception as e:
+        res["c_loop_error"] = str(e)[:100]
     res["resident"] = {"calls": int(p.get_option("resident_calls")), "launches": int(p.get_option("resident_launches")), "missed": int(p.get_option("resident_missed"))}
     p.set_option("resident", 0)
     # the fused entry point: one call and one launch per hop (process_hop_kernel: folded form, tiles combined in the kernel)

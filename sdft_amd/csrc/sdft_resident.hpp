@@ -6,7 +6,7 @@
 // together (profiles/r05_hop_time_parts.txt).  With option "resident" = 1 the first such call starts ONE kernel of kResidentBlocks small
 // workgroups that stays on the chip and serves the calls that follow: the host writes a call into one cache line of pinned memory (pointers,
 // length, cursor, state slots; the doorbell -- a sequence number -- last), workgroup 0 polls that line over PCIe (one 64-byte read per poll),
-// copies it to device memory and publishes its number there; the other workgroups poll the device word.  The work of a call is the body of
+// copies it to device memory with one 64-byte store (two slots, by the call's number); the other workgroups poll their slot there.  The work of a call is the body of
 // forward_hop2_kernel (analysis: every (tile of bins, time part) one workgroup) or of inverse_row_kernel (synthesis: a wave per row) -- the
 // same device functions, bit for bit the same results -- and completion is the kernels' own completion word in pinned memory.
 // What orders a call after the one before it: every workgroup ends a call with an agent-scope release (the ticket of the completion word)
@@ -36,7 +36,7 @@ struct __attribute__((aligned(64))) ResidentCall
   unsigned n, cursor0, parts, part_len;
   unsigned slots;                                          // bits 0-1: the state slot the call reads, bits 2-3: the delay-line slot (it writes slot ^ 1)
   unsigned op, flag_seq, blocks;                           // blocks: workgroups (analysis) / rows (synthesis) that report to the completion word
-  unsigned check;                                          // ~seq: a line whose words do not belong together is polled again
+  unsigned check;                                          // ~(seq ^ xor of words 0..13): a line whose words do not belong together is polled again
   unsigned seq;                                            // the doorbell
 };
 static_assert(sizeof(ResidentCall) == 64, "one cache line");
@@ -50,7 +50,6 @@ template <typename TD, typename FD> struct ResidentArgs
   TD* hist[4];
   const unsigned* host_call;                               // the line the host writes (pinned, mapped), as 16 words
   unsigned* dev_call;                                      // two device copies of it (by call number & 1), published by workgroup 0
-  unsigned* dev_seq;                                       // device word: the number of the latest call in dev_call
   unsigned* done_flag;                                     // completion word (pinned) and its ticket counter (device): DoneSignal
   unsigned* done_count;
   unsigned* exit_word;                                     // pinned: the last call served, written when the kernel leaves
@@ -71,6 +70,19 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
   {
     if (wave == 0)
     {
+      // xor of the line's words 0..13: part of the check word, so that a line whose words do not belong together never passes for a call
+      auto line_ok = [&](unsigned word, unsigned want_seq, bool exact) -> bool
+      {
+        unsigned f = lane < 14 ? word : 0u;
+        f ^= (unsigned)__shfl_xor((int)f, 8, 16); f ^= (unsigned)__shfl_xor((int)f, 4, 16);
+        f ^= (unsigned)__shfl_xor((int)f, 2, 16); f ^= (unsigned)__shfl_xor((int)f, 1, 16);
+        const unsigned fold = (unsigned)__builtin_amdgcn_readlane((int)f, 0);
+        const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
+        if (chk != ~(seq ^ fold)) return false;
+        // exact: this very call; else this call or a later one of the same slot (a workgroup that fell behind had no work in the ones it skips:
+        // the host rings only after every workgroup with work has reported)
+        return exact ? seq == want_seq : ((int)(seq - want_seq) >= 0 && ((seq - want_seq) & 1u) == 0u);
+      };
       if (blockIdx.x == 0)
       {
         // ---- workgroup 0: the host's line, over PCIe ----
@@ -80,38 +92,28 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
         for (;;)
         {
           word = lane < 16 ? __hip_atomic_load(const_cast<unsigned*>(ra.host_call) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-          const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
-          if (seq == next && chk == ~seq) break;
+          if (line_ok(word, next, true)) break;
           if (wall_clock64() - t0 > (unsigned long long)ra.idle_ticks) { quit = true; break; }
         }
-        if (quit) word = lane == 11 ? (unsigned)RES_QUIT : (lane == 15 ? next : (lane == 14 ? ~next : 0u));
+        if (quit) word = lane == 11 ? (unsigned)RES_QUIT : (lane == 15 ? next : (lane == 14 ? ~(next ^ (unsigned)RES_QUIT) : 0u));
         else served = next;
-        unsigned* slot = ra.dev_call + 16u * (next & 1u);
-        if (lane < 16) { __hip_atomic_store(slot + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cur[lane] = word; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store(ra.dev_seq, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // one 64-byte store publishes the call to the other workgroups (the line carries its own number and check word: nothing else to order)
+        if (lane < 16) { __hip_atomic_store(ra.dev_call + 16u * (next & 1u) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cur[lane] = word; }
       }
       else
       {
-        // ---- the others: the device word; always the LATEST call (a workgroup that fell behind had no work in the ones it skips:
-        // the host rings only after every workgroup with work has reported) ----
-        const unsigned long long t0 = wall_clock64();
-        unsigned word = 0;
+        // ---- the others: the call's slot in device memory, one 64-byte read per poll ----
         // (relaxed polls: an acquire per poll would invalidate the XCD's L2 under the workgroups that are working; the one acquire a call
         // needs is made below, by the workgroups that have work in it)
+        const unsigned long long t0 = wall_clock64();
+        unsigned word = 0;
         for (;;)
         {
-          const unsigned s = __hip_atomic_load(ra.dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((int)(s - next) >= 0)
-          {
-            word = lane < 16 ? __hip_atomic_load(ra.dev_call + 16u * (s & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            const unsigned seq = (unsigned)__builtin_amdgcn_readlane((int)word, 15), chk = (unsigned)__builtin_amdgcn_readlane((int)word, 14);
-            const unsigned s2 = __hip_atomic_load(ra.dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((s2 == s || s2 == s + 1u) && seq == s && chk == ~s) break;       // (two publishes since: the copy may be the newer call's: again)
-          }
-          else __builtin_amdgcn_s_sleep(1);
+          word = lane < 16 ? __hip_atomic_load(ra.dev_call + 16u * (next & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+          if (line_ok(word, next, false)) break;
           // (four idle periods: workgroup 0 has long said QUIT if it lives)
           if (wall_clock64() - t0 > 4ull * (unsigned long long)ra.idle_ticks) { word = lane == 11 ? (unsigned)RES_QUIT : 0u; break; }
+          __builtin_amdgcn_s_sleep(1);
         }
         if (lane < 16) cur[lane] = word;
       }
