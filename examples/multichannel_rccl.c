@@ -65,7 +65,7 @@ int main(int argc, char** argv)
 #if !defined(SDFT_NO_RCCL)
   ncclComm_t comm[MAXDEV];
 #endif
-  float *x[MAXDEV], *flag[MAXDEV]; sdft_fdx_t* dfts[MAXDEV];
+  float *x[MAXDEV], *flag[MAXDEV]; sdft_fdx_t* dfts[MAXDEV]; int placed[MAXDEV];
   int devs[MAXDEV];
   float* host = (float*)malloc(per_gpu * n * sizeof(float));
 
@@ -79,7 +79,16 @@ int main(int argc, char** argv)
     sdft_hip_set_stream(plan[d], stream[d]);
     sdft_hip_set_option(plan[d], "async", 1);
     CHECK_HIP(hipMalloc((void**)&x[d], per_gpu * n * sizeof(float)));
-    CHECK_HIP(hipMalloc((void**)&dfts[d], per_gpu * n * m * sizeof(sdft_fdx_t)));
+    /* the matrix: placed by the library inside matrix + 64 GiB (the kind of device memory decides how fast it can be written: sdft_hip.h);
+       a GPU without that much free memory takes a plain allocation */
+    {
+      const size_t bytes = per_gpu * n * m * sizeof(sdft_fdx_t);
+      double gbs = 0.0;
+      dfts[d] = (sdft_fdx_t*)sdft_hip_malloc_matrix_in_arena(bytes, bytes + ((size_t)64 << 30), &gbs);
+      placed[d] = dfts[d] != NULL;
+      if (!placed[d]) { sdft_hip_clear_error(); CHECK_HIP(hipMalloc((void**)&dfts[d], bytes)); }
+      else fprintf(stderr, "device %d: matrix placed, store-only probe %.0f GB/s\n", d, gbs);
+    }
     CHECK_HIP(hipMalloc((void**)&flag[d], sizeof(float)));
     CHECK_HIP(hipMemset(flag[d], 0, sizeof(float)));
     for (size_t c = 0; c < per_gpu; ++c) sweep(host + c * n, n, (size_t)d * per_gpu + c, channels);
@@ -133,7 +142,8 @@ int main(int argc, char** argv)
 #if !defined(SDFT_NO_RCCL)
     ncclCommDestroy(comm[d]);
 #endif
-    (void)hipFree(x[d]); (void)hipFree(dfts[d]); (void)hipFree(flag[d]);
+    (void)hipFree(x[d]); (void)hipFree(flag[d]);
+    if (placed[d]) (void)sdft_hip_free_matrix(dfts[d]); else (void)hipFree(dfts[d]);
     (void)hipStreamDestroy(stream[d]);
   }
   free(y); free(host);

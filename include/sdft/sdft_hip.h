@@ -60,7 +60,7 @@ void*       sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs);
    sdft_hip_free_matrix(window) -- NOT hipFree: the window is not the start of the allocation.  Two full-size probes check the result (the
    window, and a window at the allocation's start = what a plain hipMalloc would have been) and the better one is returned; only an arena with no
    change of kind within reach is searched window by window (every 4 GiB, at most 8).  *gbs (may be NULL) = the window's probe rate.  NULL on failure; free: 0, or -1 for a pointer this call did
-   not return.  sdft_hip_matrix_placement tells how a window was placed. */
+   not return.  Matrices below 64 MiB are not probed and get an allocation of their own size.  sdft_hip_matrix_placement tells how a window was placed. */
 typedef struct
 {
   size_t arena_bytes;      /* the allocation that holds the window */

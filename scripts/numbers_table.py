@@ -39,8 +39,8 @@ rows = [
     ("configs[2]: m = 4096, Blackman, FD float, n = 262 144, bit-identical", "analysis %s ms = %s of peak, synthesis %s, round trip %s"
      % (c("configs.config2.forward_ms_wall"), c("configs.config2.forward_frac_of_peak"), c("configs.config2.inverse_frac_of_peak"), c("configs.config2.round_trip_frac_of_peak"))),
     ("configs[3]: 64 channels × 48 000 × 2048 (100.7 GB)", "analysis %s of peak, synthesis %s" % (c("configs.config3.forward_frac_of_peak"), c("configs.config3.inverse_frac_of_peak"))),
-    ("the reference's hop loop (m = 1000, hop = 100), device pointers", "two synchronous calls %s µs per hop, with `resident` = 1 %s µs, asynchronous %s µs; the fused call %s / %s µs; the reference on one host core %s µs"
-     % (c("hop100_m1000.us_per_hop_sync"), c("hop100_m1000.us_per_hop_resident_sync"), c("hop100_m1000.us_per_hop_async"), c("hop100_m1000.us_per_hop_process_n_sync"), c("hop100_m1000.us_per_hop_process_n_async"), c("hop100_m1000.cpu_reference.us_per_hop"))),
+    ("the reference's hop loop (m = 1000, hop = 100), device pointers", "two synchronous calls %s µs per hop (%s from a C loop), with `resident` = 1 %s µs (%s), asynchronous %s µs; the fused call %s / %s µs; the reference on one host core %s µs"
+     % (c("hop100_m1000.us_per_hop_sync"), c("hop100_m1000.us_per_hop_sync_c_loop"), c("hop100_m1000.us_per_hop_resident_sync"), c("hop100_m1000.us_per_hop_resident_sync_c_loop"), c("hop100_m1000.us_per_hop_async"), c("hop100_m1000.us_per_hop_process_n_sync"), c("hop100_m1000.us_per_hop_process_n_async"), c("hop100_m1000.cpu_reference.us_per_hop"))),
     ("… on the reference driver's malloc'ed buffers", "%s µs per hop by default (pinned pieces of the plan), %s with the runtime's copy, %s registered in place; PCIe floor %s"
      % (c("hop100_m1000.us_per_hop_host_pointers"), c("hop100_m1000.us_per_hop_host_pointers_runtime_copy"), c("hop100_m1000.us_per_hop_host_pointers_registered"), c("hop100_m1000.host_pointers_pcie_floor_us"))),
     ("the reference's bench shape (m = 1000, 44 100 samples, TD = FD = double)", "`sdft` %s µs, `isdft` %s µs (the reference on one core: %s / %s µs)"

@@ -537,6 +537,7 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
   using namespace sdfthip;
   if (gbs) *gbs = 0.0;
   if (bytes == 0 || arena_bytes < bytes) { set_error("sdft_hip_malloc_matrix_in_arena", "the arena is smaller than the matrix"); return nullptr; }
+  if (bytes < ((size_t)64 << 20)) arena_bytes = bytes;     // (nothing is probed below 64 MiB: no arena either)
   char* base = nullptr;
   if (hipMalloc((void**)&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_malloc_matrix_in_arena", "out of device memory"); return nullptr; }
   sdft_hip_placement_t info;
