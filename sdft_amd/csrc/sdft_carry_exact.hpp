@@ -547,14 +547,20 @@ template <typename FD> __global__ __launch_bounds__(kWave) void relay_gate_kerne
 // the forward launches of earlier segments -- whose 16-wave workgroups cannot share a CU with it -- keep three quarters
 // of the chip instead of half (config 3: 128 relays).  FD float only: 12 waves of <= 168 registers fit a CU, FD double's
 // 185 registers allow 8.
-template <typename FD> struct relay_limits { static constexpr int waves = sizeof(FD) == 4 ? 12 : 8; static constexpr int groups = sizeof(FD) == 4 ? 2 : 1; };
+// Round 6: blocks of up to 64 steps keep the products in 64 registers, so SIXTEEN waves fit a CU (4 per SIMD: two relays of eight waves, test
+// hook "relay_groups" = 2) -- the form the round-5 review asked for; measured in profiles/r06_relay_on_64_cus.txt.
+template <typename FD, int L = 128> struct relay_limits
+{
+  static constexpr int waves = sizeof(FD) == 4 ? (L <= 64 ? 16 : 12) : 8;
+  static constexpr int groups = sizeof(FD) == 4 ? 2 : 1;
+};
 template <typename FD, int L, bool STATS = false>
-__global__ __launch_bounds__(kWave * relay_limits<FD>::waves) void carry_relay_kernel(ChainArgs<FD> a)
+__global__ __launch_bounds__((kWave * relay_limits<FD, L>::waves)) void carry_relay_kernel(ChainArgs<FD> a)
 {
   constexpr int DV = (L + 15) / 16;                        // difference vectors per block (16 steps each)
   using token = RelayToken<FD>;
   using raw_t = typename token::raw_t;
-  __shared__ __align__(16) raw_t mails[relay_limits<FD>::groups][kWave];
+  __shared__ __align__(16) raw_t mails[relay_limits<FD, L>::groups][kWave];
   __shared__ unsigned aborted;
 
   const int lane = threadIdx.x & (kWave - 1);

@@ -450,15 +450,17 @@ class Plan
   // relays (32 bins of a channel each), waves per relay.  (Two relays per workgroup -- the kernel has the form -- were measured
   // slower, 12 waves of products and two chains on one CU contend for issue: config 3 shape, 1.5 against 1.05 ms; the option is gone)
   static unsigned relay_waves_default() { return 8u; }
-  unsigned relay_waves() const
+  long opt_relay_groups = 1;     // test hook: relays per workgroup (2: half as many CUs; FD float only)
+  template <int L> unsigned relay_groups() const { return (unsigned)std::max(1L, std::min<long>(relay_limits<FD, L>::groups, opt_relay_groups)); }
+  template <int L> unsigned relay_waves() const
   {
-    const long mx = relay_limits<FD>::waves;
+    const long mx = relay_limits<FD, L>::waves / (long)relay_groups<L>();
     return (unsigned)std::max(1L, std::min(mx, opt_relay_waves > 0 ? opt_relay_waves : (long)relay_waves_default()));
   }
-  static unsigned relay_groups(unsigned) { return 1u; }
+  unsigned relay_groups_of(unsigned L) const { return L <= 64 ? relay_groups<64>() : relay_groups<128>(); }
   template <int L> bool launch_relay(ChainArgs<FD> cc, unsigned relays, hipStream_t on)
   {
-    const unsigned waves = relay_waves(), groups = relay_groups(relays);
+    const unsigned waves = relay_waves<L>(), groups = relay_groups<L>();
     const unsigned blocks = (relays + groups - 1) / groups;
     cc.P = waves; cc.chunks_channels = (unsigned)channels;
     if constexpr (L * sizeof(FD) == 512)
@@ -764,7 +766,7 @@ class Plan
         if (flow)
         {
           // the forward launch may go once every relay workgroup of this launch is resident
-          const unsigned relays = cblocks, groups = relay_groups(relays);
+          const unsigned relays = cblocks, groups = relay_groups_of(cL);
           started_target += (relays + groups - 1) / groups;
           hipLaunchKernelGGL((relay_gate_kernel<FD>), dim3(1), dim3(kWave), 0, stream, (const unsigned*)d_started, started_target);
           SDFT_TRY(hipGetLastError());
