@@ -2,7 +2,7 @@
 <value · file> (tests/test_docs.py).  python scripts/numbers_table.py > /tmp/table.md"""
 import json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = "profiles/r06_bench_n1e6_m1024.json"
+F = "profiles/r06.json"          # (a copy of profiles/r06_bench_n1e6_m1024.json under a short name: the tables cite it forty times)
 b = json.loads(open(os.path.join(R, F)).read().strip().splitlines()[-1])
 
 
