@@ -556,7 +556,11 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
       return ms > 0.0 ? (double)(rows * 16384) / (ms * 1e-3) / 1e9 : 0.0;
     };
     // ---- where does the kind of memory change?  (parts of 1 GiB; a change shows as >= 1.1 x the rate of two parts of the start's kind) ----
-    const size_t part = GiB, step = 16 * GiB;
+    // (parts of 1 GiB -- of what the arena has left beyond the last place probed when that is less, down to 256 MiB: the contrast shows from there on.
+    // A small matrix' arena ends just beyond 64 GiB, where round 5's sessions had their first change of kind)
+    const size_t step = 16 * GiB;
+    const size_t tail = arena_bytes % step;                              // what lies beyond the last multiple of 16 GiB
+    const size_t part = ((tail >= ((size_t)256 << 20) && tail < GiB ? tail : GiB) >> 14) << 14;
     size_t found = 0;                                                    // offset of the change the window is centred on (0: none)
     if (arena_bytes >= 3 * part && room >= GiB)
     {
