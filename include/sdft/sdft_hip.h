@@ -253,7 +253,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    TEST HOOKS.  Every other fork of the host logic is decided by the library alone in libsdft_hip.so.  The same sources built with
    -DSDFT_HIP_TEST_HOOKS (libsdft_hip_hooks.so, built beside the product by `python -m sdft_amd.build`; no host links it) accept the keys that force
    those forks, so that the tests can run every route against the reference and the probes under scripts/ can measure them:
-   "rows_kernel", "row_slots_max", "interior", "fused", "taper", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves", "inverse_verify",
+   "rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves", "inverse_verify",
    "relay_flow", "relay_groups", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams" (sdft_capi.inc names what each selects);
    get_option "test_hooks" = 1 in that build.
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",

@@ -11,7 +11,7 @@ x = torch.from_numpy(sine_sweep(n)).cuda()
 plain = torch.empty((n, m), dtype=torch.complex128, device="cuda")
 placed = capi.PlacedMatrix((n, m), torch.complex128)
 print("placed matrix:", placed.info, flush=True)
-variants = [("default (tapered chunks)", {}), ("chunks of one length", {"taper": 0}), ("chunk=192 (250 chunks)", {"chunk": 192}), ("chunk=96 (500)", {"chunk": 96}), ("chunk=376 (128)", {"chunk": 376}),
+variants = [("default", {}), ("chunk=192 (250 chunks)", {"chunk": 192}), ("chunk=96 (500)", {"chunk": 96}), ("chunk=376 (128)", {"chunk": 376}),
             ("chunk=128 (375)", {"chunk": 128}), ("chunk=64 (750)", {"chunk": 64}), ("pre-pass", {"self_carry": 0})]
 b = n * (m * 16 + 4)
 for rnd in range(2):

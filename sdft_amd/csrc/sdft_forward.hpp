@@ -99,10 +99,6 @@ template <typename FD> struct ForwardArgs
   unsigned nbins, chunks, chunk_len, tiles, interior_lanes, cursor0;
   unsigned chunk0, launch_chunks;   // this launch covers time chunks [chunk0, chunk0 + launch_chunks)
   unsigned chunk_shift;             // chunk j > 0 starts at sample j*chunk_len - chunk_shift (exact carries, ring form; else 0)
-  // Tapered chunks (self-carried form, one round of the chip; round 6): the prologue of a self-carried chunk grows with the samples before it (the fold),
-  // so chunks of one length end one after the other -- the first taper_a chunks are taper_d rows longer, those beyond chunk taper_b as much shorter, and
-  // all workgroups end together.  taper_d = 0: chunks of one length.  chunk_begin() is where chunk j starts.
-  unsigned taper_a, taper_b, taper_d;
   int vec_store;              // BPL==2: 16-byte stores allowed (even N, 16-byte aligned base)
   FD wscale;                  // weight (or weight*0.25 for Hann)
   DoneSignal done;            // row-group kernels of short synchronous calls: total = workgroups of the launch
@@ -119,16 +115,6 @@ template <typename FD> struct ForwardArgs
   unsigned xcd_map;           // 0, or the launch's number of (channel, chunk) workgroups
   unsigned inv_chunks, inv_channels;   // floor(2^32 / launch_chunks) + 1 and floor(2^32 / ready_channels) + 1 (0 for a divisor of 1): flow_position
 };
-template <typename FD> SDFT_D size_t chunk_begin(const ForwardArgs<FD>& a, unsigned j)
-{
-  size_t t = (size_t)j * a.chunk_len;
-  if (a.taper_d)
-  {
-    t += (size_t)a.taper_d * (j < a.taper_a ? j : a.taper_a);
-    if (j > a.taper_b) t -= (size_t)a.taper_d * (j - a.taper_b);
-  }
-  return t;
-}
 // the b-th workgroup's position in the launch's (channel, chunk) sequence: a bijection of [0, total) for any total
 SDFT_D unsigned xcd_contiguous(unsigned b, unsigned total)
 {

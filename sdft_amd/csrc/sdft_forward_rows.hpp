@@ -95,8 +95,8 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void forward_rows_kernel(Forw
 
   const long nbins = (long)a.nbins;
   const unsigned span = 2u * a.nbins, maxc = span - 1u;
-  const size_t t0 = chunk ? chunk_begin(a, chunk) - a.chunk_shift : 0;
-  const size_t tn = chunk_begin(a, chunk + 1u) - a.chunk_shift;
+  const size_t t0 = chunk ? (size_t)chunk * a.chunk_len - a.chunk_shift : 0;
+  const size_t tn = (size_t)(chunk + 1) * a.chunk_len - a.chunk_shift;
   const size_t t1 = tn < a.n ? tn : a.n;
   unsigned c = (unsigned)(((size_t)a.cursor0 + t0) % span);
 

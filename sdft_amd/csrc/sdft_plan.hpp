@@ -176,7 +176,6 @@ class Plan
   long opt_exact_inverse = 1;    // inverse sums bins in the reference's order (bit-identical)
   long opt_row_slots_max = 2;    // largest slots-per-lane the row-group kernel may use (1 = rows <= 1024*BPL only)
   long opt_fused = 1;            // fused multiply-add arithmetic in the chunk-parallel FD double path
-  long opt_taper = 1, last_taper = 0;   // self-carried calls of one round: chunks of three lengths (logic::chunk_taper); test hook "taper" = 0: one length
   long last_fused = 0;
   long opt_fft_carry = 1;        // FFT form of the chunk partial sums when 2N is a power of two
   long opt_hop_kernel = 1;       // single-chunk calls: fused delta + forward launch (forward_hop_kernel)
@@ -1088,12 +1087,6 @@ class Plan
     fa.vec_store = 0;
     fa.wscale = (window == WIN_HANN) ? (FD)(tab.aweight * (FD)(0.25)) : tab.aweight;   // :371
     fa.done.flag = nullptr; fa.done.count = nullptr; fa.done.seq = 0; fa.done.total = 0;
-    {
-      // (the row-group kernel only: the fused kernel cuts time itself; not with a forced chunk length, which the tests use to pin a geometry)
-      const logic::Taper tp = logic::chunk_taper(n, nb, sizeof(fdx), chunks, len, (long)channels, compute_units, !fuse && opt_chunk <= 0 && opt_taper != 0);
-      fa.taper_a = tp.a; fa.taper_b = tp.b; fa.taper_d = tp.d;
-      last_taper = tp.d;
-    }
     if (!grid_fits(channels * (size_t)chunks)) return false;
     if (channels * n * nb <= (fuse ? (size_t)1 << 26 : kFlagMax)) fa.done = arm_flag((unsigned)(channels * (size_t)chunks));
     const unsigned blocks = (unsigned)(channels * (size_t)chunks);

@@ -390,29 +390,6 @@ struct TunerTable
   void reset_all() { for (int i = 0; i < kSlots; ++i) { slot[i].reset(0, 1); stamp[i] = 0; } clock = 0; }
 };
 
-// ---- self-carried chunks of one round: a taper -----------------------------------------------------------------------------------------
-// A self-carried workgroup folds every sample before its chunk before it writes its first row (profiles/r06_north_star_stamps.txt: 0.21 ns per sample;
-// the last chunk of the north star's call spends 7.5 % of its time there, the first nothing), and a row costs it 16 * nbins bytes at the 28 GB/s a CU gets
-// of the store stream: chunks of one length end one after the other.  Three lengths -- the first third of the chunks d rows longer, the last third d
-// rows shorter -- let them end together; d in whole lockstep groups of 8 rows, 0 where the difference would be less than a group and a half.
-struct Taper { unsigned a = 0, b = 0, d = 0; };
-inline Taper chunk_taper(size_t n, size_t nbins, size_t fdx_bytes, long chunks, long len, long channels, int compute_units, bool enabled)
-{
-  Taper t;
-  if (!enabled || chunks < 6 || chunks * std::max(channels, 1L) > (long)compute_units || nbins == 0) return t;      // one round of the chip only
-  const double fold_ns = 0.21 * (double)n;                                  // what the last chunk folds more than the first
-  const double row_ns = (double)(nbins * fdx_bytes) / 28.0;                 // bytes / (28 GB/s) in ns
-  const double rows = fold_ns / row_ns;                                     // first chunk - last chunk, in rows
-  const unsigned d = 8u * (unsigned)((rows + 4.0) / 16.0);
-  if (d == 0 || (long)d * 2 >= len) return t;
-  // the last chunk starts d rows later than (chunks - 1) * len: what is left of it has to be worth a workgroup
-  const size_t last_begin = (size_t)(chunks - 1) * (size_t)len;
-  if (n <= last_begin + 2 * (size_t)d) return t;
-  const unsigned third = (unsigned)(chunks / 3);
-  t.a = third; t.b = (unsigned)chunks - third; t.d = d;
-  return t;
-}
-
 // ---- pipelined analyses: where they pay ------------------------------------------------------------------------------------------
 // The next call's workgroups fill what a launch leaves idle -- the launch gap, the prologue of the self-carried chunks, the ragged end: a fixed 20-30 us
 // per call.  Interleaved in one process on two equally placed matrices (profiles/r06_pipelined_calls.txt): n = 24 000 +12 %, n = 48 000 +9 % (82 against

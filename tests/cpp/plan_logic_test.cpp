@@ -81,24 +81,6 @@ static void test_chunks()
   CHECK(c.chunks > 256 && c.chunks <= 512, "two rounds at n = 1e6: %ld", c.chunks);
   q.pipelined = true; q.n = 48000; c = choose_chunks(q);
   CHECK(c.chunks == 300 && c.len == 160, "pipelined calls: about 300 chunks of >= 160 rows: %ld x %ld", c.chunks, c.len);
-  // tapered chunks of a self-carried call of one round: the north star's 250 x 192 become 83 x 200, 84 x 192, 83 x 184
-  {
-    const Taper tp = chunk_taper(48000, 1024, 16, 250, 192, 1, 256, true);
-    CHECK(tp.d == 8 && tp.a == 83 && tp.b == 167, "north star: d %u a %u b %u", tp.d, tp.a, tp.b);
-    size_t t = 0, covered = 0;
-    for (unsigned j = 0; j < 250; ++j)
-    {
-      size_t b0 = (size_t)j * 192 + (size_t)tp.d * (j < tp.a ? j : tp.a); if (j > tp.b) b0 -= (size_t)tp.d * (j - tp.b);
-      size_t b1 = (size_t)(j + 1) * 192 + (size_t)tp.d * (j + 1 < tp.a ? j + 1 : tp.a); if (j + 1 > tp.b) b1 -= (size_t)tp.d * (j + 1 - tp.b);
-      CHECK(b0 == t && b1 > b0 && (b1 - b0) % 8 == 0, "chunk %u: [%zu, %zu)", j, b0, b1);
-      t = b1; covered += b1 - b0;
-    }
-    CHECK(covered == 48000, "the tapered chunks cover the call exactly: %zu", covered);
-    CHECK(chunk_taper(24000, 1024, 16, 188, 128, 1, 256, true).d == 0, "n = 24000: less than a group and a half: no taper");
-    CHECK(chunk_taper(90000, 1024, 16, 256, 352, 1, 256, true).d == 16, "n = 90000: two groups");
-    CHECK(chunk_taper(1000000, 1024, 16, 511, 1960, 1, 256, true).d == 0 && chunk_taper(48000, 1024, 16, 8, 6000, 64, 256, true).d == 0, "more than one round: none");
-    CHECK(chunk_taper(48000, 1024, 16, 250, 192, 1, 256, false).d == 0 && chunk_taper(47820, 1024, 16, 250, 192, 1, 256, true).d == 0, "switched off; a last chunk too short to lose d rows");
-  }
   // where pipelined calls pay: calls below 2^29 bins by default, any length on request, never when off
   q.pipelined = true;
   q.n = 48000; CHECK(pipeline_pays(q, 1) && pipeline_pays(q, 2) && !pipeline_pays(q, 0), "north star: pipelined by default");

@@ -752,32 +752,3 @@ def test_synthesis_by_whole_rows_in_step_keeps_the_bits(m, n, channels):
         q.set_option("inverse_step", 1)
         q.isdft(q.sdft(torch.from_numpy(noise(2000, seed=5)).cuda()))
         assert q.get_option("last_inverse_form") != 3
-
-
-def test_tapered_chunks_of_a_self_carried_call():
-    """Round 6: a self-carried call of one round of the chip (the north star's n = 48000) cuts time into chunks of three lengths -- the first third 8 rows
-    longer, the last third 8 rows shorter -- so that the workgroups, whose prologue grows with the samples before their chunk, end together.  Results do not
-    depend on where the chunks are cut (<= 1e-11 against chunks of one length, the oracle's bar against the reference), the state after the call is the
-    same, ragged lengths and a second call continue correctly; calls of other sizes keep one length."""
-    import torch
-    from sdft_amd.sdft import SDFT
-    m = 1024
-    for n in (48000, 47999, 50001, 90000):
-        x = noise(n + 700, seed=n)
-        ref = O.best(m, "hann", 1.0, "f32f64")
-        want = ref.sdft(x[:n]); want2 = ref.sdft(x[n:])
-        res = {}
-        for taper in (1, 0):
-            with make(m, "hann", 1.0, "f32f64", taper=taper) as p:
-                d = p.sdft(torch.from_numpy(x[:n]).cuda())
-                assert p.get_option("last_self") == 1
-                assert (p.get_option("last_taper") > 0) == (taper == 1), (n, taper, p.get_option("last_taper"), p.get_option("last_chunks"), p.get_option("last_chunk_len"))
-                d2 = p.sdft(x[n:])                                   # a hop-sized... (700 samples: chunk-parallel) call on the state the tapered call left
-                res[taper] = (d.cpu().numpy(), d2, p.state())
-        assert rel_err(res[1][0], want) <= 1e-11 and rel_err(res[1][1], want2) <= 1e-11, n
-        assert rel_err(res[1][0], res[0][0]) <= 1e-11 and rel_err(res[1][1], res[0][1]) <= 1e-11
-        assert res[1][2][3] == res[0][2][3] and rel_err(res[1][2][0], res[0][2][0]) <= 1e-11 and np.array_equal(res[1][2][2], res[0][2][2])
-    with make(m, "hann", 1.0, "f32f64") as p:                      # other sizes: one length
-        for n in (12000, 300000):
-            p.sdft(torch.from_numpy(noise(n, seed=3)).cuda())
-            assert p.get_option("last_taper") == 0, n
