@@ -58,8 +58,10 @@ void*       sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs);
    bytes + 64 GiB has always held a change of kind so far), finds the first change with small two-part store probes (2 GiB written each, steps
    of 16 GiB then bisection: <= 12 ms in all), returns the window centred on it and keeps the whole allocation until
    sdft_hip_free_matrix(window) -- NOT hipFree: the window is not the start of the allocation.  Two full-size probes check the result (the
-   window, and a window at the allocation's start = what a plain hipMalloc would have been) and the better one is returned; only an arena with no
-   change of kind within reach is searched window by window (every 4 GiB, at most 8).  *gbs (may be NULL) = the window's probe rate.  NULL on failure; free: 0, or -1 for a pointer this call did
+   window, and a window at the allocation's start = what a plain hipMalloc would have been) and the better one is returned.  An allocation that
+   holds no change of kind at all (seen in a process that had allocated and freed a lot before) is answered by a second allocation made while the first
+   is held -- other memory by construction -- and the better of the two is kept; an arena too small for the two-part probes (< 3 GiB) is searched window
+   by window (every 4 GiB, at most 8).  *gbs (may be NULL) = the window's probe rate.  NULL on failure; free: 0, or -1 for a pointer this call did
    not return.  Matrices below 64 MiB are not probed and get an allocation of their own size.  sdft_hip_matrix_placement tells how a window was placed. */
 typedef struct
 {
@@ -71,6 +73,7 @@ typedef struct
   double window_gbs;       /* store-only rate of the window, GB/s */
   double start_gbs;        /* ... of a window at the allocation's start */
   double probe_ms;         /* GPU time of all probes */
+  int    arenas_tried;     /* 1; 2 when the first allocation held no change of kind and a second one was made beside it (the better is kept) */
 } sdft_hip_placement_t;
 void*       sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs);
 int         sdft_hip_matrix_placement(const void* window, sdft_hip_placement_t* out);

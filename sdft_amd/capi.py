@@ -82,12 +82,13 @@ class Placement(C.Structure):
     """sdft_hip_placement_t (include/sdft/sdft_hip.h)."""
     _fields_ = [("arena_bytes", C.c_size_t), ("window_offset", C.c_size_t), ("boundary_offset", C.c_size_t),
                 ("pair_probes", C.c_int), ("window_probes", C.c_int),
-                ("window_gbs", C.c_double), ("start_gbs", C.c_double), ("probe_ms", C.c_double)]
+                ("window_gbs", C.c_double), ("start_gbs", C.c_double), ("probe_ms", C.c_double), ("arenas_tried", C.c_int)]
 
     def as_dict(self) -> dict:
         return {"arena_bytes": int(self.arena_bytes), "window_offset": int(self.window_offset), "boundary_offset": int(self.boundary_offset),
                 "pair_probes": int(self.pair_probes), "window_probes": int(self.window_probes),
-                "window_gbs": round(float(self.window_gbs), 1), "start_gbs": round(float(self.start_gbs), 1), "probe_ms": round(float(self.probe_ms), 2)}
+                "window_gbs": round(float(self.window_gbs), 1), "start_gbs": round(float(self.start_gbs), 1), "probe_ms": round(float(self.probe_ms), 2),
+                "arenas_tried": int(self.arenas_tried)}
 
 
 class PlacedMatrix:

@@ -501,6 +501,7 @@ typedef struct
   size_t arena_bytes, window_offset, boundary_offset;
   int    pair_probes, window_probes;
   double window_gbs, start_gbs, probe_ms;
+  int    arenas_tried;
 } sdft_hip_placement_t;
 }
 namespace sdfthip {
@@ -532,15 +533,10 @@ static double pair_rate(char* a, char* b, size_t part_bytes, double* ms_total)
 }
 }  // namespace sdfthip
 
-void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs)
+namespace sdfthip {
+// places a matrix of `bytes` inside the allocation [base, base + arena_bytes): fills `info`, returns the window's offset
+static size_t place_in_arena(char* base, size_t bytes, size_t arena_bytes, sdft_hip_placement_t& info)
 {
-  using namespace sdfthip;
-  if (gbs) *gbs = 0.0;
-  if (bytes == 0 || arena_bytes < bytes) { set_error("sdft_hip_malloc_matrix_in_arena", "the arena is smaller than the matrix"); return nullptr; }
-  if (bytes < ((size_t)64 << 20)) arena_bytes = bytes;     // (nothing is probed below 64 MiB: no arena either)
-  char* base = nullptr;
-  if (hipMalloc((void**)&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_malloc_matrix_in_arena", "out of device memory"); return nullptr; }
-  sdft_hip_placement_t info;
   memset(&info, 0, sizeof info);
   info.arena_bytes = arena_bytes;
   const size_t GiB = (size_t)1 << 30, room = arena_bytes - bytes;         // the window may start anywhere in [0, room]
@@ -562,8 +558,10 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
     const size_t tail = arena_bytes % step;                              // what lies beyond the last multiple of 16 GiB
     const size_t part = ((tail >= ((size_t)256 << 20) && tail < GiB ? tail : GiB) >> 14) << 14;
     size_t found = 0;                                                    // offset of the change the window is centred on (0: none)
+    bool probed = false;                                                 // the arena was large enough for the two-part probes
     if (arena_bytes >= 3 * part && room >= GiB)
     {
+      probed = true;
       const double same = pair_rate(base, base + part, part, &info.probe_ms);
       ++info.pair_probes;
       auto differs = [&](size_t o) { ++info.pair_probes; return same > 0.0 && pair_rate(base, base + o, part, &info.probe_ms) > 1.1 * same; };
@@ -600,9 +598,9 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
         if (r > info.window_gbs) { info.window_gbs = r; off = cand; }
       }
     }
-    if (!found)
+    if (!found && !probed)
     {
-      // no change of kind within reach (a small arena): the search of round 5, a window every 4 GiB, at most 8 of them
+      // an arena too small for the two-part probes: the search of round 5, a window every 4 GiB, at most 8 of them
       const size_t scan = (size_t)4 << 30;
       for (size_t o = scan; o <= room && info.window_probes < 9; o += scan)
       {
@@ -612,6 +610,37 @@ void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* 
     }
   }
   info.window_offset = off;
+  return off;
+}
+}  // namespace sdfthip
+
+void* sdft_hip_malloc_matrix_in_arena(size_t bytes, size_t arena_bytes, double* gbs)
+{
+  using namespace sdfthip;
+  if (gbs) *gbs = 0.0;
+  if (bytes == 0 || arena_bytes < bytes) { set_error("sdft_hip_malloc_matrix_in_arena", "the arena is smaller than the matrix"); return nullptr; }
+  if (bytes < ((size_t)64 << 20)) arena_bytes = bytes;     // (nothing is probed below 64 MiB: no arena either)
+  char* base = nullptr;
+  if (hipMalloc((void**)&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); set_error("sdft_hip_malloc_matrix_in_arena", "out of device memory"); return nullptr; }
+  sdft_hip_placement_t info;
+  size_t off = place_in_arena(base, bytes, arena_bytes, info);
+  info.arenas_tried = 1;
+  // An allocation may happen to lie in ONE kind of memory for all of matrix + 64 GiB (seen in a process that had allocated and freed a lot before).
+  // Then a second allocation is made WHILE the first is held -- other memory by construction -- and the better of the two is kept.
+  if (bytes >= ((size_t)64 << 20) && info.boundary_offset == 0 && info.pair_probes >= 2)     // (an arena that was probed at 16 GiB and beyond)
+  {
+    char* second = nullptr;
+    if (hipMalloc((void**)&second, arena_bytes) == hipSuccess)
+    {
+      sdft_hip_placement_t info2;
+      const size_t off2 = place_in_arena(second, bytes, arena_bytes, info2);
+      info2.arenas_tried = 2;
+      info2.probe_ms += info.probe_ms; info2.pair_probes += info.pair_probes; info2.window_probes += info.window_probes;
+      if (info2.window_gbs > 1.02 * info.window_gbs) { (void)hipFree(base); base = second; off = off2; info = info2; }
+      else { (void)hipFree(second); info.arenas_tried = 2; info.probe_ms = info2.probe_ms; info.pair_probes = info2.pair_probes; info.window_probes = info2.window_probes; }
+    }
+    else (void)hipGetLastError();
+  }
   if (gbs) *gbs = info.window_gbs;
   std::lock_guard<std::mutex> lock(g_arena_mutex);
   g_arenas.push_back(ArenaEntry{(void*)(base + off), (void*)base, info});

@@ -951,8 +951,8 @@ def test_matrix_memory_chosen_for_its_store_rate():
 
 def test_matrix_as_the_best_window_of_one_allocation():
     """sdft_hip_malloc_matrix_in_arena: one allocation; where the kind of memory changes inside it the window is centred on the change (round 6:
-    tests/test_gpu_fullsize.py at full size), in an arena too small to hold a change -- as here -- the store-only probe on a window every 4 GiB picks
-    the best; sdft_hip_matrix_placement tells which it was; sdft_hip_free_matrix releases the whole allocation, knows its windows from other
+    tests/test_gpu_fullsize.py at full size), in an arena too small to reach a change -- as here -- the window is the allocation's start;
+    sdft_hip_matrix_placement tells which it was; sdft_hip_free_matrix releases the whole allocation, knows its windows from other
     pointers, and nothing leaks.  The window is ordinary device memory: sdft_sdft_n writes the reference's rows into it."""
     import torch
     from sdft_amd import capi
@@ -971,8 +971,8 @@ def test_matrix_as_the_best_window_of_one_allocation():
     assert 0.9 * arena < free0 - free1 < 1.1 * arena + (64 << 20)
     info = capi.Placement()
     assert lib.sdft_hip_matrix_placement(C.c_void_p(ptr), C.byref(info)) == 0
-    assert info.arena_bytes == arena and info.window_offset in (0, 4 << 30, 8 << 30) and info.boundary_offset == 0       # (9 GiB hold no change of kind)
-    assert info.window_probes == 3 and abs(info.window_gbs - gbs.value) < 1e-6 and info.start_gbs > 100.0 and info.probe_ms > 0
+    assert info.arena_bytes == arena and info.window_offset == 0 and info.boundary_offset == 0       # (9 GiB: nothing to probe beyond the start)
+    assert info.window_probes == 1 and info.arenas_tried == 1 and abs(info.window_gbs - gbs.value) < 1e-6 and info.start_gbs > 100.0 and info.probe_ms > 0
     assert lib.sdft_hip_matrix_placement(C.c_void_p(ptr + 16), C.byref(info)) == -1 and b"not a window" in lib.sdft_hip_last_error()
     lib.sdft_hip_clear_error()
     x = noise(n, seed=3)
