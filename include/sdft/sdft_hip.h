@@ -55,7 +55,7 @@ void*       sdft_hip_malloc_matrix(size_t bytes, int candidates, double* gbs);
    made of stretches of two or three KINDS of memory that alternate every 16-32 GiB (the first change lies 32 or 64 GiB into the allocation in
    every session kept), and the analysis' store stream -- every XCD writing its own eighth of the matrix at the same time -- reaches 6.8-7.1 TB/s
    when the matrix lies half in one kind and half in another, 5.6-5.85 when all of it is of one kind.  Allocates `arena_bytes` (>= bytes;
-   bytes + 64 GiB has always held a change of kind so far), finds the first change with small two-part store probes (2 GiB written each, steps
+   bytes + 64 GiB has held a change of kind in every fresh process so far), finds the first change with small two-part store probes (2 GiB written each, steps
    of 16 GiB then bisection: <= 12 ms in all), returns the window centred on it and keeps the whole allocation until
    sdft_hip_free_matrix(window) -- NOT hipFree: the window is not the start of the allocation.  Two full-size probes check the result (the
    window, and a window at the allocation's start = what a plain hipMalloc would have been) and the better one is returned.  An allocation that
