@@ -23,7 +23,7 @@ rows = [
     ("**configs[1]: n = 1e6, m = 1024, Hann, FD double, analysis** (`value`) — matrix placed by the library inside matrix + 64 GiB",
      "**%s Msamples/s, %s ms per step, %s of the 8 TB/s peak** (kernel %s ms; %s of the best store-only kernel on the same buffer; HBM traffic / algorithmic bytes 1.001)"
      % (c("value"), c("ms_per_step"), c("roofline.frac"), c("roofline.avg_launch_ms"), c("roofline.store_only_ceiling.frac_of_best_store_only"))),
-    ("… the same K steps into the process' first plain allocation (`first_allocation`)", "%s Msamples/s, %s of peak (by lease: 0.71 … 0.84 — whether the allocation happens to straddle a change of kind)"
+    ("… the same K steps into the process' first plain allocation (`first_allocation`)", "%s Msamples/s, %s of peak (by lease: 0.71 … 0.87 — whether the allocation happens to straddle a change of kind)"
      % (c("first_allocation.value"), c("first_allocation.frac"))),
     ("… placement: arena, probes", "%s bytes; %s two-part probes + %s full-size probes, %s ms of GPU time; the window %s GB/s store-only against %s at the allocation's start"
      % (c("buffer_placement.arena_bytes"), c("buffer_placement.pair_probes"), c("buffer_placement.window_probes"), c("buffer_placement.probe_ms"), c("buffer_placement.window_gbs"), c("buffer_placement.start_gbs"))),
