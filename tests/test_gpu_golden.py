@@ -168,3 +168,40 @@ def test_reference_test_wav_pattern_with_the_resident_kernel():
     assert st0[3] == st1[3]
     assert np.array_equal(np.stack([r[0] for r in rows1 if r is not None]), g["hop_first_rows"][::7][:len([r for r in rows1 if r is not None])])
     assert rel_err(y1[hop:], g["y"][hop:y1.size]) <= 1e-6
+
+
+def test_resident_kernel_calls_that_race_with_its_idle_time_out():
+    """The hop loop with pauses around the resident kernel's idle time-out (200 us): calls find the kernel gone (it is started again) or race with its leaving
+    (the exit word says the call was not served: rung again on a fresh launch).  Every compared hop and the final state are bit-identical to a plan that launches."""
+    import random
+    import time
+    import torch
+    from sdft_amd.sdft import SDFT
+    from sdft_amd.signals import noise
+    random.seed(11)
+    m, hop, hops = 1000, 100, 600
+    x = torch.from_numpy(noise(hop * hops, seed=3)).cuda()
+    pauses = [0, 0, 50e-6, 150e-6, 190e-6, 200e-6, 210e-6, 230e-6, 300e-6, 1e-3]
+    with SDFT(m, "hann", 1.0, "f32f64") as pa, SDFT(m, "hann", 1.0, "f32f64") as pb:
+        pa.set_option("resident", 1)
+        da = torch.empty((hop, m), dtype=torch.complex128, device="cuda"); db = torch.empty_like(da)
+        ya = torch.empty(hop, dtype=torch.float32, device="cuda"); yb = torch.empty_like(ya)
+        for i in range(hops):
+            seg = x[i * hop:(i + 1) * hop]
+            pa.sdft(seg, da)
+            t = time.perf_counter(); p = random.choice(pauses)
+            while time.perf_counter() - t < p:
+                pass
+            pa.isdft(da, ya)
+            if i % 3 == 0:
+                t = time.perf_counter(); p = random.choice(pauses)
+                while time.perf_counter() - t < p:
+                    pass
+            pb.sdft(seg, db)
+            if i % 25 == 0:
+                pb.isdft(db, yb)
+                assert torch.equal(da, db) and torch.equal(ya, yb), i
+        assert pa.get_option("resident") == 1 and pa.get_option("resident_calls") >= 2 * hops - 60 and pa.get_option("resident_launches") > 50
+        assert pa.api.last_warning() is None
+        sa, sb = pa.state(), pb.state()
+        assert sa[3] == sb[3] and all(np.array_equal(a, b) for a, b in zip(sa[:3], sb[:3]))
