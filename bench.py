@@ -468,10 +468,21 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
     for i in range(1000):
         p.api.sdft(p._p, float(xs[i]), hp)
     t4 = time.perf_counter()
+    # ... and with option "resident" = 1: one pair per sample (the reference's per-sample loop), no launch per call
+    p.set_option("resident", 1)
+    for i in range(200):
+        p.api.sdft(p._p, float(xs[i]), rp); p.api.isdft(p._p, rp)
+    t5 = time.perf_counter()
+    for i in range(200, 2200):
+        p.api.sdft(p._p, float(xs[i]), rp); p.api.isdft(p._p, rp)
+    t6 = time.perf_counter()
+    res_calls = int(p.get_option("resident_calls"))
+    p.set_option("resident", 0)
     p.close()
     one = {"shape": f"sdft_sdft / sdft_isdft, one sample per call, m={m}, hann, {combo}, synchronous (the sample comes back by value)",
            "sdft_us_per_call_device_row": round((t1 - t0) / 2000 * 1e6, 2), "isdft_us_per_call_device_row": round((t2 - t1) / 2000 * 1e6, 2),
-           "sdft_us_per_call_host_row": round((t4 - t3) / 1000 * 1e6, 2)}
+           "sdft_us_per_call_host_row": round((t4 - t3) / 1000 * 1e6, 2),
+           "sdft_plus_isdft_us_per_sample_resident": round((t6 - t5) / 2000 * 1e6, 2), "resident_calls": res_calls}
     if with_cpu:
         from oracle import oracle as O
         ref = O.best(m, "hann", 1.0, combo)

@@ -45,8 +45,8 @@ rows = [
      % (c("hop100_m1000.us_per_hop_host_pointers"), c("hop100_m1000.us_per_hop_host_pointers_runtime_copy"), c("hop100_m1000.us_per_hop_host_pointers_registered"), c("hop100_m1000.host_pointers_pcie_floor_us"))),
     ("the reference's bench shape (m = 1000, 44 100 samples, TD = FD = double)", "`sdft` %s µs, `isdft` %s µs (the reference on one core: %s / %s µs)"
      % (c("reference_bench_shape.gpu_sdft_us"), c("reference_bench_shape.gpu_isdft_us"), c("reference_bench_shape.cpu_sdft_us"), c("reference_bench_shape.cpu_isdft_us"))),
-    ("single samples (`sdft_sdft` / `sdft_isdft`, device row)", "%s / %s µs per call (one host core of the reference: %s / %s)"
-     % (c("configs.single_sample.sdft_us_per_call_device_row"), c("configs.single_sample.isdft_us_per_call_device_row"), c("configs.single_sample.cpu_sdft_us_per_sample"), c("configs.single_sample.cpu_isdft_us_per_sample"))),
+    ("single samples (`sdft_sdft` / `sdft_isdft`, device row)", "%s / %s µs per call, with `resident` = 1 %s µs per sample for the pair (one host core of the reference: %s / %s)"
+     % (c("configs.single_sample.sdft_us_per_call_device_row"), c("configs.single_sample.isdft_us_per_call_device_row"), c("configs.single_sample.sdft_plus_isdft_us_per_sample_resident"), c("configs.single_sample.cpu_sdft_us_per_sample"), c("configs.single_sample.cpu_isdft_us_per_sample"))),
     ("fused analysis → operation → synthesis (`sdft_hip_process_n`), n = 1e6", "%s Msamples/s (tree sum), %s in the reference's order" % (c("fused_process.tree_sum_msamples_s"), c("fused_process.reference_order_msamples_s"))),
     ("host samples in, host matrix out (PCIe-inclusive, never `value`)", "%s Msamples/s" % c("extras.host_pointer_pcie_inclusive_msamples_s")),
     ("the reference's `sdft_sdft_n` on one host core of the GPU box (`cpu_baseline`, kind reference, 256-core host)", "%s Msamples/s" % c("cpu_baseline.value")),

@@ -27,12 +27,12 @@
 namespace sdfthip {
 
 constexpr unsigned kResidentBlocks = 256;                  // workgroups of the resident kernel (two waves each): one per CU
-enum { RES_ANALYSIS = 1, RES_SYNTHESIS = 2, RES_QUIT = 3 };
+enum { RES_ANALYSIS = 1, RES_SYNTHESIS = 2, RES_QUIT = 3, RES_ANALYSIS_SAMPLE = 4 };     // (4: sdft_sdft -- ONE sample, carried by the call itself)
 
 // one call = one cache line of pinned host memory; the host writes `seq` LAST (the line is read with one 64-byte request: a snapshot)
 struct __attribute__((aligned(64))) ResidentCall
 {
-  unsigned long long x, out, y;                            // device pointers: analysis x -> out, synthesis out -> y
+  unsigned long long x, out, y;                            // device pointers: analysis x -> out, synthesis out -> y (RES_ANALYSIS_SAMPLE: y holds the sample's bits)
   unsigned n, cursor0, parts, part_len;
   unsigned slots;                                          // bits 0-1: the state slot the call reads, bits 2-3: the delay-line slot (it writes slot ^ 1)
   unsigned op, flag_seq, blocks;                           // blocks: workgroups (analysis) / rows (synthesis) that report to the completion word
@@ -60,7 +60,7 @@ template <typename TD, typename FD> struct ResidentArgs
 template <typename TD, typename FD, int BPL, int WIN, bool LAT1>
 __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD, FD> ra)
 {
-  __shared__ unsigned cur[16];                             // the call being served (ResidentCall as words)
+  __shared__ __align__(16) unsigned cur[16];               // the call being served (ResidentCall as words)
   __shared__ __align__(16) FD terms[2][inverse_row_geometry<FD>::TB];
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -120,21 +120,23 @@ __global__ __launch_bounds__(2 * kWave) void resident_hop_kernel(ResidentArgs<TD
     }
     __syncthreads();
     const unsigned op = cur[11];
-    if (op != (unsigned)RES_ANALYSIS && op != (unsigned)RES_SYNTHESIS) break;      // QUIT (or a line nobody should have written)
+    if (op != (unsigned)RES_ANALYSIS && op != (unsigned)RES_SYNTHESIS && op != (unsigned)RES_ANALYSIS_SAMPLE) break;      // QUIT (or a line nobody should have written)
     const unsigned long long px = ((unsigned long long)cur[1] << 32) | cur[0], pout = ((unsigned long long)cur[3] << 32) | cur[2],
                              py = ((unsigned long long)cur[5] << 32) | cur[4];
     const unsigned n = cur[6], blocks = cur[13];
     DoneSignal done; done.flag = ra.done_flag; done.count = ra.done_count; done.seq = cur[12]; done.total = blocks;
     // a workgroup with work in this call sees what the call before it wrote, on any XCD (its own release was the completion ticket)
-    const bool has_work = op == (unsigned)RES_ANALYSIS ? blockIdx.x < blocks : blockIdx.x < n;
+    const bool analysis = op != (unsigned)RES_SYNTHESIS;
+    const bool has_work = analysis ? blockIdx.x < blocks : blockIdx.x < n;
     if (has_work) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (op == (unsigned)RES_ANALYSIS)
+    if (analysis)
     {
       if (blockIdx.x < blocks)
       {
         HopArgs<TD, FD> a = ra.ha;
         const unsigned ss = cur[10] & 3u, hs = (cur[10] >> 2) & 3u;
-        a.x = reinterpret_cast<const TD*>(px); a.x_stride = n;
+        // (a single sample travels in the call's line: the workgroup's own copy of it in LDS is the sample "array")
+        a.x = op == (unsigned)RES_ANALYSIS_SAMPLE ? reinterpret_cast<const TD*>(&cur[4]) : reinterpret_cast<const TD*>(px); a.x_stride = n;
         a.out = reinterpret_cast<cx<FD>*>(pout); a.out_stride = (size_t)n * a.nbins; a.out_rows = nullptr;
         a.n = n; a.cursor0 = cur[7]; a.parts = cur[8]; a.part_len = cur[9];
         a.acc_in = ra.acc[ss]; a.fid_in = ra.fid[ss]; a.acc_out = ra.acc[ss ^ 1u]; a.fid_out = ra.fid[ss ^ 1u];

@@ -205,3 +205,37 @@ def test_resident_kernel_calls_that_race_with_its_idle_time_out():
         assert pa.api.last_warning() is None
         sa, sb = pa.state(), pb.state()
         assert sa[3] == sb[3] and all(np.array_equal(a, b) for a, b in zip(sa[:3], sb[:3]))
+
+
+@pytest.mark.parametrize("combo", ["f32f64", "f64f64", "f32f32"])
+def test_single_sample_calls_through_the_resident_kernel(combo):
+    """sdft_sdft / sdft_isdft (sdft.h:562, :635), one sample per call, with option "resident" = 1: the sample rides in the doorbell line, the result comes back
+    through the plan's pinned scratch -- no launch per sample.  Bit-identical to the launches and to the reference, across the roll-over (t = 2N - 1)."""
+    import ctypes as C
+    import torch
+    from oracle import oracle as O
+    from sdft_amd.sdft import SDFT
+    from sdft_amd.signals import noise
+    td, fd, fdx = O.combo_types(combo)
+    m, n = 96, 2 * 96 + 37
+    x = noise(n, seed=4, dtype=td)
+    ref = O.best(m, "hamming", 1.0, combo)
+    want = ref.sdft(x); ywant = ref.isdft(want)
+    res = {}
+    for resident in (0, 1):
+        with SDFT(m, "hamming", 1.0, combo) as p:
+            p.set_option("resident", resident)
+            row = torch.empty(m, dtype=torch.complex128 if fd == np.float64 else torch.complex64, device="cuda")
+            rows, ys = [], []
+            for i in range(n):
+                p.api.sdft(p._p, td(x[i]).item(), C.c_void_p(row.data_ptr()))
+                ys.append(p.api.isdft(p._p, C.c_void_p(row.data_ptr())))
+                if i % 16 == 0 or i >= 2 * m - 2:
+                    rows.append((i, row.cpu().numpy().copy()))
+            if resident:
+                assert p.get_option("resident_calls") >= 2 * n - 4 * len(rows) - 4, (p.get_option("resident_calls"), n)
+            res[resident] = (rows, np.array(ys, dtype=td), p.state())
+    for (i, a), (j, b) in zip(res[0][0], res[1][0]):
+        assert i == j and np.array_equal(a, b) and np.array_equal(a, want[i]), i
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[1][1], ywant)
+    assert res[0][2][3] == res[1][2][3] and all(np.array_equal(a, b) for a, b in zip(res[0][2][:3], res[1][2][:3]))
