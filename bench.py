@@ -491,7 +491,8 @@ def baseline_configs(torch, np, SDFT, sine_sweep, device, with_cpu=True, placeme
         ta = time.perf_counter(); ref.sdft(xs[:2000], buf); tb = time.perf_counter(); ref.isdft(buf); tc = time.perf_counter()
         one.update({"cpu_sdft_us_per_sample": round((tb - ta) / 2000 * 1e6, 2), "cpu_isdft_us_per_sample": round((tc - tb) / 2000 * 1e6, 2),
                     "cpu_kind": ref.kind, "cpu_cores": 1,
-                    "note": "per sample, the drop-in costs a launch and a completion: at best on a par with one host core -- hosts that have the samples call sdft_sdft_n"})
+                    "note": "per sample, the drop-in costs a launch and a completion: on a par with one host core; with option resident = 1 a doorbell instead (sdft_plus_isdft_us_per_sample_resident "
+                            "for the pair); hosts that have the samples call sdft_sdft_n"})
     res["single_sample"] = one
     return res
 
