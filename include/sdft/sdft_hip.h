@@ -258,7 +258,7 @@ double sdft_hip_time_hops(sdft_t* sdft, size_t hops, size_t hop, const sdft_td_t
    -DSDFT_HIP_TEST_HOOKS (libsdft_hip_hooks.so, built beside the product by `python -m sdft_amd.build`; no host links it) accept the keys that force
    those forks, so that the tests can run every route against the reference and the probes under scripts/ can measure them:
    "rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves", "inverse_verify",
-   "relay_flow", "relay_groups", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams" (sdft_capi.inc names what each selects);
+   "relay_flow", "relay_groups", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "inverse_ordered", "host_direct", "copy_streams" (sdft_capi.inc names what each selects);
    get_option "test_hooks" = 1 in that build.
    get_option additionally answers "tiles", "bins_per_lane", "row_slots", "last_chunks",
    "last_chunk_len", "last_kernel" (1 tiles, 2 row groups, 3 hop), "last_segments", "last_fused",

@@ -292,6 +292,240 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void inverse_rows2_kernel(Inv
 }
 
 // ------------------------------------------------------------------------------------------
+// K2 (whole rows, ordered sum; round 6)  the reference's summation order (sdft.h:641-651) for EVERY type pair -- no rounding-interval proof,
+// no second pass -- read the way inverse_rows_body reads: a workgroup owns a chunk of consecutive rows and fetches WHOLE rows, 1 KiB per load
+// instruction, non-temporal.  The tiles of inverse_exact_kernel below read 256-byte pieces of 16 ... 32 rows per wave: 5.8 ... 6.35 TB/s at
+// n = 1e6 x 1024 where this kernel reads 6.8 ... 6.9 for every type pair (rows in step with the tree sum and the proof: 6.54;
+// profiles/r06_synthesis_forms.txt).  Eleven LOADER waves turn the bins into the scalars the reference adds and park them in LDS, row by row
+// (row slots of N terms; NG groups of G slots); ONE wave adds: lane j owns row slot j and walks it in ascending bin order, 128 bins per pass,
+// every group of slots at its own place in its rows -- a group is handed over when its last loader has written (counter `filled`) and handed
+// back when its sums are stored (counter `freed`), so the loaders run up to NG groups ahead in LDS and three more in registers while the
+// chains of N dependent additions run 16 ... 64 abreast.  Rows of up to 8 KiB of terms (1024 double bins, 2048 float bins): with fewer than
+// 16 slots the adding wave cannot keep up with HBM (N x 6.5 cycles per row).
+// What the first versions lost, in the order found (each is a comment at its place below): a load whose other half nobody reads gives that
+// half's registers away and is waited for at once; a load behind a condition, a polling loop inside the ring's loop or a fetch at the loop's
+// top make the compiler wait for ALL loads that are on their way; a 64-bit division per load; and `nt ? __builtin_nontemporal_load(p) : *p`
+// with a constant nt compiles to an ORDINARY load -- 6.2 TB/s instead of 6.85.
+// ------------------------------------------------------------------------------------------
+template <typename FD, int NLOAD = 11> struct ordered_rows_geometry   // (NLOAD: scripts/inverse_forms_probe.hip tries 7, 8, 11 and 15 loader waves)
+{
+  static constexpr int BPL = 16 / (int)sizeof(cx<FD>);     // bins per 16-byte load
+  static constexpr int PIECE = kWave * BPL;                // bins per load instruction of a wave (1 KiB of a row)
+  static constexpr int LOADERS = NLOAD;                    // waves 1 .. 11 (wave 0 adds); twelve waves: 168 registers each (sixteen: 128, and the adding wave spills)
+  static constexpr int MAXP = (64 + NLOAD - 1) / NLOAD;    // pieces of a group per loader wave (G * ppr <= 64 <= LOADERS * MAXP)
+  static constexpr unsigned kFlagBytes = 512;              // filled[64], freed[64]
+  static constexpr int kBlockBins = 128;                   // the adding wave's pass: a row slot is a whole number of these (bins past N-1 hold +0)
+  unsigned ppr, stride_bytes, G, NG;                       // pieces per row, bytes from a row slot to the next, rows per group, groups
+  size_t lds_bytes;
+  SDFT_HD bool make(unsigned nbins, size_t lds_budget)
+  {
+    ppr = (nbins + PIECE - 1) / PIECE;
+    while ((ppr * PIECE) % kBlockBins) ++ppr;
+    const size_t row_bytes = (size_t)ppr * PIECE * sizeof(FD);
+    if (nbins < 1 || row_bytes > 8192) return false;
+    stride_bytes = (unsigned)row_bytes + 16;               // (lanes of the adding wave read the same bin of different rows: 16 bytes apart in the banks)
+    size_t slots = (lds_budget - kFlagBytes - 256) / stride_bytes;
+    if (slots > 64) slots = 64;
+    if (slots < 16) return false;
+    G = 64 / ppr; if (G > slots / 4) G = (unsigned)(slots / 4);
+    NG = (unsigned)(slots / G);
+    lds_bytes = kFlagBytes + (size_t)NG * G * stride_bytes + 256;   // (slack: the adding wave fetches one stage past a row's end)
+    return true;
+  }
+};
+
+template <typename TD, typename FD, bool LAT1, int NLOAD = 11>
+__global__ __launch_bounds__(kWave * (NLOAD + 1)) void inverse_rows_ordered_kernel(InverseArgs<TD, FD> a, unsigned chunk_len, ordered_rows_geometry<FD, NLOAD> geo)
+{
+  using GEO = ordered_rows_geometry<FD, NLOAD>;
+  constexpr int BPL = GEO::BPL, PIECE = GEO::PIECE, LOADERS = GEO::LOADERS, MAXP = GEO::MAXP;
+  using V = typename StoreVec<FD, (sizeof(cx<FD>) == 16 ? 1 : 2)>::type;            // 16 bytes of the matrix
+  using TV = typename StoreVec<FD, (sizeof(FD) == 8 ? 1 : 2)>::type;               // 16 bytes of terms (2 double / 4 float)
+  extern __shared__ __align__(16) unsigned char ordered_lds[];
+  unsigned* filled = reinterpret_cast<unsigned*>(ordered_lds);
+  unsigned* freed = filled + 64;
+  unsigned char* slots = ordered_lds + GEO::kFlagBytes;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t rows = (size_t)a.channels * a.n;
+  // chunks are taken from the END of the matrix first (what the analysis wrote last still sits in the Infinity Cache)
+  const size_t nchunks = (rows + chunk_len - 1) / chunk_len;
+  const size_t cidx = nchunks - 1 - blockIdx.x;
+  const int nt = (a.nt && (size_t)blockIdx.x * chunk_len >= a.nt_skip) ? 1 : 0;
+  const size_t r0 = cidx * (size_t)chunk_len;
+  const size_t r1 = r0 + chunk_len < rows ? r0 + chunk_len : rows;
+  const unsigned G = geo.G, NG = geo.NG, ppr = geo.ppr, stride = geo.stride_bytes;
+  const unsigned ngroups = (unsigned)((r1 - r0 + G - 1) / G);
+  if (threadIdx.x < 128) filled[threadIdx.x] = 0u;
+  __syncthreads();
+
+  if (wave == 0)
+  {
+    // ---- the adding wave: lane j owns row slot j ----
+    // One pass of the loop adds a block of 128 bins in stages of 128 bytes of terms (16 double / 32 float); while a stage is added the next one
+    // is on its way from LDS into the other of two register buffers (the last stage fetches the first one of the row's next block).
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int SV = 8, PER = 16 / (int)sizeof(FD);      // 16-byte vectors per stage, terms per vector
+    constexpr int BLK = GEO::kBlockBins, NS = BLK / (SV * PER);
+    static_assert(NS % 2 == 0, "the stages alternate between two buffers");
+    const bool mine = (unsigned)lane < NG * G;
+    const unsigned q = (unsigned)lane / G, rin = (unsigned)lane - q * G;
+    const unsigned blocks = ppr * (unsigned)PIECE / (unsigned)BLK;
+    const unsigned char* my = slots + (size_t)lane * stride;
+    unsigned it = 0, pos = 0;                              // occupancy number of my group of slots (its rows: group it * NG + q of the chunk), block within the row
+    bool active = false;
+    FD sum = (FD)0;
+    unsigned remaining = ngroups;
+    TV b0[SV], b1[SV];
+    while (remaining)
+    {
+      if (mine && !active && it * NG + q < ngroups)
+      {
+        if (__hip_atomic_load(&filled[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)LOADERS * (it + 1u))
+        {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          active = true; pos = 0; sum = (FD)0;
+          const TV* t = reinterpret_cast<const TV*>(my);
+#pragma unroll
+          for (int c = 0; c < SV; ++c) b0[c] = t[c];
+        }
+      }
+      if (__ballot(active) == 0ull) { __builtin_amdgcn_s_sleep(2); continue; }
+      bool finished = false;
+      if (active)
+      {
+        const TV* t = reinterpret_cast<const TV*>(my + (size_t)pos * (BLK * sizeof(FD)));
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+        {
+          // (past the row's last block: the next slot's first terms, or the slack after the last slot -- fetched, never added)
+#pragma unroll
+          for (int c = 0; c < SV; ++c) { if ((st & 1) == 0) b1[c] = t[(st + 1) * SV + c]; else b0[c] = t[(st + 1) * SV + c]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < SV; ++c)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) sum += ((st & 1) == 0 ? b0[c][e] : b1[c][e]);   // sdft.h:641-651: one accumulator, ascending bins
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ++pos;
+        finished = pos == blocks;
+      }
+      if (finished)
+      {
+        const size_t r = r0 + (size_t)(it * NG + q) * G + rin;
+        if (r < r1) a.y[r] = (TD)(sum * a.sweight);      // sdft.h:654-656 (the samples of the channels follow each other as the rows do)
+        active = false; ++it;
+        if (rin == 0) __hip_atomic_fetch_add(&freed[q], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      remaining -= (unsigned)__popcll(__ballot(finished && rin == 0));
+    }
+    return;
+  }
+
+  // ---- the loaders: the pieces of a group (G rows x ppr pieces of 1 KiB) dealt round over the loader waves ----
+  const unsigned lw = wave - 1u;
+  const unsigned np = G * ppr;
+  unsigned prow[MAXP], kbin[MAXP]; bool live[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p)
+  {
+    const unsigned i = lw + (unsigned)p * LOADERS;
+    live[p] = i < np;
+    prow[p] = i / ppr;
+    kbin[p] = (i - prow[p] * ppr) * PIECE + (unsigned)lane * BPL;
+  }
+  // (16-byte loads only, and the matrix is one run of rows: the launch sees to it that FD float rows have an even number of bins and a 16-byte
+  // aligned start, and that channels follow each other without a gap -- a load costs a handful of instructions, not a 64-bit division)
+  bool livek[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) livek[p] = live[p] && kbin[p] < a.nbins;
+  // a piece of group g this wave does not have (past the group, the chunk or the row) is loaded all the same, from the chunk's first bytes (not from one
+  // address for the whole chip: 3 % of the loads on one line of one channel cost 5 % of the speed), and
+  // parked as +0: EVERY fetch issues MAXP loads, so the wait before a group is parked is for that group's loads alone (behind conditional
+  // loads the compiler waits for all that are on their way -- the ring would drain every third group)
+  auto have = [&](unsigned g, int p) -> bool { return livek[p] && g < ngroups && r0 + (size_t)g * G + prow[p] < r1; };
+  auto loaders = [&](auto nt_tag)
+  {
+    constexpr int NT = decltype(nt_tag)::value;
+    auto fetch = [&](unsigned g, V (&x)[MAXP])
+    {
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p)
+      {
+        const cx<FD>* src = a.in + (have(g, p) ? (r0 + (size_t)g * G + prow[p]) * (size_t)a.nbins + kbin[p] : r0 * (size_t)a.nbins);
+        // (not load_vec(src, NT): the select of two loads with a constant condition folds to an ordinary load)
+        if constexpr (NT != 0) x[p] = __builtin_nontemporal_load(reinterpret_cast<const V*>(src)); else x[p] = *reinterpret_cast<const V*>(src);
+      }
+    };
+    auto put = [&](unsigned g, const V (&x)[MAXP])
+    {
+      const unsigned it = g / NG, q = g - it * NG;
+      // the slots' rows before these have been added and stored
+      // (the wait is one opaque statement: around a polling LOOP the compiler waits for every load that is on its way at the top of the
+      // ring's loop, and the ring drains every third group)
+      {
+        unsigned seen;
+        const unsigned at = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)(&freed[q]);
+        asm volatile("1:\n\t"
+                     "ds_read_b32 %0, %1\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_cmp_ge_u32 vcc, %0, %2\n\t"
+                     "s_cbranch_vccnz 2f\n\t"
+                     "s_sleep 1\n\t"
+                     "s_branch 1b\n\t"
+                     "2:"
+                     : "=&v"(seen) : "v"(at), "v"(it) : "vcc", "memory");
+      }
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p)
+      {
+        // (every load is waited for here, in the order of issue, whether the wave has the piece or not: a load nobody consumes stays "on its way"
+        // in the compiler's count and costs a wait for everything at the top of the ring's loop; latency 1 needs the real halves only, and
+        // without this the other halves' registers are handed out while the load is on its way)
+        if constexpr (sizeof(FD) == 8) asm volatile("" : : "v"(x[p][0]), "v"(x[p][1]));
+        else asm volatile("" : : "v"(x[p][0]), "v"(x[p][1]), "v"(x[p][2]), "v"(x[p][3]));
+        if (live[p])
+        {
+          const bool h = have(g, p);
+          FD tv[BPL];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b)
+          {
+            const unsigned k = kbin[p] + b;                // (bins past N-1 park +0)
+            const cx<FD> v = cmake<FD>((FD)x[p][2 * b], (FD)x[p][2 * b + 1]);
+            tv[b] = (h && k < a.nbins) ? synth_term<FD, LAT1, false>(v, k, a.op, a.syn, a.nbins) : (FD)0;
+          }
+          FD* dst = reinterpret_cast<FD*>(slots + (size_t)(q * G + prow[p]) * stride) + kbin[p];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) dst[b] = tv[b];
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(&filled[q], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    V xa[MAXP], xb[MAXP], xc[MAXP];                        // a ring of three groups: two on their way while one is parked
+    // (every pass begins by parking what was fetched first: the same eighteen loads are on their way, in the same order, whether the loop is
+    // entered or repeated -- with a fetch at the top the compiler waits for ALL of them there)
+    fetch(0, xa);
+    fetch(1, xb);
+    fetch(2, xc);
+    for (unsigned g = 0; g < ngroups; g += 3)
+    {
+      put(g, xa);
+      fetch(g + 3, xa);
+      if (g + 1 >= ngroups) break;
+      put(g + 1, xb);
+      fetch(g + 4, xb);
+      if (g + 2 >= ngroups) break;
+      put(g + 2, xc);
+      fetch(g + 5, xc);
+    }
+  };
+  if (nt) loaders(OpTag<1>{}); else loaders(OpTag<0>{});
+}
+
+// ------------------------------------------------------------------------------------------
 // K2 (exact order)  inverse with the reference's summation order (sdft.h:641-651: one accumulator
 // per row, bins added in ascending order), at streaming bandwidth: a wave owns RW consecutive rows
 // and, in the summation phase, lane r adds row r's terms strictly in bin order.  Tiles of RW rows x

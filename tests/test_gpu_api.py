@@ -1007,7 +1007,7 @@ def test_product_library_knows_22_options_and_the_hooks_library_the_rest():
                "profile", "resident", "chunk", "segments", "chain", "self_carry", "hop_kernel", "fused_exact", "inverse_rows", "inverse_tune",
                "pointers", "stage_bytes")
     hooks = ("rows_kernel", "row_slots_max", "interior", "fused", "fft_carry", "fold", "rows_f32", "hop_parts", "xcd_map", "chain_block", "relay_waves",
-             "relay_flow", "relay_groups", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "host_direct", "copy_streams", "inverse_verify")
+             "relay_flow", "relay_groups", "chain_debug", "inverse_nt", "inverse_nt_skip_mb", "inverse_step", "inverse_ordered", "host_direct", "copy_streams", "inverse_verify")
     gone = ("rows_split", "inverse_rpi", "hop_pipe", "flag_max", "no_such_option")
     assert len(product) == 22
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdft", "sdft_hip.h")).read()

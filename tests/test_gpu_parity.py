@@ -722,6 +722,49 @@ def test_streaming_loads_change_no_bit(combo, m, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("combo", ["f32f64", "f64f64", "f32f32", "f64f32"])
+@pytest.mark.parametrize("m,n,channels,latency", [(1024, 70000, 1, 1.0), (1000, 9001, 1, 1.0), (1024, 5003, 2, 0.5), (320, 20001, 3, 1.0), (64, 70, 1, 1.0),
+                                                  (6, 777, 1, 1.0), (2048, 4097, 1, 1.0), (998, 6001, 1, 0.25)])
+def test_synthesis_by_whole_rows_with_the_ordered_sum_keeps_the_bits(combo, m, n, channels, latency):
+    """Round 6: every type pair and latency can be synthesised by workgroups that read WHOLE ROWS of a chunk of the matrix while ONE wave
+    adds the terms in the reference's order, a lane per row (inverse_rows_ordered_kernel: loader waves, row slots in LDS, two counters
+    per group of slots).  Forced (inverse_ordered = 1) on shapes that exercise full and partly filled pieces, rows padded to whole blocks,
+    ragged chunk ends, channels, a matrix of 70 rows and rows too long for the form (2048 double bins: the form does not apply and the
+    call takes another): the bits of the streaming forms and of the reference."""
+    import torch
+    td, fd, fdx = O.combo_types(combo)
+    x = noise(n * channels, seed=500 + m, dtype=td).reshape(channels, n) if channels > 1 else noise(n, seed=500 + m, dtype=td)
+    applies = m * np.dtype(fd).itemsize <= 8192
+    with make(m, "hann", latency, combo, channels=channels) as p:
+        if combo.endswith("f32"): p.set_option("float_carry_parallel", 1)      # (only to fill the matrix quickly: the synthesis is what is tested)
+        d = p.sdft(torch.from_numpy(x).cuda())
+        p.set_option("inverse_ordered", -1); p.set_option("inverse_tune", 0)
+        y0 = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") != 4
+        p.set_option("inverse_ordered", 1)
+        y1 = p.isdft(d).cpu().numpy()
+        assert (p.get_option("last_inverse_form") == 4) == applies
+        assert np.array_equal(y0.view(np.uint8), y1.view(np.uint8))
+        ref = O.best(m, "hann", latency, combo)
+        dh = d.cpu().numpy()
+        rows = dh if channels == 1 else dh[channels - 1]
+        want = ref.isdft(rows[: min(n, 3000)])
+        got = y1 if channels == 1 else y1[channels - 1]
+        assert np.array_equal(got[: len(want)], want)
+        # both kinds of load in one call (the rows read first take ordinary loads), and a matrix whose rows do not start on 16 bytes
+        p.set_option("inverse_nt", 1); p.set_option("inverse_nt_skip_mb", 1)
+        y2 = p.isdft(d).cpu().numpy()
+        assert np.array_equal(y0.view(np.uint8), y2.view(np.uint8))
+        if channels == 1 and combo.endswith("f32") and n > 100:
+            flat = torch.empty(n * m + 1, dtype=d.dtype, device="cuda")
+            off = flat[1:].view(n, m)                           # 8 bytes past a 16-byte boundary
+            off.copy_(d)
+            y3 = p.isdft(off).cpu().numpy()
+            assert p.get_option("last_inverse_form") != 4
+            assert np.array_equal(y0.view(np.uint8), y3.view(np.uint8))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,n,channels", [(1024, 70000, 1), (1000, 9001, 1), (2048, 5003, 2), (320, 20001, 3), (64, 70, 1), (1536, 4097, 1)])
 def test_synthesis_by_whole_rows_in_step_keeps_the_bits(m, n, channels):
     """Round 5: float samples from double bins at latency 1 can be synthesised by workgroups that read WHOLE ROWS of a chunk of the
