@@ -56,6 +56,9 @@ def run(label, n, m, window, combo, channels=1, reps=5, roundtrip=True, **opts):
     for _ in range(reps):
         p.sdft(x, out)
     p.synchronize(); wall_f = (time.perf_counter() - t0) / reps
+    for _ in range(16):                                       # (the plan tries its synthesis forms on the host's own calls: past that --
+        p.isdft(out, y)                                       # one call at a time: a trial reports when its events have completed)
+        p.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         p.isdft(out, y)
@@ -100,11 +103,13 @@ if __name__ == "__main__":
     run("configs[2] with the serial pass instead of the chain form", 262144, 4096, "blackman", "f32f32", chain=0)
     run("reference bench shape (cpp/examples/bench.cpp): m=1000, 44100 samples, TD = FD = double", 44100, 1000, "hann", "f64f64")
     run("north-star size with double samples: n=48000, m=1024, f64f64", 48000, 1024, "hann", "f64f64")
+    run("TD = FD = double, n=1e6, m=1024", 1_000_000, 1024, "hann", "f64f64")
+    run("FD float, n=1e6, m=1024", 1_000_000, 1024, "hann", "f32f32")
     run("FD float, m=1024", 262144, 1024, "hann", "f32f32")
     run("FD float, m=1024, float_carry_parallel=1 (not the float reference's bits)", 262144, 1024, "hann", "f32f32", float_carry_parallel=1)
     run("configs[2] with float_carry_parallel=1 (not the float reference's bits)", 262144, 4096, "blackman", "f32f32", float_carry_parallel=1)
     print(f"# BASELINE config shapes on 1× MI355X ({torch.cuda.get_device_name(0)}), device-resident buffers\n")
-    print("forward = sdft_sdft_n (delta + carries + forward kernel, wall per call incl. launches); inverse = sdft_isdft_n.")
+    print("forward = sdft_sdft_n (delta + carries + forward kernel, wall per call incl. launches); inverse = sdft_isdft_n (after the 16 calls on which the plan tries its forms).")
     print("TB/s = algorithmic bytes (N·sizeof(fdx) + sizeof(td) per sample) / wall time.")
     print("process = sdft_hip_process_n (identity), the fused analysis→synthesis call; its last column is the speed-up over forward + inverse.\n")
     print("| config | shape | time chunks | fwd ms | fwd Msamples/s | fwd TB/s | fwd-kernel ms | carry ms (on main stream) | inv ms | inv Msamples/s | inv TB/s | process ms | process Msamples/s | vs two calls |")

@@ -165,5 +165,6 @@ int main(int argc, char** argv)
   if (which == 0 || which == 4) sweep<float, float>(1000000, 1024, 1);
   if (which == 0 || which == 3) sweep<double, double>(1000000, 1000, 1);
   if (which == 0 || which == 5) sweep<float, double>(1000000, 1024, 1);
+  if (which == 0 || which == 6) sweep<float, double>(500000, 2048, 1);
   return 0;
 }

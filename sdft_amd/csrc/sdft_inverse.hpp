@@ -42,6 +42,10 @@ __global__ __launch_bounds__(kBlock) void scale_rows_kernel(cx<FD>* mat, size_t 
 
 // a bin of the matrix; nt: non-temporal load (the matrix is read once: it should not push what the analysis left in the
 // Infinity Cache -- dirty lines of the same matrix's tail -- out to HBM)
+// (through the row-pointer table or the dense base, the pointer is GENERIC and these are FLAT loads, which count as LDS operations too: a wave
+// of inverse_exact_kernel that waits for its LDS tile also waits for the matrix loads it has on its way.  Round 6 tried global loads here
+// (an address-space cast): the tiles' forms got SLOWER, 6.3 -> 5.8 TB/s at n = 1e6 x 1024 double -- fewer loads on their way per wave is what
+// these forms want (scripts/inverse_forms_probe.hip) -- so the loads stay as they are.)
 template <typename FD> SDFT_D cx<FD> load_bin(const cx<FD>* p, int nt)
 {
   if (nt)
@@ -52,6 +56,8 @@ template <typename FD> SDFT_D cx<FD> load_bin(const cx<FD>* p, int nt)
   }
   return *p;
 }
+// (nt a run-time value: two loads behind a branch.  With a CONSTANT nt the select folds to an ordinary load -- inverse_rows_ordered_kernel
+// calls the builtin itself)
 template <typename V> SDFT_D V load_vec(const V* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
 template <typename TD, typename FD> struct InverseArgs
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void inverse_rows2_kernel(Inv
 // every group of slots at its own place in its rows -- a group is handed over when its last loader has written (counter `filled`) and handed
 // back when its sums are stored (counter `freed`), so the loaders run up to NG groups ahead in LDS and three more in registers while the
 // chains of N dependent additions run 16 ... 64 abreast.  Rows of up to 8 KiB of terms (1024 double bins, 2048 float bins): with fewer than
-// 16 slots the adding wave cannot keep up with HBM (N x 6.5 cycles per row).
+// 16 slots the adding wave cannot keep up with HBM (measured: 12 ... 14 cycles per term).
 // What the first versions lost, in the order found (each is a comment at its place below): a load whose other half nobody reads gives that
 // half's registers away and is waited for at once; a load behind a condition, a polling loop inside the ring's loop or a fetch at the loop's
 // top make the compiler wait for ALL loads that are on their way; a 64-bit division per load; and `nt ? __builtin_nontemporal_load(p) : *p`
@@ -322,7 +328,7 @@ template <typename FD, int NLOAD = 11> struct ordered_rows_geometry   // (NLOAD:
     ppr = (nbins + PIECE - 1) / PIECE;
     while ((ppr * PIECE) % kBlockBins) ++ppr;
     const size_t row_bytes = (size_t)ppr * PIECE * sizeof(FD);
-    if (nbins < 1 || row_bytes > 8192) return false;
+    if (nbins < 1 || row_bytes > 8192) return false;       // (16 KiB rows, 8 slots: the adding wave sets the pace -- 3.1 TB/s at N = 4096 float, 5.5 at 2048 double)
     stride_bytes = (unsigned)row_bytes + 16;               // (lanes of the adding wave read the same bin of different rows: 16 bytes apart in the banks)
     size_t slots = (lds_budget - kFlagBytes - 256) / stride_bytes;
     if (slots > 64) slots = 64;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(kWave * (NLOAD + 1)) void inverse_rows_ordered_kern
     // One pass of the loop adds a block of 128 bins in stages of 128 bytes of terms (16 double / 32 float); while a stage is added the next one
     // is on its way from LDS into the other of two register buffers (the last stage fetches the first one of the row's next block).
     __builtin_amdgcn_s_setprio(3);
-    constexpr int SV = 8, PER = 16 / (int)sizeof(FD);      // 16-byte vectors per stage, terms per vector
+    constexpr int SV = 8, PER = 16 / (int)sizeof(FD);      // 16-byte vectors per stage (the statement below names eight), terms per vector
     constexpr int BLK = GEO::kBlockBins, NS = BLK / (SV * PER);
     static_assert(NS % 2 == 0, "the stages alternate between two buffers");
     const bool mine = (unsigned)lane < NG * G;
@@ -402,6 +408,12 @@ __global__ __launch_bounds__(kWave * (NLOAD + 1)) void inverse_rows_ordered_kern
           // (past the row's last block: the next slot's first terms, or the slack after the last slot -- fetched, never added)
 #pragma unroll
           for (int c = 0; c < SV; ++c) { if ((st & 1) == 0) b1[c] = t[(st + 1) * SV + c]; else b0[c] = t[(st + 1) * SV + c]; }
+          __builtin_amdgcn_sched_barrier(0);
+          // ONE wait for the whole stage: the empty statement reads all of the stage's registers, so the compiler waits here once (LDS answers
+          // in order: when at most the SV reads just issued are open, the stage before them has arrived) and not again before every second
+          // addition -- s_waitcnt takes an issue slot like any instruction, and a lone wave issues one instruction in 4.5 cycles
+          if ((st & 1) == 0) asm volatile("" : : "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b0[4]), "v"(b0[5]), "v"(b0[6]), "v"(b0[7]) : "memory");
+          else asm volatile("" : : "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]), "v"(b1[4]), "v"(b1[5]), "v"(b1[6]), "v"(b1[7]) : "memory");
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < SV; ++c)
