@@ -139,9 +139,9 @@ class HostIo
   // later gets the address back (numpy does; so does any long-lived process) makes the next copy find a pin whose pages
   // left the process in between -- the driver does not re-attach it and the copy kernel faults the GPU ("Write access to a
   // read-only page", the process is gone; seen in this library's own test suite about one run in three, round 4).  So
-  // nothing of the caller's is ever handed to the runtime to pin: copies beyond 64 KiB go through a pair of pinned 2 MiB
-  // pieces of the plan (DMA of one piece while the host copies the other), smaller ones through the runtime's staging
-  // buffers as before.  scripts/pageable_copy_probe.hip, profiles/r04_host_copy_paths.txt: every piece costs ~15 us
+  // nothing of the caller's is ever handed to the runtime: every copy goes through pinned 2 MiB pieces of the plan (DMA of
+  // one piece while the host copies the other) -- until round 6 copies of up to 64 KiB went through the runtime's staging
+  // buffers; see to_device below.  scripts/pageable_copy_probe.hip, profiles/r04_host_copy_paths.txt: every piece costs ~15 us
   // of its own (1.6 MB in pieces of 128 KiB: 200 us), the host's copy out of pinned memory the device has just written
   // runs at 42 GB/s with streaming stores (host_copy_bytes; glibc memcpy 30); 1.6 MB as one piece: ~70 us out, ~50 us in,
   // against 37 us each way on a pin the runtime remembered;
@@ -296,7 +296,10 @@ class HostIo
   bool to_device(void* dst, const void* src, size_t bytes, hipStream_t stream)
   {
     if (bytes == 0) return true;
-    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
+    // (small copies too, since round 6: the runtime looks a pageable address up among the pins it remembers BEFORE it decides how to copy, so a few
+    // hundred bytes of samples at an address some earlier large copy of the process -- not this library's -- once had pinned went by that stale
+    // pin, and the copy faulted the GPU: "Write access to a read-only page", one run of the test suite in four on some hosts)
+    if (opt_host_copy == 1 || !ensure_pin())
     {
       SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
       return true;
@@ -311,7 +314,7 @@ class HostIo
   bool to_host(void* dst, const void* src, size_t bytes, hipStream_t stream)
   {
     if (bytes == 0) return true;
-    if (bytes <= kSmallHostBytes || opt_host_copy == 1 || !ensure_pin())
+    if (opt_host_copy == 1 || !ensure_pin())
     {
       SDFT_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
       return true;
