@@ -278,11 +278,7 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
     xh = sine_sweep(total, dtype=td)
     yh = np.zeros(total, dtype=td)
     dh = np.zeros((hop, m), dtype=np.complex128 if combo[3:] == "f64" else np.complex64)
-    for label, reg, rt in (("us_per_hop_host_pointers", 0, 0), ("us_per_hop_host_pointers_runtime_copy", 0, 1),
-                           ("us_per_hop_host_pointers_registered", 1, 0)):
-        p = SDFT(m, "hann", 1.0, combo, device=device)
-        p.set_option("host_register", reg)
-        p.set_option("host_copy", rt)
+    def hop_loop(p):
         w = 0.0
         for rep in range(2):
             t0 = time.perf_counter()
@@ -290,10 +286,55 @@ def hop_streaming(torch, np, SDFT, sine_sweep, combo, td, cdt, device, m=1000, h
                 p.api.sdft_n(p._p, hop, C.c_void_p(xh.ctypes.data + i * isz), C.c_void_p(dh.ctypes.data))
                 p.api.isdft_n(p._p, hop, C.c_void_p(dh.ctypes.data), C.c_void_p(yh.ctypes.data + i * isz))
             w = (time.perf_counter() - t0) / (total // hop)
-        res[label] = round(w * 1e6, 1)
-        p.close()
+        return round(w * 1e6, 1)
+    p = SDFT(m, "hann", 1.0, combo, device=device)
+    res["us_per_hop_host_pointers"] = hop_loop(p)
+    p.close()
+    # The two legs that hand the caller's memory to the RUNTIME run in a process of their own: the runtime remembers the pins it makes by
+    # address, and in a process that has copied and freed large host buffers (this one has) a remembered pin under a new buffer faults the
+    # GPU -- the test suite's copy of this leg did, one run in four on some hosts.  A host that allocates its buffers once is safe.
+    res.update(_host_pointer_legs_in_a_child(combo, m, hop, total, device))
     res["host_pointers_pcie_floor_us"] = round(2 * hop * m * dh.itemsize / 55e9 * 1e6, 1)      # the matrix out and back in at 55 GB/s
     return res
+
+
+_HOST_LEGS = r"""
+import sys, time, json, ctypes as C, numpy as np
+sys.path.insert(0, sys.argv[1])
+from sdft_amd.sdft import SDFT
+from sdft_amd.signals import sine_sweep
+combo, m, hop, total, device = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+td = np.float32 if combo[:3] == "f32" else np.float64
+isz = np.dtype(td).itemsize
+xh = sine_sweep(total, dtype=td); yh = np.zeros(total, dtype=td)
+dh = np.zeros((hop, m), dtype=np.complex128 if combo[3:] == "f64" else np.complex64)
+out = {}
+for label, reg, rt in (("us_per_hop_host_pointers_runtime_copy", 0, 1), ("us_per_hop_host_pointers_registered", 1, 0)):
+    p = SDFT(m, "hann", 1.0, combo, device=device)
+    p.set_option("host_register", reg); p.set_option("host_copy", rt)
+    w = 0.0
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for i in range(0, total, hop):
+            p.api.sdft_n(p._p, hop, C.c_void_p(xh.ctypes.data + i * isz), C.c_void_p(dh.ctypes.data))
+            p.api.isdft_n(p._p, hop, C.c_void_p(dh.ctypes.data), C.c_void_p(yh.ctypes.data + i * isz))
+        w = (time.perf_counter() - t0) / (total // hop)
+    out[label] = round(w * 1e6, 1)
+    p.close()
+print(json.dumps(out))
+"""
+
+
+def _host_pointer_legs_in_a_child(combo, m, hop, total, device):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", _HOST_LEGS, os.path.dirname(os.path.abspath(__file__)), combo, str(m), str(hop), str(total), str(device)],
+                           capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        pass
+    return {"us_per_hop_host_pointers_runtime_copy": None, "us_per_hop_host_pointers_registered": None}
 
 
 def cpu_hop_baseline(np, sine_sweep, combo, td, m=1000, hop=100, total=2000):
