@@ -236,6 +236,41 @@ def test_double_samples_at_baseline_size(combo):
     assert 10 * np.log10(np.mean(x[2 * m:-lag] ** 2) / np.mean(err ** 2)) > (40 if combo == "f64f64" else 20)
 
 
+@pytest.mark.parametrize("combo", ["f32f64", "f64f64", "f32f32"])
+def test_ordered_sum_synthesis_at_n1e6_is_the_other_forms_bit_for_bit(combo):
+    """Round 6: synthesis by whole rows with the ordered sum (inverse_rows_ordered_kernel: loader waves, row slots in LDS, one adding wave)
+    at configs[1]'s size for the three type pairs a host meets -- all 1e6 samples bit-identical to the tiles' form (and, float samples
+    from double bins, to the tree sum with the rounding-interval proof), the first and the last rows against the oracle (chunks are
+    taken from the matrix' end first, the last chunk is ragged), and what the plan chooses by itself from 6 GB on."""
+    import torch
+    from sdft_amd.sdft import SDFT
+    n, m = 1_000_000, 1024
+    td, fd, fdx = O.combo_types(combo)
+    x = (sine_sweep(n, dtype=np.float64) + 0.25 * sine_sweep(n, channel=3, channels=8, dtype=np.float64)).astype(td)
+    with SDFT(m, "hann", 1.0, combo) as p:
+        if combo == "f32f32": p.set_option("float_carry_parallel", 1)          # (fills the matrix quickly; the synthesis is what is tested)
+        d = p.sdft(torch.from_numpy(x).cuda())
+        p.set_option("inverse_tune", 0)
+        y_auto = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 4                            # (8 and 16 GB: the static choice from 6 GB on)
+        p.set_option("inverse_ordered", -1); p.set_option("inverse_step", -1)
+        y_tiles = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") not in (3, 4)
+        p.set_option("inverse_ordered", 1)
+        y_ordered = p.isdft(d).cpu().numpy()
+        assert p.get_option("last_inverse_form") == 4
+        assert np.array_equal(y_tiles.view(np.uint8), y_ordered.view(np.uint8)) and np.array_equal(y_auto.view(np.uint8), y_ordered.view(np.uint8))
+        if combo == "f32f64":
+            p.set_option("inverse_ordered", -1); p.set_option("inverse_step", 1)
+            y_step = p.isdft(d).cpu().numpy()
+            assert p.get_option("last_inverse_form") == 3
+            assert np.array_equal(y_step.view(np.uint8), y_ordered.view(np.uint8))
+        port = O.best(m, "hann", 1.0, combo)
+        head = d[:3000].cpu().numpy(); tail = d[-3001:].cpu().numpy()
+        assert np.array_equal(y_ordered[:3000], port.isdft(head))
+        assert np.array_equal(y_ordered[-3001:], port.isdft(tail))
+
+
 def test_exact_carries_under_contention():
     """The inter-workgroup protocols of the exact-carry route (relay token, flow-mode flags, the stream-wait gate) rely on
     co-residency and bounded polls; round 3 tested their failure path through a debug bit only.  Here the call runs while
