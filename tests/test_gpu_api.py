@@ -792,8 +792,9 @@ def test_pipelined_calls_are_the_calls_one_after_the_other():
         outs = [torch.empty((n, m), dtype=torch.complex128, device="cuda") for _ in range(3)]
         for i in range(3):
             p.sdft(xd[i], outs[i])
-        host = np.empty((n, m), dtype=np.complex128)
-        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(outs[2].data_ptr()), C.c_size_t(host.nbytes), 2) == 0   # device to host, no other synchronisation
+        host_t = torch.empty((n, m), dtype=torch.complex128).pin_memory()      # (pinned: the runtime's path for PAGEABLE memory is the hazard of test_host_memory_is_never_handed_to_the_runtime_to_pin)
+        host = host_t.numpy()
+        assert hip.hipMemcpy(C.c_void_p(host_t.data_ptr()), C.c_void_p(outs[2].data_ptr()), C.c_size_t(host.nbytes), 2) == 0   # device to host, no other synchronisation
         assert p.get_option("pipelined_calls") == 2
         assert np.array_equal(host, got[1][0][2])
         p.synchronize()
@@ -966,9 +967,10 @@ def test_matrix_memory_chosen_for_its_store_rate():
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         xd = torch.from_numpy(x).cuda()
         p.api.sdft_n(p._p, n, C.c_void_p(xd.data_ptr()), C.c_void_p(ptr)); p.api.check()
-        got = np.empty((n, m), dtype=np.complex128)
+        got_t = torch.empty((n, m), dtype=torch.complex128).pin_memory()       # (pinned: not the runtime's pageable path)
+        got = got_t.numpy()
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+        assert hip.hipMemcpy(C.c_void_p(got_t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
     assert rel(got, want) <= 1e-11
     assert hip.hipFree(C.c_void_p(ptr)) == 0
     small = lib.sdft_hip_malloc_matrix(4096, 4, None)          # small buffers: one allocation, no probe
@@ -1008,8 +1010,9 @@ def test_matrix_as_the_best_window_of_one_allocation():
     with SDFT(m, "hann", 1.0, "f32f64") as p:
         xd = torch.from_numpy(x).cuda()
         p.api.sdft_n(p._p, n, C.c_void_p(xd.data_ptr()), C.c_void_p(ptr)); p.api.check()
-        got = np.empty((n, m), dtype=np.complex128)
-        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+        got_t = torch.empty((n, m), dtype=torch.complex128).pin_memory()       # (pinned: not the runtime's pageable path)
+        got = got_t.numpy()
+        assert hip.hipMemcpy(C.c_void_p(got_t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
     assert rel(got, want) <= 1e-11
     assert lib.sdft_hip_free_matrix(C.c_void_p(ptr + 16)) == -1 and b"not a window" in lib.sdft_hip_last_error()
     lib.sdft_hip_clear_error()

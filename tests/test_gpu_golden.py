@@ -144,9 +144,10 @@ def test_reference_test_wav_pattern_with_the_resident_kernel():
                 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
                 p.sdft(xd[:hop], d); p.isdft(d, y[:hop])          # (the kernel is alive: two resident calls)
                 assert p.get_option("resident_alive") == 1
-                host = np.empty(hop, dtype=np.float32)
+                host_t = torch.empty(hop, dtype=torch.float32).pin_memory()  # (pinned: not the runtime's path for pageable memory)
+                host = host_t.numpy()
                 t0 = time.perf_counter()
-                assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(y.data_ptr()), C.c_size_t(host.nbytes), 2) == 0
+                assert hip.hipMemcpy(C.c_void_p(host_t.data_ptr()), C.c_void_p(y.data_ptr()), C.c_size_t(host.nbytes), 2) == 0
                 waited = time.perf_counter() - t0
                 assert waited < 5e-3, waited                       # (200 us of idle time-out and the copy itself; 5 ms leaves room for a busy box)
                 # undo those two calls' effect on the comparison below: run the other plan's loop the same way
