@@ -148,6 +148,9 @@ template <typename TD, typename FD> static void sweep(size_t n, unsigned nbins, 
     run_ordered<TD, FD>("whole rows, ordered", a, 1024, 140 * 1024, d_sum, s);
     run_ordered<TD, FD>("whole rows, ordered", a, 2048, 140 * 1024, d_sum, s);
     run_ordered<TD, FD>("whole rows, ordered", a, 4096, 140 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 512, 158 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 1024, 158 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 2048, 158 * 1024, d_sum, s);
     run_ordered<TD, FD, 7>("whole rows, ordered", a, 2048, 140 * 1024, d_sum, s);
     run_ordered<TD, FD, 8>("whole rows, ordered", a, 2048, 140 * 1024, d_sum, s);
     run<TD, FD, 8, 2, 2>("8 rows x 512 B, 2 ahead", a, big, d_sum, s);
@@ -166,5 +169,6 @@ int main(int argc, char** argv)
   if (which == 0 || which == 3) sweep<double, double>(1000000, 1000, 1);
   if (which == 0 || which == 5) sweep<float, double>(1000000, 1024, 1);
   if (which == 0 || which == 6) sweep<float, double>(500000, 2048, 1);
+  if (which == 0 || which == 7) sweep<float, float>(1000000, 2048, 1);
   return 0;
 }

@@ -307,7 +307,9 @@ __global__ __launch_bounds__(kWave * kRowWavesMax) void inverse_rows2_kernel(Inv
 // every group of slots at its own place in its rows -- a group is handed over when its last loader has written (counter `filled`) and handed
 // back when its sums are stored (counter `freed`), so the loaders run up to NG groups ahead in LDS and three more in registers while the
 // chains of N dependent additions run 16 ... 64 abreast.  Rows of up to 8 KiB of terms (1024 double bins, 2048 float bins): with fewer than
-// 16 slots the adding wave cannot keep up with HBM (measured: 12 ... 14 cycles per term).
+// 16 slots the adding wave cannot keep up with HBM (measured: 12 ... 14 cycles of the nominal clock per term in the kernel, 6.5 float / 9 double for
+// a lone wave on an idle chip -- scripts/adding_wave_probe.hip; giving the adding wave its SIMD to itself changes nothing: 2048 float bins, 16 slots,
+// run at 5.6 ... 5.8 TB/s either way, at the adding wave's pace).
 // What the first versions lost, in the order found (each is a comment at its place below): a load whose other half nobody reads gives that
 // half's registers away and is waited for at once; a load behind a condition, a polling loop inside the ring's loop or a fetch at the loop's
 // top make the compiler wait for ALL loads that are on their way; a 64-bit division per load; and `nt ? __builtin_nontemporal_load(p) : *p`
@@ -333,8 +335,12 @@ template <typename FD, int NLOAD = 11> struct ordered_rows_geometry   // (NLOAD:
     size_t slots = (lds_budget - kFlagBytes - 256) / stride_bytes;
     if (slots > 64) slots = 64;
     if (slots < 16) return false;
-    G = 64 / ppr; if (G > slots / 4) G = (unsigned)(slots / 4);
+    // rows per group: at most 64 pieces to a group, at least four groups, as many slots in use as can be (19 fit beside 8 KiB rows: 6 x 3)
+    unsigned gmax = 64 / ppr; if (gmax > slots / 4) gmax = (unsigned)(slots / 4);
+    G = gmax;
+    for (unsigned g = gmax; g >= 1 && 4 * g >= 3 * gmax; --g) if ((slots / g) * g > (slots / G) * G) G = g;   // (small groups cost more than slots gain: 17 x 1 ran at 4.6 TB/s)
     NG = (unsigned)(slots / G);
+    if (NG > 64) NG = 64;
     lds_bytes = kFlagBytes + (size_t)NG * G * stride_bytes + 256;   // (slack: the adding wave fetches one stage past a row's end)
     return true;
   }
