@@ -148,6 +148,9 @@ template <typename TD, typename FD> static void sweep(size_t n, unsigned nbins, 
     run_ordered<TD, FD>("whole rows, ordered", a, 1024, 140 * 1024, d_sum, s);
     run_ordered<TD, FD>("whole rows, ordered", a, 2048, 140 * 1024, d_sum, s);
     run_ordered<TD, FD>("whole rows, ordered", a, 4096, 140 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered", a, 256, 140 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered", a, 768, 140 * 1024, d_sum, s);
+    run_ordered<TD, FD, 11>("whole rows, ordered", a, 1500, 140 * 1024, d_sum, s);
     run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 512, 158 * 1024, d_sum, s);
     run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 1024, 158 * 1024, d_sum, s);
     run_ordered<TD, FD, 11>("whole rows, ordered, 158 KB", a, 2048, 158 * 1024, d_sum, s);
@@ -170,5 +173,8 @@ int main(int argc, char** argv)
   if (which == 0 || which == 5) sweep<float, double>(1000000, 1024, 1);
   if (which == 0 || which == 6) sweep<float, double>(500000, 2048, 1);
   if (which == 0 || which == 7) sweep<float, float>(1000000, 2048, 1);
+  if (which == 8) sweep<float, double>(48000, 1024, 1);
+  if (which == 9) sweep<float, double>(48000, 1024, 0);
+  if (which == 10) sweep<float, double>(200000, 1024, 1);
   return 0;
 }
